@@ -1,0 +1,122 @@
+/*
+ * proxqp_hip.h -- C-ABI of libproxqp_hip.so: batched dense ProxQP on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of Simple-Robotics/proxsuite: the dense
+ * backend's `QP` / `BatchQP` init / update / solve driven by `solve_in_parallel`.
+ * ProxSuite has no FFI layer of its own; each entry point below replaces the C++
+ * member it cites (paths relative to the reference's include/proxsuite/proxqp/), and
+ * the header-only facade in include/proxsuite/ (C++17) plus the Python package
+ * proxsuite_amd/ rebuild the reference's public names on top of these calls.
+ *
+ * Conventions
+ *  - all matrices row-major fp64 (reference dense/fwd.hpp:16-19); a batch handle
+ *    owns B QPs of identical (n, n_eq, n_in, box, hessian type);
+ *  - `idx >= 0` addresses one QP, `idx == -1` the whole batch (arrays then carry a
+ *    leading [B] dimension);
+ *  - pointers may be host or device pointers (unified addressing);
+ *  - NULL array == the reference's `nullopt`; NaN scalar == `nullopt`;
+ *  - every function returns 0 on success, a negative pqp_error otherwise and leaves
+ *    a message for pqp_last_error(); solver outcomes are NOT errors, they are
+ *    reported in pqp_info.status (reference status.hpp:17-26);
+ *  - the library fails loudly (PQP_ERR_NO_DEVICE) when no HIP device is present:
+ *    there is no CPU fallback.
+ */
+#ifndef PROXQP_HIP_H
+#define PROXQP_HIP_H
+
+#include "pqp_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pqp_batch pqp_batch;
+
+enum pqp_error
+{
+  PQP_OK = 0,
+  PQP_ERR_INVALID_ARGUMENT = -1, /* the reference throws std::invalid_argument */
+  PQP_ERR_NO_DEVICE = -2,
+  PQP_ERR_HIP = -3,
+  PQP_ERR_UNSUPPORTED = -4
+};
+
+/* number of entries of the per-QP statistics record, see pqp_batch_get_stats */
+#define PQP_STATS_COUNT 16
+
+const char* pqp_last_error(void);
+int pqp_device_count(void);
+
+/* dense::BatchQP<T>(batch_size) + B x init_qp_in_place(dim, n_eq, n_in)
+ * (reference dense/wrapper.hpp:1263-1283) and the QP constructors (:140-333).
+ * `dense_backend` follows dense_backend_choice (:81-113); `device` is the HIP
+ * device ordinal. */
+int pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in,
+                     int box_constraints, int hessian_type, int dense_backend, int device,
+                     pqp_batch** out);
+void pqp_batch_destroy(pqp_batch* h);
+
+int64_t pqp_batch_size(const pqp_batch* h);
+int pqp_batch_dense_backend(const pqp_batch* h); /* QP::which_dense_backend() */
+
+/* QP::settings (public member, mutated by users between calls; re-read at every
+ * solve: reference benchmark/timings-parallel.cpp:79-88).  Host memory, valid until
+ * pqp_batch_destroy. */
+pqp_settings* pqp_batch_settings(pqp_batch* h, int64_t idx);
+
+/* QP::init (reference dense/wrapper.hpp:354-498 and, with boxes, :520-703). */
+int pqp_batch_init(pqp_batch* h, int64_t idx, const double* H, const double* g, const double* A,
+                   const double* b, const double* C, const double* l, const double* u,
+                   const double* l_box, const double* u_box, int compute_preconditioner,
+                   double rho, double mu_eq, double mu_in, double manual_minimal_H_eigenvalue);
+
+/* QP::update (reference dense/wrapper.hpp:723-807 / :831-918). */
+int pqp_batch_update(pqp_batch* h, int64_t idx, const double* H, const double* g, const double* A,
+                     const double* b, const double* C, const double* l, const double* u,
+                     const double* l_box, const double* u_box, int update_preconditioner,
+                     double rho, double mu_eq, double mu_in, double manual_minimal_H_eigenvalue);
+
+/* the warm-start half of QP::solve(x, y, z) (reference dense/wrapper.hpp:940-957,
+ * helpers.hpp:715-763): stores the guess and switches initial_guess to WARM_START. */
+int pqp_batch_warm_start(pqp_batch* h, int64_t idx, const double* x, const double* y,
+                         const double* z);
+
+/* QP::cleanup (reference dense/wrapper.hpp:958-962). */
+int pqp_batch_cleanup(pqp_batch* h, int64_t idx);
+
+/* Runs the queued init/update work (Ruiz equilibration, reference helpers.hpp:500-667)
+ * on the device.  pqp_batch_solve calls it implicitly; call it explicitly to keep
+ * setup out of a timed solve, as the reference bills it to setup_time. */
+int pqp_batch_flush(pqp_batch* h);
+
+/* dense::solve_in_parallel(BatchQP&) (reference parallel/qp_solve.hpp:41-59):
+ * QP::solve() on every QP of the batch, one workgroup per QP.  Synchronous. */
+int pqp_batch_solve(pqp_batch* h);
+
+/* QP::results (x, y, z, se, si, info); any output pointer may be NULL. */
+int pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z, double* se,
+                          double* si, pqp_info* info);
+
+/* device pointers of the result arrays ([B][n], [B][n_eq], [B][n_c]) for consumers that
+ * keep the solution on the GPU (the QPLayer forward). */
+int pqp_batch_result_device_ptrs(pqp_batch* h, double** x, double** y, double** z);
+
+/* scaled model and equilibration of one QP (testing / reference
+ * test/src/dense_ruiz_equilibration.cpp) */
+int pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A, double* b,
+                         double* C, double* l, double* u, double* delta, double* c);
+
+/* per-QP device statistics of the last solve: [B][PQP_STATS_COUNT] int64
+ * (cycles per phase and event counters, see proxsuite_amd/csrc/pqp_solver.hpp ST_*) */
+int pqp_batch_get_stats(pqp_batch* h, int64_t* stats);
+
+/* device time of the last solve kernel in milliseconds (HIP events on the launch stream) */
+double pqp_batch_last_solve_ms(const pqp_batch* h);
+/* bytes of dynamic LDS and threads per workgroup chosen for this batch */
+int pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PROXQP_HIP_H */

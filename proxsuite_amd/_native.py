@@ -1,0 +1,248 @@
+"""ctypes binding of the C-ABI in include/proxqp_hip.h (libproxqp_hip.so).
+
+`load()` only ever opens proxsuite_amd/csrc/libproxqp_hip.so -- the HIP build for gfx950 --
+and raises if it is missing or if no HIP device is present: there is no CPU fallback in the
+product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from ._ctypes_defs import pqp_info, pqp_settings
+
+PQP_STATS_COUNT = 16
+STAT_NAMES = ("cyc_total", "cyc_scale", "cyc_factor_h", "cyc_zg", "cyc_schur", "cyc_kkt_solve",
+              "cyc_residual", "cyc_linesearch", "cyc_global_res", "cyc_newton_misc", "n_newton",
+              "n_schur_fact", "n_new_rows", "n_kkt_solves", "n_ls_breakpoints", "n_active_final")
+
+_DP = C.POINTER(C.c_double)
+NAN = float("nan")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class NativeLib:
+    """Prototypes of every symbol include/proxqp_hip.h declares."""
+
+    SYMBOLS = ("pqp_last_error", "pqp_device_count", "pqp_batch_create", "pqp_batch_destroy",
+               "pqp_batch_size", "pqp_batch_dense_backend", "pqp_batch_settings", "pqp_batch_init",
+               "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_flush",
+               "pqp_batch_solve", "pqp_batch_get_results", "pqp_batch_result_device_ptrs",
+               "pqp_batch_get_scaled", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
+               "pqp_batch_launch_config")
+
+    def __init__(self, path):
+        self.path = str(path)
+        L = C.CDLL(self.path)
+        vp = C.c_void_p
+        L.pqp_last_error.restype = C.c_char_p
+        L.pqp_device_count.restype = C.c_int
+        L.pqp_batch_create.argtypes = [C.c_int64] * 4 + [C.c_int] * 4 + [C.POINTER(vp)]
+        L.pqp_batch_destroy.argtypes = [vp]
+        L.pqp_batch_destroy.restype = None
+        L.pqp_batch_size.argtypes = [vp]
+        L.pqp_batch_size.restype = C.c_int64
+        L.pqp_batch_dense_backend.argtypes = [vp]
+        L.pqp_batch_settings.argtypes = [vp, C.c_int64]
+        L.pqp_batch_settings.restype = C.POINTER(pqp_settings)
+        for name in ("pqp_batch_init", "pqp_batch_update"):
+            getattr(L, name).argtypes = [vp, C.c_int64] + [_DP] * 9 + [C.c_int] + [C.c_double] * 4
+        L.pqp_batch_warm_start.argtypes = [vp, C.c_int64] + [_DP] * 3
+        L.pqp_batch_cleanup.argtypes = [vp, C.c_int64]
+        L.pqp_batch_flush.argtypes = [vp]
+        L.pqp_batch_solve.argtypes = [vp]
+        L.pqp_batch_get_results.argtypes = [vp, C.c_int64] + [_DP] * 5 + [C.POINTER(pqp_info)]
+        L.pqp_batch_result_device_ptrs.argtypes = [vp] + [C.POINTER(_DP)] * 3
+        L.pqp_batch_get_scaled.argtypes = [vp, C.c_int64] + [_DP] * 9
+        L.pqp_batch_get_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.pqp_batch_last_solve_ms.argtypes = [vp]
+        L.pqp_batch_last_solve_ms.restype = C.c_double
+        L.pqp_batch_launch_config.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        self.L = L
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.L.pqp_last_error().decode(errors="replace")
+            if rc == -1:
+                raise ValueError(msg)  # the reference throws std::invalid_argument
+            raise NativeError("libproxqp_hip error %d: %s" % (rc, msg))
+
+
+_lib = None
+
+
+def hip_library_path() -> Path:
+    return Path(__file__).resolve().parent / "csrc" / "libproxqp_hip.so"
+
+
+def load() -> NativeLib:
+    """The product path: the gfx950 HIP library, or a loud failure."""
+    global _lib
+    if _lib is None:
+        p = hip_library_path()
+        if not p.exists():
+            raise NativeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+        lib = NativeLib(p)
+        if lib.L.pqp_device_count() <= 0:
+            raise NativeError("no HIP device visible: proxsuite_amd runs on MI355X only (no CPU fallback)")
+        _lib = lib
+    return _lib
+
+
+def _as_array(a, shape, name):
+    """numpy / torch (host or ROCm) -> (keepalive, pointer).  None or size 0 == nullopt."""
+    if a is None:
+        return None, None
+    if hasattr(a, "data_ptr"):  # torch tensor: zero-copy when fp64 contiguous, host or device
+        import torch
+        if a.numel() == 0:
+            return None, None
+        t = a.detach()
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            t = t.to(torch.float64).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("wrong argument size: %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+        return t, C.cast(t.data_ptr(), _DP)
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if arr.size == 0:
+        return None, None
+    if tuple(arr.shape) != tuple(shape):
+        raise ValueError("wrong argument size: %s has shape %s, expected %s" % (name, arr.shape, tuple(shape)))
+    return arr, arr.ctypes.data_as(_DP)
+
+
+def _opt(v):
+    return NAN if v is None else float(v)
+
+
+class Batch:
+    """Thin object wrapper over a pqp_batch handle (one device, B QPs of identical sizes)."""
+
+    def __init__(self, batch_size, n, n_eq, n_in, box_constraints=False, hessian_type=1, dense_backend=0,
+                 device=0, lib: NativeLib | None = None):
+        self.lib = lib if lib is not None else load()
+        self.B, self.n, self.n_eq, self.n_in = int(batch_size), int(n), int(n_eq), int(n_in)
+        self.box = bool(box_constraints)
+        self.n_c = self.n_in + (self.n if self.box else 0)
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.pqp_batch_create(self.B, self.n, self.n_eq, self.n_in, int(self.box),
+                                                   int(hessian_type), int(dense_backend), int(device),
+                                                   C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.L.pqp_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dense_backend(self):
+        return self.lib.L.pqp_batch_dense_backend(self._h)
+
+    def settings(self, idx) -> pqp_settings:
+        p = self.lib.L.pqp_batch_settings(self._h, int(idx))
+        if not p:
+            raise IndexError(idx)
+        return p.contents
+
+    def _shapes(self, idx):
+        pre = (self.B,) if idx < 0 else ()
+        n, ne, ni = self.n, self.n_eq, self.n_in
+        return dict(H=pre + (n, n), g=pre + (n,), A=pre + (ne, n), b=pre + (ne,), C=pre + (ni, n),
+                    l=pre + (ni,), u=pre + (ni,), l_box=pre + (n,), u_box=pre + (n,))
+
+    def _setup(self, fn, idx, H, g, A, b, Cm, l, u, l_box, u_box, flag, rho, mu_eq, mu_in, min_eig):
+        sh = self._shapes(idx)
+        keep, ptrs = [], []
+        for name, arr in (("H", H), ("g", g), ("A", A), ("b", b), ("C", Cm), ("l", l), ("u", u),
+                          ("l_box", l_box), ("u_box", u_box)):
+            k, p = _as_array(arr, sh[name], name)
+            keep.append(k)
+            ptrs.append(p)
+        self.lib.check(fn(self._h, int(idx), *ptrs, int(bool(flag)), _opt(rho), _opt(mu_eq), _opt(mu_in),
+                          _opt(min_eig)))
+
+    def init(self, idx=-1, H=None, g=None, A=None, b=None, C=None, l=None, u=None, l_box=None, u_box=None,
+             compute_preconditioner=True, rho=None, mu_eq=None, mu_in=None, manual_minimal_H_eigenvalue=None):
+        self._setup(self.lib.L.pqp_batch_init, idx, H, g, A, b, C, l, u, l_box, u_box,
+                    compute_preconditioner, rho, mu_eq, mu_in, manual_minimal_H_eigenvalue)
+
+    def update(self, idx=-1, H=None, g=None, A=None, b=None, C=None, l=None, u=None, l_box=None, u_box=None,
+               update_preconditioner=False, rho=None, mu_eq=None, mu_in=None,
+               manual_minimal_H_eigenvalue=None):
+        self._setup(self.lib.L.pqp_batch_update, idx, H, g, A, b, C, l, u, l_box, u_box,
+                    update_preconditioner, rho, mu_eq, mu_in, manual_minimal_H_eigenvalue)
+
+    def warm_start(self, idx=-1, x=None, y=None, z=None):
+        pre = (self.B,) if idx < 0 else ()
+        kx, px = _as_array(x, pre + (self.n,), "x")
+        ky, py = _as_array(y, pre + (self.n_eq,), "y")
+        kz, pz = _as_array(z, pre + (self.n_c,), "z")
+        self.lib.check(self.lib.L.pqp_batch_warm_start(self._h, int(idx), px, py, pz))
+
+    def cleanup(self, idx=-1):
+        self.lib.check(self.lib.L.pqp_batch_cleanup(self._h, int(idx)))
+
+    def flush(self):
+        self.lib.check(self.lib.L.pqp_batch_flush(self._h))
+
+    def solve(self):
+        self.lib.check(self.lib.L.pqp_batch_solve(self._h))
+
+    @property
+    def last_solve_ms(self):
+        return self.lib.L.pqp_batch_last_solve_ms(self._h)
+
+    def results(self, idx=-1):
+        pre = (self.B,) if idx < 0 else ()
+        x = np.zeros(pre + (self.n,))
+        y = np.zeros(pre + (self.n_eq,))
+        z = np.zeros(pre + (self.n_c,))
+        se = np.zeros(pre + (self.n_eq,))
+        si = np.zeros(pre + (self.n_c,))
+        info = (pqp_info * self.B)() if idx < 0 else pqp_info()
+        p = lambda a: a.ctypes.data_as(_DP)
+        ip = C.cast(info, C.POINTER(pqp_info)) if idx < 0 else C.byref(info)
+        self.lib.check(self.lib.L.pqp_batch_get_results(self._h, int(idx), p(x), p(y), p(z), p(se), p(si), ip))
+        return x, y, z, se, si, info
+
+    def scaled(self, idx):
+        n, ne, ni = self.n, self.n_eq, self.n_in
+        out = dict(H=np.zeros((n, n)), g=np.zeros(n), A=np.zeros((ne, n)), b=np.zeros(ne), C=np.zeros((ni, n)),
+                   l=np.zeros(ni), u=np.zeros(ni), delta=np.zeros(n + ne + self.n_c))
+        c = C.c_double(0)
+        p = lambda a: a.ctypes.data_as(_DP)
+        self.lib.check(self.lib.L.pqp_batch_get_scaled(
+            self._h, int(idx), p(out["H"]), p(out["g"]), p(out["A"]), p(out["b"]), p(out["C"]), p(out["l"]),
+            p(out["u"]), p(out["delta"]), C.cast(C.byref(c), _DP)))
+        out["c"] = c.value
+        return out
+
+    def stats(self):
+        a = np.zeros((self.B, PQP_STATS_COUNT), dtype=np.int64)
+        self.lib.check(self.lib.L.pqp_batch_get_stats(self._h, a.ctypes.data_as(C.POINTER(C.c_int64))))
+        return a
+
+    def launch_config(self):
+        t = C.c_int(0)
+        b = C.c_int64(0)
+        self.lib.check(self.lib.L.pqp_batch_launch_config(self._h, C.byref(t), C.byref(b)))
+        return t.value, b.value
+
+    def result_device_ptrs(self):
+        x, y, z = _DP(), _DP(), _DP()
+        self.lib.check(self.lib.L.pqp_batch_result_device_ptrs(self._h, C.byref(x), C.byref(y), C.byref(z)))
+        return tuple(C.cast(p, C.c_void_p).value for p in (x, y, z))

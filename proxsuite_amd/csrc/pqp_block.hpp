@@ -1,0 +1,588 @@
+// Workgroup-cooperative building blocks of the batched ProxQP kernels (gfx950).
+//
+// Execution model: ONE workgroup of NT threads (NT/64 wavefronts) owns ONE QP.
+// Per-QP vectors live in LDS; per-QP matrices live in HBM as contiguous row-major
+// panels and are always walked so that consecutive lanes read consecutive
+// addresses of one row (coalesced 512-B wave transactions):
+//   * every mat-vec is "thread-per-output, loop over the inner index"
+//     (out[j] = sum_k M[k][j] v[k]); both orientations of A and C are stored
+//     so that A*x, A^T*y, C*x, C^T*z all take this form and need no cross-lane
+//     reduction;
+//   * the inner index is split across the wavefronts of the workgroup and the
+//     partial sums meet in LDS.
+// Scalars that steer control flow are computed redundantly by every thread
+// from LDS broadcasts, so all branches are workgroup-uniform.
+#ifndef PQP_BLOCK_HPP
+#define PQP_BLOCK_HPP
+
+#include <hip/hip_runtime.h>
+
+// Explicit address spaces: the shared routines below are real (non-inlined)
+// functions so that the persistent solve kernel stays small enough for the
+// instruction cache; typing their pointer parameters keeps LDS traffic on ds_*
+// and HBM traffic on global_* instructions instead of flat_*.
+#ifndef PQP_LDS
+#define PQP_LDS __attribute__((address_space(3)))
+#define PQP_GLOBAL __attribute__((address_space(1)))
+#endif
+// Inlining policy of the shared dense routines (see DESIGN.md "code size vs
+// registers"): real calls keep the kernel small but force every uniform scalar
+// of the caller into VGPRs across the call; inlining does the opposite.
+#ifndef PQP_CALL
+#define PQP_CALL __forceinline__
+#endif
+
+namespace pqp {
+
+typedef PQP_LDS double* lptr;
+typedef const PQP_LDS double* clptr;
+typedef PQP_LDS int* liptr;
+typedef const PQP_LDS int* cliptr;
+typedef PQP_GLOBAL double* gptr;
+typedef const PQP_GLOBAL double* cgptr;
+
+constexpr int WAVE = 64;
+constexpr int PQP_NB = 16; // panel width of the blocked LDL^T / substitutions
+
+__device__ __forceinline__ double
+wave_sum(double v)
+{
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1)
+    v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double
+wave_max(double v)
+{
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1)
+    v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double
+wave_min(double v)
+{
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1)
+    v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Block reductions with a parity-toggled LDS scratch: ONE barrier per reduction.
+// `red` points at 2 * 4 * (NT/64) doubles.  Every thread of the block must call
+// these in the same order (the parity lives in a register).
+template<int NT>
+struct Reducer
+{
+  static constexpr int NW = NT / WAVE;
+  lptr red;
+  int parity;
+  __device__ __forceinline__ Reducer(lptr scratch)
+    : red(scratch)
+    , parity(0)
+  {
+  }
+  __device__ __forceinline__ lptr slot() { return red + parity * 4 * NW; }
+
+  __device__ __forceinline__ double sum(double v)
+  {
+    v = wave_sum(v);
+    lptr s = slot();
+    if ((threadIdx.x & (WAVE - 1)) == 0)
+      s[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      r += s[w];
+    parity ^= 1;
+    return r;
+  }
+  __device__ __forceinline__ double max(double v)
+  {
+    v = wave_max(v);
+    lptr s = slot();
+    if ((threadIdx.x & (WAVE - 1)) == 0)
+      s[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    double r = s[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+      r = fmax(r, s[w]);
+    parity ^= 1;
+    return r;
+  }
+  __device__ __forceinline__ double min(double v)
+  {
+    v = wave_min(v);
+    lptr s = slot();
+    if ((threadIdx.x & (WAVE - 1)) == 0)
+      s[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    double r = s[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+      r = fmin(r, s[w]);
+    parity ^= 1;
+    return r;
+  }
+  // two sums in one barrier
+  __device__ __forceinline__ void sum2(double& a, double& b)
+  {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    lptr s = slot();
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+      s[threadIdx.x / WAVE] = a;
+      s[NW + threadIdx.x / WAVE] = b;
+    }
+    __syncthreads();
+    double ra = 0, rb = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      ra += s[w];
+      rb += s[NW + w];
+    }
+    a = ra;
+    b = rb;
+    parity ^= 1;
+  }
+  // up to three maxima in one barrier
+  __device__ __forceinline__ void max3(double& a, double& b, double& c)
+  {
+    a = wave_max(a);
+    b = wave_max(b);
+    c = wave_max(c);
+    lptr s = slot();
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+      s[threadIdx.x / WAVE] = a;
+      s[NW + threadIdx.x / WAVE] = b;
+      s[2 * NW + threadIdx.x / WAVE] = c;
+    }
+    __syncthreads();
+    double ra = s[0], rb = s[NW], rc = s[2 * NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      ra = fmax(ra, s[w]);
+      rb = fmax(rb, s[NW + w]);
+      rc = fmax(rc, s[2 * NW + w]);
+    }
+    a = ra;
+    b = rb;
+    c = rc;
+    parity ^= 1;
+  }
+  // four sums in one barrier
+  __device__ __forceinline__ void sum4(double& a, double& b, double& c, double& d)
+  {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    d = wave_sum(d);
+    lptr s = slot();
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+      int w = threadIdx.x / WAVE;
+      s[w] = a;
+      s[NW + w] = b;
+      s[2 * NW + w] = c;
+      s[3 * NW + w] = d;
+    }
+    __syncthreads();
+    double ra = 0, rb = 0, rc = 0, rd = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      ra += s[w];
+      rb += s[NW + w];
+      rc += s[2 * NW + w];
+      rd += s[3 * NW + w];
+    }
+    a = ra;
+    b = rb;
+    c = rc;
+    d = rd;
+    parity ^= 1;
+  }
+};
+
+// infinity norm of an LDS vector
+template<int NT>
+__device__ __forceinline__ double
+block_inf_norm(Reducer<NT>& R, clptr v, int n)
+{
+  double m = 0;
+  for (int i = threadIdx.x; i < n; i += NT)
+    m = fmax(m, fabs(v[i]));
+  return R.max(m);
+}
+
+// ---------------------------------------------------------------------------
+// gemv:  out[j] = sum_{k<K} M[row(k)*ld + col(j)] * v[k]     for j < J
+// M in HBM (row-major, row contiguous), v / out / part in LDS.  The J outputs are
+// tiled over 64-lane column chunks, the K range is split across the wavefronts that
+// share a chunk and the partial sums meet in `part` (gemv_part_len() doubles).
+// Optional gathers pick an active subset of rows / columns without copies:
+//   index(i) = i                         when i <  split
+//            = split + map[i - split]    when i >= split      (map in LDS)
+// pass map == nullptr for the identity.  Two barriers inside (after the partial
+// sums, after `out` is written); `out` may alias `v`.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int
+gemv_part_len(int nt, int jmax)
+{
+  return (nt > jmax ? nt : jmax) + WAVE;
+}
+
+template<int NT>
+__device__ PQP_CALL void
+gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap, int rowsplit,
+     cliptr colmap, int colsplit)
+{
+  constexpr int NW = NT / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x / WAVE;
+  const int JC = (J + WAVE - 1) / WAVE; // column chunks
+  int KS = 1;                           // k-splits per chunk
+  if (JC > 0 && JC <= NW) {
+    KS = NW / JC;
+    const int chunk = wid % JC;
+    const int ks = wid / JC;
+    if (ks < KS) {
+      const int j = chunk * WAVE + lane;
+      if (j < J) {
+        int cj = j;
+        if (colmap && j >= colsplit)
+          cj = colsplit + colmap[j - colsplit];
+        cgptr col = M + cj;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int k = ks;
+        if (rowmap) {
+          for (; k < K; k += KS) {
+            int rk = (k < rowsplit) ? k : rowsplit + rowmap[k - rowsplit];
+            a0 = fma(col[(long)rk * ld], v[k], a0);
+          }
+        } else {
+          const long step = (long)KS * ld;
+          cgptr p = col + (long)k * ld;
+          for (; k + 3 * KS < K; k += 4 * KS) {
+            a0 = fma(p[0], v[k], a0);
+            a1 = fma(p[step], v[k + KS], a1);
+            a2 = fma(p[2 * step], v[k + 2 * KS], a2);
+            a3 = fma(p[3 * step], v[k + 3 * KS], a3);
+            p += 4 * step;
+          }
+          for (; k < K; k += KS) {
+            a0 = fma(p[0], v[k], a0);
+            p += step;
+          }
+        }
+        part[ks * J + j] = (a0 + a1) + (a2 + a3);
+      }
+    }
+  } else {
+    // more chunks than waves: each wave loops over its chunks, no k-split
+    for (int chunk = wid; chunk < JC; chunk += NW) {
+      const int j = chunk * WAVE + lane;
+      if (j < J) {
+        int cj = j;
+        if (colmap && j >= colsplit)
+          cj = colsplit + colmap[j - colsplit];
+        cgptr col = M + cj;
+        double a0 = 0, a1 = 0;
+        for (int k = 0; k < K; ++k) {
+          int rk = k;
+          if (rowmap && k >= rowsplit)
+            rk = rowsplit + rowmap[k - rowsplit];
+          if (k & 1)
+            a1 = fma(col[(long)rk * ld], v[k], a1);
+          else
+            a0 = fma(col[(long)rk * ld], v[k], a0);
+        }
+        part[j] = a0 + a1;
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += NT) {
+    double s = part[j];
+    for (int q = 1; q < KS; ++q)
+      s += part[q * J + j];
+    out[j] = s;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Blocked left-looking LDL^T of a symmetric m x m matrix stored FULL row-major
+// in HBM (leading dimension ld, m <= NT: thread i owns row i of the panel in
+// registers).  On exit (mirrored storage):
+//   M[k][i], k<i, outside the diagonal blocks : L[i][k]     (upper part = L^T)
+//   M[i][k], k<i, outside the diagonal blocks : L[i][k]     (lower part = L)
+//   M[j][j]                                   : d_j  (also d[j] in LDS)
+//   diagonal 16x16 blocks: strict lower = inv(L_bb), strict upper = inv(L_bb)^T
+// so that both triangular sweeps are row-coalesced axpy passes and the
+// dependent chain inside a diagonal block collapses to a 16x16 mat-vec.
+// Restates what the reference's factorization computes
+// (reference include/proxsuite/linalg/dense/factorize.hpp:89-148, 215-280:
+// D from the diagonal recurrence, L = unit lower) with a static pivot order.
+// `top` is LDS scratch of PQP_NB*PQP_NB + PQP_NB*PQP_NB doubles.
+// ---------------------------------------------------------------------------
+template<int NT>
+__device__ PQP_CALL void
+ldlt_factor(gptr M, int ld, int m, lptr d, lptr top)
+{
+  constexpr int NB = PQP_NB;
+  const int i = threadIdx.x;
+  lptr tl = top + NB * NB; // normalised top block (unit lower), for the inverse
+  for (int j0 = 0; j0 < m; j0 += NB) {
+    const int nb = (m - j0 < NB) ? (m - j0) : NB;
+    double p[NB];
+    const bool row_active = (i >= j0 && i < m);
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      p[c] = 0.0;
+    if (row_active) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        if (c < nb && i >= j0 + c)
+          p[c] = M[(long)(j0 + c) * ld + i];
+      // left-looking update with the already factorised columns k < j0
+      for (int k = 0; k < j0; ++k) {
+        cgptr rowk = M + (long)k * ld;
+        double lik = rowk[i] * d[k];
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c < nb)
+            p[c] = fma(-lik, rowk[j0 + c], p[c]);
+      }
+    }
+    // in-panel right-looking elimination; one barrier per column
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      if (c < nb) {
+        if (row_active && i >= j0 + c && i < j0 + nb)
+          top[c * NB + (i - j0)] = p[c];
+        __syncthreads();
+        if (row_active && i > j0 + c) {
+          double dc = top[c * NB + c];
+          double lic = p[c] / dc;
+#pragma unroll
+          for (int c2 = c + 1; c2 < NB; ++c2)
+            if (c2 < nb && i >= j0 + c2)
+              p[c2] = fma(-lic, top[c * NB + c2], p[c2]);
+          p[c] = lic;
+        }
+      }
+    }
+    // write back: diagonal, upper mirror (coalesced), lower rows, LDS copy of T
+    if (row_active) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        if (c < nb) {
+          if (i == j0 + c) {
+            d[i] = p[c];
+            M[(long)i * ld + i] = p[c];
+          } else if (i > j0 + c) {
+            if (i >= j0 + nb) {
+              M[(long)(j0 + c) * ld + i] = p[c];
+              M[(long)i * ld + (j0 + c)] = p[c];
+            } else {
+              tl[(i - j0) * NB + c] = p[c];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // inverse of the unit-lower diagonal block: thread c solves column c
+    if (i >= j0 && i < j0 + nb) {
+      const int c = i - j0;
+      double xcol[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+        xcol[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 1; r < NB; ++r) {
+        if (r < nb && r > c) {
+          double acc = 0;
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+            if (q >= c && q < r)
+              acc = fma(tl[r * NB + q], xcol[q], acc);
+          xcol[r] = -acc;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+        if (r < nb && r > c) {
+          M[(long)(j0 + r) * ld + (j0 + c)] = xcol[r]; // inv(L_bb)[r][c]
+          M[(long)(j0 + c) * ld + (j0 + r)] = xcol[r]; // its transpose
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Solve (L D L^T) x = v in place for an LDS vector v (length m <= NT) using the
+// mirrored factor produced by ldlt_factor.  Restates reference
+// include/proxsuite/linalg/dense/solve.hpp:15-26 (forward unit-lower sweep,
+// diagonal scaling, backward sweep).  `blk` is LDS scratch of 2*PQP_NB doubles.
+// ---------------------------------------------------------------------------
+template<int NT>
+__device__ PQP_CALL void
+ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
+{
+  constexpr int NB = PQP_NB;
+  const int a = threadIdx.x;
+  lptr yb = blk + NB;
+  double val = (a < m) ? v[a] : 0.0;
+  // forward: L y = v
+  for (int j0 = 0; j0 < m; j0 += NB) {
+    const int nb = (m - j0 < NB) ? (m - j0) : NB;
+    const bool inblk = (a >= j0 && a < j0 + nb);
+    if (inblk)
+      blk[a - j0] = val;
+    __syncthreads();
+    if (inblk) {
+      const int c = a - j0;
+      cgptr row = M + (long)a * ld + j0;
+      double y = blk[c];
+      for (int c2 = 0; c2 < c; ++c2)
+        y = fma(row[c2], blk[c2], y);
+      val = y;
+      yb[c] = y;
+    }
+    __syncthreads();
+    if (a >= j0 + nb && a < m) {
+      double acc = val;
+      for (int c = 0; c < nb; ++c)
+        acc = fma(-M[(long)(j0 + c) * ld + a], yb[c], acc);
+      val = acc;
+    }
+  }
+  if (a < m)
+    val /= d[a];
+  // backward: L^T x = y
+  const int last = ((m - 1) / NB) * NB;
+  for (int j0 = last; j0 >= 0; j0 -= NB) {
+    const int nb = (m - j0 < NB) ? (m - j0) : NB;
+    const bool inblk = (a >= j0 && a < j0 + nb);
+    if (inblk)
+      blk[a - j0] = val;
+    __syncthreads();
+    if (inblk) {
+      const int c = a - j0;
+      cgptr row = M + (long)a * ld + j0;
+      double x = blk[c];
+      for (int c2 = c + 1; c2 < nb; ++c2)
+        x = fma(row[c2], blk[c2], x);
+      val = x;
+      yb[c] = x;
+    }
+    __syncthreads();
+    if (a < j0) {
+      double acc = val;
+      for (int c = 0; c < nb; ++c)
+        acc = fma(-M[(long)(j0 + c) * ld + a], yb[c], acc);
+      val = acc;
+    }
+  }
+  if (a < m)
+    v[a] = val;
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Explicit inverse of the unit-lower factor held in the mirrored storage of
+// ldlt_factor:  WL = L^{-1} (row-major, zeros above the diagonal, ones on it)
+// and WU = WL^T, both n x n with leading dimension ld.  With the inverse in both
+// orientations the primal-block solves become two gemv_t passes with no
+// dependent chain at all; it is computed once per factorisation of H + rho I.
+// ---------------------------------------------------------------------------
+template<int NT>
+__device__ PQP_CALL void
+tri_inverse(cgptr F, int ld, int n, gptr WL, gptr WU)
+{
+  constexpr int NB = PQP_NB;
+  for (int o = threadIdx.x; o < n * n; o += NT) {
+    int r = o / n, c = o - r * n;
+    double v = (r == c) ? 1.0 : 0.0;
+    WL[(long)r * ld + c] = v;
+    WU[(long)r * ld + c] = v;
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += NB) {
+    const int nb = (n - i0 < NB) ? (n - i0) : NB;
+    // diagonal block: inv(L_bb) sits in the strict lower part of F's diagonal block
+    for (int o = threadIdx.x; o < nb * nb; o += NT) {
+      int r = o / nb, c = o - r * nb;
+      if (r > c) {
+        double v = F[(long)(i0 + r) * ld + (i0 + c)];
+        WL[(long)(i0 + r) * ld + (i0 + c)] = v;
+        WU[(long)(i0 + c) * ld + (i0 + r)] = v;
+      }
+    }
+    if (i0 > 0) {
+      const int cnt = nb * i0;
+      // phase A: Y[r][q] = sum_{k=q}^{i0-1} L[i0+r][k] * X[k][q]   -> parked in WU[q][i0+r]
+      for (int o = threadIdx.x; o < cnt; o += NT) {
+        int r = o / i0, q = o - r * i0;
+        cgptr lrow = F + (long)(i0 + r) * ld;
+        double acc = 0;
+        for (int k = q; k < i0; ++k)
+          acc = fma(lrow[k], WL[(long)k * ld + q], acc);
+        WU[(long)q * ld + (i0 + r)] = acc;
+      }
+      __syncthreads();
+      // phase B: X[i0+r][q] = - sum_{r2<=r} inv(L_bb)[r][r2] * Y[r2][q]   -> WL
+      for (int o = threadIdx.x; o < cnt; o += NT) {
+        int r = o / i0, q = o - r * i0;
+        cgptr yq = WU + (long)q * ld + i0;
+        double s = yq[r];
+        for (int r2 = 0; r2 < r; ++r2)
+          s = fma(F[(long)(i0 + r) * ld + (i0 + r2)], yq[r2], s);
+        WL[(long)(i0 + r) * ld + q] = -s;
+      }
+      __syncthreads();
+      // phase C: mirror into WU
+      for (int o = threadIdx.x; o < cnt; o += NT) {
+        int r = o / i0, q = o - r * i0;
+        WU[(long)q * ld + (i0 + r)] = WL[(long)(i0 + r) * ld + q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// exclusive prefix count of a per-thread flag over the block; returns this
+// thread's rank among the set flags and the total through `total`.
+// `cnt` is LDS scratch of NT/64 + 1 ints.
+template<int NT>
+__device__ __forceinline__ int
+block_rank(bool flag, liptr cnt, int& total)
+{
+  constexpr int NW = NT / WAVE;
+  unsigned long long m = __ballot(flag ? 1 : 0);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x / WAVE;
+  int before = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (WAVE - lane))));
+  if (lane == 0)
+    cnt[wid] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    int c = cnt[w];
+    if (w < wid)
+      off += c;
+    tot += c;
+  }
+  total = tot;
+  __syncthreads();
+  return off + before;
+}
+
+} // namespace pqp
+
+#endif

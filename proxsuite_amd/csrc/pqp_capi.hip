@@ -1,0 +1,705 @@
+// libproxqp_hip.so -- host side of the C-ABI declared in include/proxqp_hip.h:
+// HBM layout of a batch, the host mirror of the reference's settings state machine
+// (dense/wrapper.hpp init/update, helpers.hpp:174-189, 678-763) and the launches of
+// the two kernels (setup = init/update + Ruiz; solve = qp_solve on every QP).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "proxqp_hip.h"
+#include "pqp_solver.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int
+fail(int code, const std::string& msg)
+{
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(PQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+bool
+absent(double v)
+{
+  return std::isnan(v);
+}
+
+// reference dense/wrapper.hpp:81-113
+int
+dense_backend_choice(int backend, int64_t dim, int64_t n_eq, int64_t n_in, bool box)
+{
+  if (backend != PQP_BACKEND_AUTOMATIC)
+    return backend;
+  int64_t n_constraints = n_in + (box ? dim : 0);
+  double threshold = 1.5, frequence = 0.2, d = double(dim);
+  double PrimalDualLDLTCost =
+    0.5 * std::pow(double(n_eq) / d, 2) +
+    0.17 * (std::pow(double(n_eq) / d, 3) + std::pow(double(n_constraints) / d, 3)) +
+    frequence * std::pow(double(n_eq + n_constraints) / d, 2) / d;
+  double PrimalLDLTCost = threshold * ((0.5 * double(n_eq) + double(n_constraints)) / d + frequence / d);
+  return PrimalDualLDLTCost > PrimalLDLTCost ? PQP_BACKEND_PRIMAL_LDLT : PQP_BACKEND_PRIMAL_DUAL_LDLT;
+}
+
+} // namespace
+
+template<int NT>
+__global__ __launch_bounds__(NT) void
+pqp_setup_kernel(pqp::Batch batch)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  pqp::setup_body<NT>(batch, (long)blockIdx.x, (pqp::lptr)smem);
+}
+
+// 1024 threads per CU resident (4 waves per SIMD -> at most 128 VGPRs per lane)
+template<int NT>
+__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void
+pqp_solve_kernel(pqp::Batch batch)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  pqp::solve_body<NT>(batch, (long)blockIdx.x, (pqp::lptr)smem);
+}
+
+struct pqp_batch
+{
+  pqp::Batch dev{};
+  int device = 0;
+  int nt = 256;
+  int backend = PQP_BACKEND_PRIMAL_DUAL_LDLT;
+  size_t lds_solve = 0, lds_setup = 0;
+  std::vector<pqp_settings> settings;
+  std::vector<pqp::Cmd> cmd;
+  std::vector<char> is_initialized;
+  bool settings_dirty = true;
+  bool cmd_pending = false;
+  pqp_settings* d_settings = nullptr;
+  pqp::Cmd* d_cmd = nullptr;
+  std::vector<void*> allocs;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+};
+
+namespace {
+
+template<typename T>
+int
+dalloc(pqp_batch* h, T** p, size_t count)
+{
+  void* q = nullptr;
+  size_t bytes = (count ? count : 1) * sizeof(T);
+  HIP_TRY(hipMalloc(&q, bytes));
+  HIP_TRY(hipMemset(q, 0, bytes));
+  h->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return PQP_OK;
+}
+
+template<int NT>
+int
+launch_setup(pqp_batch* h)
+{
+  if (h->lds_setup > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_setup_kernel<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_setup));
+  hipLaunchKernelGGL(pqp_setup_kernel<NT>, dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, nullptr,
+                     h->dev);
+  HIP_TRY(hipGetLastError());
+  return PQP_OK;
+}
+
+template<int NT>
+int
+launch_solve(pqp_batch* h)
+{
+  if (h->lds_solve > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
+  HIP_TRY(hipEventRecord(h->ev0, nullptr));
+  hipLaunchKernelGGL(pqp_solve_kernel<NT>, dim3((unsigned)h->dev.B), dim3(NT), h->lds_solve, nullptr,
+                     h->dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, nullptr));
+  return PQP_OK;
+}
+
+int
+upload_settings(pqp_batch* h)
+{
+  if (!h->settings_dirty)
+    return PQP_OK;
+  HIP_TRY(hipMemcpy(h->d_settings, h->settings.data(), h->settings.size() * sizeof(pqp_settings),
+                    hipMemcpyHostToDevice));
+  // the host copy stays "dirty" for ever: users hold raw pointers into it and may
+  // write at any time (reference: qp.settings is a public member)
+  return PQP_OK;
+}
+
+int
+check_idx(pqp_batch* h, int64_t idx)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (idx < -1 || idx >= h->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+  return PQP_OK;
+}
+
+// copies `count` QPs worth of one model array
+int
+copy_in(double* dst_base, const double* src, int64_t idx, int64_t B, size_t per_qp)
+{
+  if (!src || per_qp == 0)
+    return PQP_OK;
+  if (idx < 0) {
+    HIP_TRY(hipMemcpy(dst_base, src, per_qp * size_t(B) * sizeof(double), hipMemcpyDefault));
+  } else {
+    HIP_TRY(hipMemcpy(dst_base + size_t(idx) * per_qp, src, per_qp * sizeof(double), hipMemcpyDefault));
+  }
+  return PQP_OK;
+}
+
+int
+copy_out(double* dst, const double* src_base, int64_t idx, int64_t B, size_t per_qp)
+{
+  if (!dst || per_qp == 0)
+    return PQP_OK;
+  if (idx < 0) {
+    HIP_TRY(hipMemcpy(dst, src_base, per_qp * size_t(B) * sizeof(double), hipMemcpyDefault));
+  } else {
+    HIP_TRY(hipMemcpy(dst, src_base + size_t(idx) * per_qp, per_qp * sizeof(double), hipMemcpyDefault));
+  }
+  return PQP_OK;
+}
+
+int
+dispatch_setup(pqp_batch* h)
+{
+  switch (h->nt) {
+    case 256:
+      return launch_setup<256>(h);
+    case 512:
+      return launch_setup<512>(h);
+    default:
+      return launch_setup<1024>(h);
+  }
+}
+int
+dispatch_solve(pqp_batch* h)
+{
+  switch (h->nt) {
+    case 256:
+      return launch_solve<256>(h);
+    case 512:
+      return launch_solve<512>(h);
+    default:
+      return launch_solve<1024>(h);
+  }
+}
+
+// the scalar half of QP::init / QP::update that lives in `settings`
+// (reference dense/wrapper.hpp:375, 754-759; helpers.hpp:174-189, 678-705)
+void
+host_settings_state_machine(pqp_settings& st, bool is_init, int precond_flag, double rho, double mu_eq,
+                            double mu_in, double min_eig)
+{
+  if (is_init)
+    st.compute_preconditioner = precond_flag;
+  else
+    st.update_preconditioner = precond_flag;
+  if (!absent(rho))
+    st.default_rho = rho;
+  if (!absent(mu_eq))
+    st.default_mu_eq = mu_eq;
+  if (!absent(mu_in))
+    st.default_mu_in = mu_in;
+  if (!absent(min_eig))
+    st.default_H_eigenvalue_estimate = min_eig;
+  // results.info.minimal_H_eigenvalue_estimate always equals
+  // settings.default_H_eigenvalue_estimate (results.hpp:175-194, helpers.hpp:181-186)
+  st.default_rho += std::fabs(st.default_H_eigenvalue_estimate);
+}
+
+int
+enqueue_setup(pqp_batch* h, int64_t idx, bool update_call, const double* H, const double* g,
+              const double* A, const double* b, const double* C, const double* l, const double* u,
+              const double* l_box, const double* u_box, int precond_flag, double rho, double mu_eq,
+              double mu_in, double min_eig)
+{
+  if (int rc = check_idx(h, idx))
+    return rc;
+  const pqp::Dims& d = h->dev.d;
+  // wrapper.hpp:367-372, 542-546, 736-741, 846-850
+  if (!d.box && (l_box || u_box))
+    return fail(PQP_ERR_INVALID_ARGUMENT,
+                "wrong model setup: the QP object is designed without box constraints, but is "
+                "initialized or updated with lower or upper box inequalities.");
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t lo = idx < 0 ? 0 : idx, hi = idx < 0 ? h->dev.B : idx + 1;
+  // one queued command per QP: run what is pending before stacking another one
+  for (int64_t q = lo; q < hi; ++q)
+    if (h->cmd[size_t(q)].op != pqp::CMD_NONE) {
+      if (int rc = pqp_batch_flush(h))
+        return rc;
+      break;
+    }
+  const size_t n = size_t(d.n), ne = size_t(d.n_eq), ni = size_t(d.n_in);
+  pqp::Batch& D = h->dev;
+  int rc = 0;
+  if ((rc = copy_in(D.H, H, idx, D.B, n * n)) || (rc = copy_in(D.g, g, idx, D.B, n)) ||
+      (rc = copy_in(D.A, A, idx, D.B, ne * n)) || (rc = copy_in(D.b, b, idx, D.B, ne)) ||
+      (rc = copy_in(D.C, C, idx, D.B, ni * n)) || (rc = copy_in(D.l, l, idx, D.B, ni)) ||
+      (rc = copy_in(D.u, u, idx, D.B, ni)))
+    return rc;
+  if (d.box && ((rc = copy_in(D.l_box, l_box, idx, D.B, n)) || (rc = copy_in(D.u_box, u_box, idx, D.B, n))))
+    return rc;
+  for (int64_t q = lo; q < hi; ++q) {
+    pqp_settings& st = h->settings[size_t(q)];
+    bool is_init = !update_call || !h->is_initialized[size_t(q)];
+    double me = min_eig;
+    if (update_call && is_init)
+      me = std::numeric_limits<double>::quiet_NaN(); // wrapper.hpp:743-746 does not forward it
+    host_settings_state_machine(st, is_init, precond_flag, rho, mu_eq, mu_in, me);
+    pqp::Cmd c{};
+    c.op = is_init ? pqp::CMD_INIT : pqp::CMD_UPDATE;
+    c.preconditioner = precond_flag;
+    c.matrices_given = (H || A || C) ? 1 : 0;
+    c.rho = rho;
+    c.mu_eq = mu_eq;
+    c.mu_in = mu_in;
+    c.min_eig = me;
+    h->cmd[size_t(q)] = c;
+    if (is_init) {
+      h->is_initialized[size_t(q)] = 1;
+    } else {
+      // setup() -> work.cleanup() clears is_initialized except on the keep-everything
+      // WARM_START_WITH_PREVIOUS_RESULT path (helpers.hpp:522-572, workspace.hpp:372)
+      bool ppu = !absent(rho) || !absent(mu_eq) || !absent(mu_in);
+      bool keep = st.initial_guess == PQP_WARM_START_WITH_PREVIOUS_RESULT && !c.matrices_given && !ppu;
+      if (!keep)
+        h->is_initialized[size_t(q)] = 0;
+    }
+  }
+  h->cmd_pending = true;
+  return PQP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char*
+pqp_last_error(void)
+{
+  return g_err.c_str();
+}
+
+int
+pqp_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int
+pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, int box_constraints,
+                 int hessian_type, int dense_backend, int device, pqp_batch** out)
+{
+  if (!out)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null output handle");
+  *out = nullptr;
+  if (dim <= 0) // reference dense/model.hpp:65-68
+    return fail(PQP_ERR_INVALID_ARGUMENT,
+                "wrong argument size: the dimension wrt the primal variable x should be strictly positive.");
+  if (batch_size < 0 || n_eq < 0 || n_in < 0)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "negative size");
+  if (hessian_type < PQP_HESSIAN_ZERO || hessian_type > PQP_HESSIAN_DIAGONAL)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "unknown hessian type");
+  int ndev = pqp_device_count();
+  if (ndev <= 0)
+    return fail(PQP_ERR_NO_DEVICE, "no HIP device: libproxqp_hip has no CPU fallback");
+  if (device < 0 || device >= ndev)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  pqp_batch* h = new pqp_batch();
+  h->device = device;
+  h->backend = dense_backend_choice(dense_backend, dim, n_eq, n_in, box_constraints != 0);
+  pqp::Dims& d = h->dev.d;
+  d.n = int(dim);
+  d.n_eq = int(n_eq);
+  d.n_in = int(n_in);
+  d.box = box_constraints ? 1 : 0;
+  d.nc = int(n_in + (box_constraints ? dim : 0));
+  d.nd = d.n_eq + d.nc;
+  d.ntot = d.n + d.nd;
+  d.hessian = hessian_type;
+  h->dev.B = batch_size;
+  const int need = d.nd > d.n ? d.nd : d.n;
+  h->nt = need <= 256 ? 256 : (need <= 512 ? 512 : 1024);
+  if (need > 1024 || d.nc > 1024) {
+    delete h;
+    return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq+n_in(+n)) > 1024 is not supported by this build");
+  }
+  h->lds_solve = pqp::lds_bytes(d, h->nt);
+  h->lds_setup = pqp::setup_lds_bytes(d, h->nt);
+  if (h->lds_solve > 160 * 1024) {
+    delete h;
+    return fail(PQP_ERR_UNSUPPORTED, "per-QP vector state exceeds the 160 KiB LDS of one CU");
+  }
+  const size_t B = size_t(batch_size), n = size_t(dim), ne = size_t(n_eq), ni = size_t(n_in),
+               nc = size_t(d.nc), nd = size_t(d.nd);
+  pqp::Batch& D = h->dev;
+  int rc = 0;
+#define ALLOC(ptr, cnt)                                                                             \
+  if ((rc = dalloc(h, &(ptr), (cnt)))) {                                                            \
+    pqp_batch_destroy(h);                                                                           \
+    return rc;                                                                                      \
+  }
+  ALLOC(D.H, B * n * n)
+  ALLOC(D.g, B * n)
+  ALLOC(D.A, B * ne * n)
+  ALLOC(D.b, B * ne)
+  ALLOC(D.C, B * ni * n)
+  ALLOC(D.u, B * ni)
+  ALLOC(D.l, B * ni)
+  ALLOC(D.u_box, B * n)
+  ALLOC(D.l_box, B * n)
+  ALLOC(D.Hs, B * n * n)
+  ALLOC(D.gs, B * n)
+  ALLOC(D.As, B * ne * n)
+  ALLOC(D.ATs, B * ne * n)
+  ALLOC(D.bs, B * ne)
+  ALLOC(D.Cs, B * ni * n)
+  ALLOC(D.CTs, B * ni * n)
+  ALLOC(D.us, B * ni)
+  ALLOC(D.ls, B * ni)
+  ALLOC(D.ubs, B * n)
+  ALLOC(D.lbs, B * n)
+  ALLOC(D.is, B * n)
+  ALLOC(D.delta, B * size_t(d.ntot))
+  ALLOC(D.x, B * n)
+  ALLOC(D.y, B * ne)
+  ALLOC(D.z, B * nc)
+  ALLOC(D.se, B * ne)
+  ALLOC(D.si, B * nc)
+  ALLOC(D.info, B)
+  ALLOC(D.state, B)
+  ALLOC(D.F, B * n * n)
+  ALLOC(D.WL, B * n * n)
+  ALLOC(D.WU, B * n * n)
+  ALLOC(D.dF, B * n)
+  ALLOC(D.Zr, B * nd * n)
+  ALLOC(D.Zc, B * nd * n)
+  ALLOC(D.G, B * nd * nd)
+  ALLOC(D.LS, B * nd * nd)
+  ALLOC(D.dS, B * nd)
+  ALLOC(D.act, B * nc)
+  ALLOC(D.zvalid, B * nd)
+  ALLOC(D.stats, B * size_t(pqp::ST_COUNT))
+  ALLOC(h->d_settings, B)
+  ALLOC(h->d_cmd, B)
+#undef ALLOC
+  D.settings = h->d_settings;
+  D.cmd = h->d_cmd;
+
+  // host-side defaults: Settings(dense_backend) (settings.hpp:213-315), Results(...)
+  // (results.hpp:90-144), Model bounds +-sqrt(DBL_MAX) (model.hpp:70-91), Ruiz delta = 1
+  h->settings.resize(B);
+  for (auto& s : h->settings)
+    pqp_settings_default(&s, h->backend);
+  h->cmd.assign(B, pqp::Cmd{});
+  h->is_initialized.assign(B, 0);
+  {
+    std::vector<pqp_info> info(B);
+    for (auto& i : info)
+      pqp_info_default(&i, h->backend);
+    if (B)
+      HIP_TRY(hipMemcpy(D.info, info.data(), B * sizeof(pqp_info), hipMemcpyHostToDevice));
+    std::vector<pqp::State> st(B);
+    for (auto& s : st) {
+      std::memset(&s, 0, sizeof(s));
+      s.ruiz_c = 1.0;
+    }
+    if (B)
+      HIP_TRY(hipMemcpy(D.state, st.data(), B * sizeof(pqp::State), hipMemcpyHostToDevice));
+    const double ib = std::sqrt(std::numeric_limits<double>::max());
+    std::vector<double> tmp;
+    auto fill = [&](double* dst, size_t cnt, double v) -> int {
+      if (!cnt)
+        return PQP_OK;
+      tmp.assign(cnt, v);
+      HIP_TRY(hipMemcpy(dst, tmp.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+      return PQP_OK;
+    };
+    if ((rc = fill(D.u, B * ni, +ib)) || (rc = fill(D.l, B * ni, -ib)) ||
+        (rc = fill(D.u_box, B * n, +ib)) || (rc = fill(D.l_box, B * n, -ib)) ||
+        (rc = fill(D.delta, B * size_t(d.ntot), 1.0)) || (rc = fill(D.is, B * n, 1.0))) {
+      pqp_batch_destroy(h);
+      return rc;
+    }
+  }
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  *out = h;
+  return PQP_OK;
+}
+
+void
+pqp_batch_destroy(pqp_batch* h)
+{
+  if (!h)
+    return;
+  (void)hipSetDevice(h->device);
+  for (void* p : h->allocs)
+    (void)hipFree(p);
+  if (h->ev0)
+    (void)hipEventDestroy(h->ev0);
+  if (h->ev1)
+    (void)hipEventDestroy(h->ev1);
+  delete h;
+}
+
+int64_t
+pqp_batch_size(const pqp_batch* h)
+{
+  return h ? h->dev.B : 0;
+}
+
+int
+pqp_batch_dense_backend(const pqp_batch* h)
+{
+  return h ? h->backend : PQP_BACKEND_AUTOMATIC;
+}
+
+pqp_settings*
+pqp_batch_settings(pqp_batch* h, int64_t idx)
+{
+  if (!h || idx < 0 || idx >= h->dev.B)
+    return nullptr;
+  return &h->settings[size_t(idx)];
+}
+
+int
+pqp_batch_init(pqp_batch* h, int64_t idx, const double* H, const double* g, const double* A,
+               const double* b, const double* C, const double* l, const double* u,
+               const double* l_box, const double* u_box, int compute_preconditioner, double rho,
+               double mu_eq, double mu_in, double manual_minimal_H_eigenvalue)
+{
+  if (h && h->dev.d.box == 0 && (l_box || u_box))
+    return fail(PQP_ERR_INVALID_ARGUMENT,
+                "wrong model setup: the QP object is designed without box constraints, but is "
+                "initialized with lower or upper box inequalities."); // wrapper.hpp:542-546
+  return enqueue_setup(h, idx, false, H, g, A, b, C, l, u, l_box, u_box, compute_preconditioner ? 1 : 0,
+                       rho, mu_eq, mu_in, manual_minimal_H_eigenvalue);
+}
+
+int
+pqp_batch_update(pqp_batch* h, int64_t idx, const double* H, const double* g, const double* A,
+                 const double* b, const double* C, const double* l, const double* u,
+                 const double* l_box, const double* u_box, int update_preconditioner, double rho,
+                 double mu_eq, double mu_in, double manual_minimal_H_eigenvalue)
+{
+  return enqueue_setup(h, idx, true, H, g, A, b, C, l, u, l_box, u_box, update_preconditioner ? 1 : 0,
+                       rho, mu_eq, mu_in, manual_minimal_H_eigenvalue);
+}
+
+int
+pqp_batch_warm_start(pqp_batch* h, int64_t idx, const double* x, const double* y, const double* z)
+{
+  if (int rc = check_idx(h, idx))
+    return rc;
+  if (!x && !y && !z) // helpers.hpp:724-725
+    return PQP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  // the guess must land after any queued cleanup of the results
+  if (h->cmd_pending)
+    if (int rc = pqp_batch_flush(h))
+      return rc;
+  const pqp::Dims& d = h->dev.d;
+  int rc = 0;
+  if ((rc = copy_in(h->dev.x, x, idx, h->dev.B, size_t(d.n))) ||
+      (rc = copy_in(h->dev.y, y, idx, h->dev.B, size_t(d.n_eq))) ||
+      (rc = copy_in(h->dev.z, z, idx, h->dev.B, size_t(d.nc))))
+    return rc;
+  const int64_t lo = idx < 0 ? 0 : idx, hi = idx < 0 ? h->dev.B : idx + 1;
+  for (int64_t q = lo; q < hi; ++q)
+    h->settings[size_t(q)].initial_guess = PQP_WARM_START; // helpers.hpp:727
+  return PQP_OK;
+}
+
+int
+pqp_batch_cleanup(pqp_batch* h, int64_t idx)
+{
+  if (int rc = check_idx(h, idx))
+    return rc;
+  if (h->cmd_pending)
+    if (int rc = pqp_batch_flush(h))
+      return rc;
+  const int64_t lo = idx < 0 ? 0 : idx, hi = idx < 0 ? h->dev.B : idx + 1;
+  for (int64_t q = lo; q < hi; ++q) {
+    pqp::Cmd c{};
+    c.op = pqp::CMD_CLEANUP;
+    h->cmd[size_t(q)] = c;
+    h->is_initialized[size_t(q)] = 0;
+  }
+  h->cmd_pending = true;
+  return pqp_batch_flush(h);
+}
+
+int
+pqp_batch_flush(pqp_batch* h)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (!h->cmd_pending || h->dev.B == 0)
+    return PQP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  if (int rc = upload_settings(h))
+    return rc;
+  HIP_TRY(hipMemcpy(h->d_cmd, h->cmd.data(), h->cmd.size() * sizeof(pqp::Cmd), hipMemcpyHostToDevice));
+  if (int rc = dispatch_setup(h))
+    return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  for (auto& c : h->cmd)
+    c.op = pqp::CMD_NONE;
+  h->cmd_pending = false;
+  return PQP_OK;
+}
+
+int
+pqp_batch_solve(pqp_batch* h)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (h->dev.B == 0)
+    return PQP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  if (int rc = pqp_batch_flush(h))
+    return rc;
+  if (int rc = upload_settings(h))
+    return rc;
+  if (int rc = dispatch_solve(h))
+    return rc;
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
+  std::fill(h->is_initialized.begin(), h->is_initialized.end(), char(1));
+  return PQP_OK;
+}
+
+int
+pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z, double* se, double* si,
+                      pqp_info* info)
+{
+  if (int rc = check_idx(h, idx))
+    return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->cmd_pending)
+    if (int rc = pqp_batch_flush(h))
+      return rc;
+  const pqp::Dims& d = h->dev.d;
+  const pqp::Batch& D = h->dev;
+  int rc = 0;
+  if ((rc = copy_out(x, D.x, idx, D.B, size_t(d.n))) || (rc = copy_out(y, D.y, idx, D.B, size_t(d.n_eq))) ||
+      (rc = copy_out(z, D.z, idx, D.B, size_t(d.nc))) || (rc = copy_out(se, D.se, idx, D.B, size_t(d.n_eq))) ||
+      (rc = copy_out(si, D.si, idx, D.B, size_t(d.nc))))
+    return rc;
+  if (info) {
+    if (idx < 0)
+      HIP_TRY(hipMemcpy(info, D.info, size_t(D.B) * sizeof(pqp_info), hipMemcpyDefault));
+    else
+      HIP_TRY(hipMemcpy(info, D.info + idx, sizeof(pqp_info), hipMemcpyDefault));
+  }
+  return PQP_OK;
+}
+
+int
+pqp_batch_result_device_ptrs(pqp_batch* h, double** x, double** y, double** z)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (x)
+    *x = h->dev.x;
+  if (y)
+    *y = h->dev.y;
+  if (z)
+    *z = h->dev.z;
+  return PQP_OK;
+}
+
+int
+pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A, double* b, double* C,
+                     double* l, double* u, double* delta, double* c)
+{
+  if (int rc = check_idx(h, idx))
+    return rc;
+  if (idx < 0)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_get_scaled addresses one QP");
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->cmd_pending)
+    if (int rc = pqp_batch_flush(h))
+      return rc;
+  const pqp::Dims& d = h->dev.d;
+  const pqp::Batch& D = h->dev;
+  const size_t n = size_t(d.n), ne = size_t(d.n_eq), ni = size_t(d.n_in);
+  int rc = 0;
+  if ((rc = copy_out(H, D.Hs, idx, D.B, n * n)) || (rc = copy_out(g, D.gs, idx, D.B, n)) ||
+      (rc = copy_out(A, D.As, idx, D.B, ne * n)) || (rc = copy_out(b, D.bs, idx, D.B, ne)) ||
+      (rc = copy_out(C, D.Cs, idx, D.B, ni * n)) || (rc = copy_out(l, D.ls, idx, D.B, ni)) ||
+      (rc = copy_out(u, D.us, idx, D.B, ni)) || (rc = copy_out(delta, D.delta, idx, D.B, size_t(d.ntot))))
+    return rc;
+  if (c) {
+    pqp::State s;
+    HIP_TRY(hipMemcpy(&s, D.state + idx, sizeof(s), hipMemcpyDefault));
+    *c = s.ruiz_c;
+  }
+  return PQP_OK;
+}
+
+int
+pqp_batch_get_stats(pqp_batch* h, int64_t* stats)
+{
+  if (!h || !stats)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
+  static_assert(PQP_STATS_COUNT == pqp::ST_COUNT, "stats record size");
+  static_assert(sizeof(long long) == sizeof(int64_t), "stats element size");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(stats, h->dev.stats, size_t(h->dev.B) * pqp::ST_COUNT * sizeof(int64_t), hipMemcpyDefault));
+  return PQP_OK;
+}
+
+double
+pqp_batch_last_solve_ms(const pqp_batch* h)
+{
+  return h ? double(h->last_ms) : 0.0;
+}
+
+int
+pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (threads)
+    *threads = h->nt;
+  if (lds_bytes)
+    *lds_bytes = int64_t(h->lds_solve);
+  return PQP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,2156 @@
+// Batched dense ProxQP on MI355X: device-side state, the setup (init/update +
+// Ruiz equilibration) kernel body and the solve kernel body.
+//
+// What is computed follows the reference function for function (cited inline,
+// paths relative to /root/reference/include/proxsuite/proxqp/); HOW it is
+// computed is re-designed for a workgroup-per-QP SIMT machine:
+//
+//  * KKT factorisation.  The reference keeps one permuted LDL^T of the whole
+//    KKT matrix and edits it with rank-1 recurrences (insert / delete /
+//    diagonal update: m sequential column steps each).  Here the same LDL^T is
+//    held in *block* form with a static primal-first pivot order,
+//        K = [ H+rho I   B_J^T ]   H+rho I = L D L^T          (once per solve)
+//            [ B_J      -M_J   ]   Z = L^{-1} B^T, G = Z^T D^{-1} Z (cached rows)
+//                                   M_J + G_JJ = L_S D_S L_S^T  (dual Schur block)
+//    so an active-set change or a mu update is a gather of G_JJ plus a small
+//    dense LDL^T (GEMM-shaped, no sequential rank-1 chains), new constraints
+//    cost one triangular mat-vec each, and L^{-1} is kept explicitly so the
+//    primal-block solves are chain-free mat-vecs.
+//  * Line search.  phi'(alpha) is evaluated at ALL breakpoints concurrently
+//    (one thread per breakpoint) instead of sort + sequential walk.
+//  * Everything else (Ruiz, residuals, BCL, Newton bookkeeping, infeasibility
+//    certificates, counters) restates the reference line by line on LDS vectors.
+#ifndef PQP_SOLVER_HPP
+#define PQP_SOLVER_HPP
+
+#include "pqp_block.hpp"
+#include "pqp_types.h"
+
+namespace pqp {
+
+constexpr double MACHINE_EPS = 2.220446049250313e-16;
+
+struct Dims
+{
+  int n, n_eq, n_in; // problem sizes
+  int nc;            // n_in (+ n if box constraints)
+  int nd;            // n_eq + nc   : capacity of the dual block
+  int ntot;          // n + nd
+  int box;           // box constraints present
+  int hessian;       // pqp_hessian_type
+};
+
+// commands consumed by the setup kernel (reference dense/wrapper.hpp init/update)
+enum
+{
+  CMD_NONE = 0,
+  CMD_INIT = 1,
+  CMD_UPDATE = 2,
+  CMD_CLEANUP = 3
+};
+struct Cmd
+{
+  int op;
+  int preconditioner; // compute_preconditioner (init) / update_preconditioner (update)
+  int matrices_given; // update: H, A or C given  (helpers.hpp:466-468)
+  int _pad;
+  double rho, mu_eq, mu_in, min_eig; // NaN == nullopt
+};
+
+// per-QP persistent scalar state (reference dense/workspace.hpp flags + Ruiz c)
+struct State
+{
+  int dirty;
+  int refactorize;
+  int proximal_parameter_update;
+  int is_initialized;
+  int n_c;          // active inequalities kept for WARM_START_WITH_PREVIOUS_RESULT
+  int factor_valid; // primal block, Z and G in HBM match (model, rho)
+  int ls_valid;     // the Schur factor in HBM matches (mu_eq_fact, mu_in_fact, active list)
+  int _pad0;
+  double ruiz_c;
+  double dual_feasibility_rhs_2;
+  double correction_guess_rhs_g;
+  double mu_eq_fact, mu_in_fact, rho_fact;
+};
+
+// per-QP statistics (device cycles per phase, event counts)
+enum
+{
+  ST_CYC_TOTAL = 0,
+  ST_CYC_SCALE,
+  ST_CYC_FACTOR_H,
+  ST_CYC_ZG,
+  ST_CYC_SCHUR,
+  ST_CYC_KKT_SOLVE,
+  ST_CYC_RESIDUAL,
+  ST_CYC_LINESEARCH,
+  ST_CYC_GLOBAL_RES,
+  ST_CYC_NEWTON_MISC,
+  ST_N_NEWTON,
+  ST_N_SCHUR_FACT,
+  ST_N_NEW_ROWS,
+  ST_N_KKT_SOLVES,
+  ST_N_LS_BREAKPOINTS,
+  ST_N_ACTIVE_FINAL,
+  ST_COUNT
+};
+
+// device view of one batch (all pointers are HBM; QP q starts at ptr + q*stride)
+struct Batch
+{
+  Dims d;
+  long B;
+  // unscaled model (row-major), reference dense/model.hpp
+  double *H, *g, *A, *b, *C, *u, *l, *u_box, *l_box;
+  // equilibrated copies + both orientations of A and C
+  double *Hs, *gs, *As, *ATs, *bs, *Cs, *CTs, *us, *ls, *ubs, *lbs, *is;
+  double* delta; // ntot (Ruiz cumulative scaling, ruiz.hpp:319)
+  // results (reference results.hpp)
+  double *x, *y, *z, *se, *si;
+  pqp_info* info;
+  const pqp_settings* settings;
+  State* state;
+  const Cmd* cmd;
+  // block factorisation workspace
+  double *F;      // n x n   mirrored LDL^T of H_s + rho I
+  double *WL, *WU; // n x n  L^{-1} and its transpose
+  double *dF;     // n
+  double *Zr;     // nd x n  row cid = L^{-1} b_cid
+  double *Zc;     // n x nd  transpose of Zr
+  double *G;      // nd x nd Gram matrix  Z^T D^{-1} Z over validated constraints
+  double *LS;     // nd x nd mirrored LDL^T of M_J + G_JJ (slot order)
+  double *dS;     // nd
+  int* act;       // nc      active list kept across solves
+  int* zvalid;    // nd
+  long long* stats; // ST_COUNT per QP
+};
+
+// LDS carve-up: typed 32-bit LDS pointers ---------------------------------------
+struct Lds
+{
+  lptr x, y, z, xp, yp, zp;
+  lptr gs, bs, us, ls, ubs, lbs, isc;
+  lptr dx, dy, dz;
+  lptr rx, rd;
+  lptr ex, ed;
+  lptr sd;
+  lptr Hdx, Adx, Cdx, ATdy, CTdz, CTzin;
+  lptr dres, se, si, rup;
+  lptr dF, dS;
+  lptr t1, t2, zfull;
+  lptr part, red, top;
+  liptr slot_of, act, zvalid, aflags, icnt;
+  PQP_LDS long long* stat;
+};
+
+__host__ __device__ inline size_t
+lds_doubles(const Dims& d, int nt)
+{
+  size_t n = d.n, ne = d.n_eq, nc = d.nc, nd = d.nd;
+  size_t tmax = nd > n ? nd : n;
+  size_t s = 0;
+  s += 2 * (n + ne + nc);                // x y z xp yp zp
+  s += n + ne + 2 * d.n_in + 3 * n;      // gs bs us ls ubs lbs isc
+  s += n + ne + nc;                      // dx dy dz
+  s += 2 * (n + nd);                     // rx rd ex ed
+  s += nd;                               // sd
+  s += n + ne + nc + 3 * n;              // Hdx Adx Cdx ATdy CTdz CTzin
+  s += n + ne + 2 * nc;                  // dres se si rup
+  s += n + nd;                           // dF dS
+  s += n + tmax + nc;                    // t1 t2 zfull
+  s += gemv_part_len(nt, (int)tmax);     // part
+  s += 2 * 4 * (nt / WAVE) + 8;          // red
+  s += 2 * PQP_NB * PQP_NB + 2 * PQP_NB; // top
+  s += ST_COUNT;                         // stat (long long)
+  return s;
+}
+__host__ __device__ inline size_t
+lds_bytes(const Dims& d, int nt)
+{
+  size_t ints = (size_t)d.nc * 3 + d.nd + nt / WAVE + 8;
+  return lds_doubles(d, nt) * sizeof(double) + ints * sizeof(int) + 64;
+}
+
+__device__ __forceinline__ void
+lds_carve(Lds& L, lptr base, const Dims& d, int nt)
+{
+  const int n = d.n, ne = d.n_eq, nc = d.nc, nd = d.nd, ni = d.n_in;
+  const int tmax = nd > n ? nd : n;
+  lptr p = base;
+  auto take = [&](int k) {
+    lptr r = p;
+    p += k;
+    return r;
+  };
+  L.x = take(n);
+  L.y = take(ne);
+  L.z = take(nc);
+  L.xp = take(n);
+  L.yp = take(ne);
+  L.zp = take(nc);
+  L.gs = take(n);
+  L.bs = take(ne);
+  L.us = take(ni);
+  L.ls = take(ni);
+  L.ubs = take(n);
+  L.lbs = take(n);
+  L.isc = take(n);
+  L.dx = take(n);
+  L.dy = take(ne);
+  L.dz = take(nc);
+  L.rx = take(n);
+  L.rd = take(nd);
+  L.ex = take(n);
+  L.ed = take(nd);
+  L.sd = take(nd);
+  L.Hdx = take(n);
+  L.Adx = take(ne);
+  L.Cdx = take(nc);
+  L.ATdy = take(n);
+  L.CTdz = take(n);
+  L.CTzin = take(n);
+  L.dres = take(n);
+  L.se = take(ne);
+  L.si = take(nc);
+  L.rup = take(nc);
+  L.dF = take(n);
+  L.dS = take(nd);
+  L.t1 = take(n);
+  L.t2 = take(tmax);
+  L.zfull = take(nc);
+  L.part = take(gemv_part_len(nt, tmax));
+  L.red = take(2 * 4 * (nt / WAVE) + 8);
+  L.top = take(2 * PQP_NB * PQP_NB + 2 * PQP_NB);
+  L.stat = (PQP_LDS long long*)take(ST_COUNT);
+  liptr q = (liptr)p;
+  L.slot_of = q;
+  q += nc;
+  L.act = q;
+  q += nc;
+  L.zvalid = q;
+  q += nd;
+  L.aflags = q;
+  q += nc;
+  L.icnt = q;
+}
+
+// Per-QP HBM pointers, recomputed from the kernel argument on demand (a few
+// scalar instructions) instead of being held in ~90 registers.
+struct QpRef
+{
+  const Batch& b;
+  const long q;
+  __device__ __forceinline__ QpRef(const Batch& b_, long q_)
+    : b(b_)
+    , q(q_)
+  {
+  }
+  __device__ __forceinline__ long n() const { return b.d.n; }
+  __device__ __forceinline__ long ne() const { return b.d.n_eq; }
+  __device__ __forceinline__ long ni() const { return b.d.n_in; }
+  __device__ __forceinline__ long nc() const { return b.d.nc; }
+  __device__ __forceinline__ long nd() const { return b.d.nd; }
+#define PQP_PTR(name, stride) \
+  __device__ __forceinline__ gptr name() const { return (gptr)(b.name + q * (stride)); }
+  PQP_PTR(H, n() * n())
+  PQP_PTR(g, n())
+  PQP_PTR(A, ne() * n())
+  PQP_PTR(C, ni() * n())
+  PQP_PTR(u, ni())
+  PQP_PTR(l, ni())
+  PQP_PTR(u_box, n())
+  PQP_PTR(l_box, n())
+  PQP_PTR(Hs, n() * n())
+  PQP_PTR(gs, n())
+  PQP_PTR(As, ne() * n())
+  PQP_PTR(ATs, ne() * n())
+  PQP_PTR(bs, ne())
+  PQP_PTR(Cs, ni() * n())
+  PQP_PTR(CTs, ni() * n())
+  PQP_PTR(us, ni())
+  PQP_PTR(ls, ni())
+  PQP_PTR(ubs, n())
+  PQP_PTR(lbs, n())
+  PQP_PTR(is, n())
+  PQP_PTR(delta, (long)b.d.ntot)
+  PQP_PTR(x, n())
+  PQP_PTR(y, ne())
+  PQP_PTR(z, nc())
+  PQP_PTR(se, ne())
+  PQP_PTR(si, nc())
+  PQP_PTR(F, n() * n())
+  PQP_PTR(WL, n() * n())
+  PQP_PTR(WU, n() * n())
+  PQP_PTR(dF, n())
+  PQP_PTR(Zr, nd() * n())
+  PQP_PTR(Zc, nd() * n())
+  PQP_PTR(G, nd() * nd())
+  PQP_PTR(LS, nd() * nd())
+  PQP_PTR(dS, nd())
+#undef PQP_PTR
+  // `b` is also the name of the equality right-hand side: spelled out
+  __device__ __forceinline__ gptr bvec() const { return (gptr)(b.b + q * ne()); }
+  __device__ __forceinline__ PQP_GLOBAL int* act() const { return (PQP_GLOBAL int*)(b.act + q * nc()); }
+  __device__ __forceinline__ PQP_GLOBAL int* zvalid() const
+  {
+    return (PQP_GLOBAL int*)(b.zvalid + q * nd());
+  }
+  __device__ __forceinline__ PQP_GLOBAL long long* stats() const
+  {
+    return (PQP_GLOBAL long long*)(b.stats + q * ST_COUNT);
+  }
+  __device__ __forceinline__ pqp_info* info() const { return b.info + q; }
+  __device__ __forceinline__ State* state() const { return b.state + q; }
+  __device__ __forceinline__ const pqp_settings& settings() const { return b.settings[q]; }
+  // Ruiz scalings
+  __device__ __forceinline__ cgptr dlt_x() const { return delta(); }
+  __device__ __forceinline__ cgptr dlt_eq() const { return delta() + n(); }
+  __device__ __forceinline__ cgptr dlt_in() const { return delta() + n() + ne(); }
+  __device__ __forceinline__ cgptr dlt_box() const { return delta() + n() + ne() + ni(); }
+};
+
+__device__ __forceinline__ bool
+absent(double v)
+{
+  return v != v;
+}
+
+// reference results.hpp:157-174
+__device__ __forceinline__ void
+cleanup_statistics(pqp_info& i)
+{
+  i.run_time = 0;
+  i.setup_time = 0;
+  i.solve_time = 0;
+  i.objValue = 0.;
+  i.iter = 0;
+  i.iter_ext = 0;
+  i.mu_updates = 0;
+  i.rho_updates = 0;
+  i.pri_res = 0.;
+  i.dua_res = 0.;
+  i.duality_gap = 0.;
+  i.iterative_residual = 0.;
+  i.status = PQP_MAX_ITER_REACHED;
+}
+// reference results.hpp:175-194
+__device__ __forceinline__ void
+cold_start(pqp_info& i, const pqp_settings& s)
+{
+  i.nu = 1.;
+  i.rho = s.default_rho;
+  i.mu_eq = s.default_mu_eq;
+  i.mu_eq_inv = 1.0 / i.mu_eq;
+  i.mu_in = s.default_mu_in;
+  i.mu_in_inv = 1.0 / i.mu_in;
+  i.minimal_H_eigenvalue_estimate = s.default_H_eigenvalue_estimate;
+  cleanup_statistics(i);
+}
+
+// reference workspace.hpp:330-377 (scalar part; LDS vectors are reset where used)
+__device__ __forceinline__ void
+work_cleanup_flags(State& w)
+{
+  w.dirty = 0;
+  w.refactorize = 0;
+  w.proximal_parameter_update = 0;
+  w.is_initialized = 0;
+  w.n_c = 0;
+  w.factor_valid = 0;
+  w.ls_valid = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Equilibrated copies.  Restates what reference preconditioner/ruiz.hpp:205-307
+// (execute) and :442-511 (re-apply) leave in the workspace, from the cumulative
+// scaling S (LDS, ntot) and c:  H_s = c S_x H S_x, A_s = S_eq A S_x, ...; both
+// orientations of A_s and C_s are written for the solve kernel.
+// ---------------------------------------------------------------------------
+template<int NT>
+__device__ PQP_CALL void
+write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp)
+{
+  const QpRef P(batch, q);
+  const Dims& d = batch.d;
+  const int n = d.n, ne = d.n_eq, ni = d.n_in;
+  clptr Sx = S;
+  clptr Se = S + n;
+  clptr Si = S + n + ne;
+  clptr Sb = S + n + ne + ni;
+  {
+    cgptr H = P.H();
+    gptr Hs = P.Hs();
+    if (d.hessian == PQP_HESSIAN_DENSE) {
+      for (int o = threadIdx.x; o < n * n; o += NT) {
+        int r = o / n, k = o - r * n;
+        Hs[o] = Sx[r] * H[o] * Sx[k] * c;
+      }
+    } else {
+      for (int o = threadIdx.x; o < n * n; o += NT) {
+        int r = o / n, k = o - r * n;
+        double v = H[o];
+        if (d.hessian == PQP_HESSIAN_DIAGONAL)
+          v = (r == k) ? v * Sx[r] * Sx[r] * c : v * c;
+        Hs[o] = v;
+      }
+    }
+  }
+  {
+    cgptr A = P.A();
+    gptr As = P.As(), ATs = P.ATs();
+    for (int o = threadIdx.x; o < ne * n; o += NT) {
+      int r = o / n, k = o - r * n;
+      double v = Se[r] * A[o] * Sx[k];
+      As[o] = v;
+      ATs[(long)k * ne + r] = v;
+    }
+  }
+  {
+    cgptr C = P.C();
+    gptr Cs = P.Cs(), CTs = P.CTs();
+    for (int o = threadIdx.x; o < ni * n; o += NT) {
+      int r = o / n, k = o - r * n;
+      double v = Si[r] * C[o] * Sx[k];
+      Cs[o] = v;
+      CTs[(long)k * ni + r] = v;
+    }
+  }
+  for (int k = threadIdx.x; k < n; k += NT)
+    P.gs()[k] = P.g()[k] * Sx[k] * c;
+  for (int k = threadIdx.x; k < ne; k += NT)
+    P.bs()[k] = P.bvec()[k] * Se[k];
+  for (int k = threadIdx.x; k < ni; k += NT) {
+    double uu = P.u()[k], ll = P.l()[k];
+    if (clamp) { // helpers.hpp:628-637
+      uu = (uu <= 1.E20) ? uu : 1.E20;
+      ll = (ll >= -1.E20) ? ll : -1.E20;
+    }
+    P.us()[k] = uu * Si[k];
+    P.ls()[k] = ll * Si[k];
+  }
+  if (d.box) {
+    for (int k = threadIdx.x; k < n; k += NT) {
+      double uu = P.u_box()[k], ll = P.l_box()[k];
+      uu = (uu <= 1.E20) ? uu : 1.E20; // helpers.hpp:638-649
+      ll = (ll >= -1.E20) ? ll : -1.E20;
+      P.ubs()[k] = uu * Sb[k];
+      P.lbs()[k] = ll * Sb[k];
+      P.is()[k] = Sx[k] * Sb[k];
+    }
+  }
+  for (int k = threadIdx.x; k < d.ntot; k += NT)
+    P.delta()[k] = S[k];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Ruiz equilibration, reference preconditioner/ruiz.hpp:29-311.  The cumulative
+// scaling S stays in LDS and every sweep takes its norms from the UNSCALED model
+// with S applied on the fly: two read-only coalesced passes per sweep instead of
+// a read-modify-write of H, A and C.
+// ---------------------------------------------------------------------------
+template<int NT>
+__device__ __forceinline__ double
+ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl, Reducer<NT>& R)
+{
+  const QpRef P(batch, q);
+  const Dims& d = batch.d;
+  const int n = d.n, ne = d.n_eq, ni = d.n_in, ntot = d.ntot;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  constexpr int NW = NT / WAVE;
+  double c = 1, gamma = 1;
+  for (int k = threadIdx.x; k < ntot; k += NT) {
+    S[k] = 1.0;
+    dl[k] = 0.0; // LDLT_TEMP_VEC is zero-initialised (ruiz.hpp:75)
+  }
+  __syncthreads();
+  lptr Sx = S;
+  lptr Se = S + n;
+  lptr Si = S + n + ne;
+  lptr Sb = S + n + ne + ni;
+  cgptr H = P.H();
+  cgptr A = P.A();
+  cgptr C = P.C();
+  const bool infeas = st.primal_infeasibility_solving != 0;
+  long iter = 1;
+  while (true) {
+    double e = 0;
+    for (int k = threadIdx.x; k < ntot; k += NT)
+      e = fmax(e, fabs(1 - dl[k]));
+    e = R.max(e);
+    if (!(e > st.preconditioner_accuracy))
+      break;
+    if (iter == st.preconditioner_max_iter)
+      break;
+    ++iter;
+    // column norms of [H; A; C] under the current scaling: thread per column
+    for (int k = threadIdx.x; k < n; k += NT) {
+      double m = 0;
+      if (d.hessian == PQP_HESSIAN_DENSE) {
+        double hm = 0;
+        for (int i = 0; i < n; ++i)
+          hm = fmax(hm, Sx[i] * fabs(H[(long)i * n + k]));
+        m = hm * Sx[k];
+      } else if (d.hessian == PQP_HESSIAN_DIAGONAL) {
+        m = fabs(H[(long)k * n + k]) * Sx[k] * Sx[k] * c;
+      }
+      double am = 0;
+      for (int i = 0; i < ne; ++i)
+        am = fmax(am, Se[i] * fabs(A[(long)i * n + k]));
+      if (ne > 0)
+        m = fmax(m, am * Sx[k]);
+      double cm = 0;
+      for (int i = 0; i < ni; ++i)
+        cm = fmax(cm, Si[i] * fabs(C[(long)i * n + k]));
+      if (ni > 0)
+        m = fmax(m, cm * Sx[k]);
+      if (d.box)
+        m = fmax(m, Sx[k] * Sb[k]);
+      double aux = sqrt(m);
+      dl[k] = (aux == 0.0) ? 1.0 : 1.0 / (aux + MACHINE_EPS);
+    }
+    // row norms of A and C: one wavefront per row, lanes along the row
+    if (infeas) {
+      for (int k = n + threadIdx.x; k < ntot; k += NT)
+        dl[k] = 1.0;
+    } else {
+      for (int r = wid; r < ne + ni; r += NW) {
+        cgptr row = (r < ne) ? (A + (long)r * n) : (C + (long)(r - ne) * n);
+        double m = 0;
+        for (int k = lane; k < n; k += WAVE)
+          m = fmax(m, fabs(row[k]) * Sx[k]);
+        m = wave_max(m);
+        if (lane == 0) {
+          double sr = (r < ne) ? Se[r] : Si[r - ne];
+          double aux = sqrt(m * sr);
+          dl[n + r] = (aux == 0.0) ? 1.0 : 1.0 / (aux + MACHINE_EPS);
+        }
+      }
+      if (d.box)
+        for (int k = threadIdx.x; k < n; k += NT)
+          dl[n + ne + ni + k] = 1.0 / sqrt(Sx[k] * Sb[k] + MACHINE_EPS);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ntot; k += NT)
+      S[k] *= dl[k];
+    __syncthreads();
+    // cost scaling gamma (ruiz.hpp:256-303); NB: not applied to a Dense H
+    if (d.hessian == PQP_HESSIAN_DENSE) {
+      double acc = 0;
+      for (int k = threadIdx.x; k < n; k += NT) {
+        double hm = 0;
+        for (int i = 0; i < n; ++i)
+          hm = fmax(hm, Sx[i] * fabs(H[(long)i * n + k]));
+        acc += hm * Sx[k];
+      }
+      acc = R.sum(acc);
+      gamma = 1 / fmax(1.0, acc / (double)n);
+    } else if (d.hessian == PQP_HESSIAN_DIAGONAL) {
+      double mx = 0;
+      for (int k = threadIdx.x; k < n; k += NT)
+        mx = fmax(mx, fabs(H[(long)k * n + k]) * Sx[k] * Sx[k] * c);
+      mx = R.max(mx);
+      gamma = 1 / fmax(1.0, mx / (double)n);
+    }
+    c *= gamma;
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------------------
+// setup kernel body: QP::init / QP::update / QP::cleanup
+// (reference dense/wrapper.hpp:354-498, 723-807, 958-962; helpers.hpp:500-705)
+// The host side has already mutated `settings` exactly as the reference does and
+// copied the provided arrays into the model buffers.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t
+setup_lds_bytes(const Dims& d, int nt)
+{
+  return (size_t)(2 * d.ntot + 2 * 4 * (nt / WAVE) + 16) * sizeof(double);
+}
+
+template<int NT>
+__device__ __forceinline__ void
+setup_body(const Batch& batch, long q, lptr lds_base)
+{
+  const Dims& d = batch.d;
+  const QpRef P(batch, q);
+  const Cmd cmd = batch.cmd[q];
+  if (cmd.op == CMD_NONE)
+    return;
+  const pqp_settings& st = P.settings();
+  State& W = *P.state();
+  pqp_info& info = *P.info();
+  const int n = d.n, ne = d.n_eq, nc = d.nc;
+  lptr S = lds_base;
+  lptr dl = S + d.ntot;
+  lptr red = dl + d.ntot;
+  Reducer<NT> R(red);
+
+  if (cmd.op == CMD_CLEANUP) { // wrapper.hpp:958-962
+    for (int k = threadIdx.x; k < n; k += NT)
+      P.x()[k] = 0;
+    for (int k = threadIdx.x; k < ne; k += NT) {
+      P.y()[k] = 0;
+      P.se()[k] = 0;
+    }
+    for (int k = threadIdx.x; k < nc; k += NT) {
+      P.z()[k] = 0;
+      P.si()[k] = 0;
+    }
+    if (threadIdx.x == 0) {
+      cold_start(info, st);
+      work_cleanup_flags(W);
+    }
+    return;
+  }
+
+  const bool is_init = (cmd.op == CMD_INIT) || !W.is_initialized; // wrapper.hpp:743-746
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (is_init) {
+      W.refactorize = (st.initial_guess == PQP_WARM_START_WITH_PREVIOUS_RESULT) ? 1 : 0;
+      W.proximal_parameter_update = 0;
+    } else {
+      W.refactorize = cmd.matrices_given ? 1 : 0; // helpers.hpp:466-468
+      W.proximal_parameter_update = 0;
+    }
+    // helpers.hpp:678-705
+    if (!absent(cmd.rho)) {
+      info.rho = cmd.rho;
+      W.proximal_parameter_update = 1;
+    }
+    if (!absent(cmd.mu_eq)) {
+      info.mu_eq = cmd.mu_eq;
+      info.mu_eq_inv = 1.0 / cmd.mu_eq;
+      W.proximal_parameter_update = 1;
+    }
+    if (!absent(cmd.mu_in)) {
+      info.mu_in = cmd.mu_in;
+      info.mu_in_inv = 1.0 / cmd.mu_in;
+      W.proximal_parameter_update = 1;
+    }
+    // helpers.hpp:174-189 (settings.default_rho already carries the shift)
+    if (!absent(cmd.min_eig))
+      info.minimal_H_eigenvalue_estimate = cmd.min_eig;
+    info.rho = st.default_rho;
+  }
+  __syncthreads();
+  const int precond = is_init ? (cmd.preconditioner ? 0 : 2) : (cmd.preconditioner ? 0 : 1);
+
+  // helpers.hpp:522-572 : result / workspace reset per initial guess
+  bool zero_xyz = false;
+  {
+    const int ig = st.initial_guess;
+    const bool ppu = W.proximal_parameter_update != 0;
+    const bool refac = W.refactorize != 0;
+    __syncthreads();
+    if (ig == PQP_EQUALITY_CONSTRAINED_INITIAL_GUESS || ig == PQP_NO_INITIAL_GUESS ||
+        ig == PQP_WARM_START) {
+      zero_xyz = true;
+      if (threadIdx.x == 0) {
+        if (ppu)
+          cleanup_statistics(info);
+        else
+          cold_start(info, st);
+        work_cleanup_flags(W);
+      }
+    } else if (ig == PQP_COLD_START_WITH_PREVIOUS_RESULT) {
+      if (threadIdx.x == 0) {
+        if (ppu)
+          cleanup_statistics(info);
+        else
+          cold_start(info, st);
+        work_cleanup_flags(W);
+      }
+    } else { // WARM_START_WITH_PREVIOUS_RESULT
+      if (threadIdx.x == 0) {
+        if (refac || ppu) {
+          work_cleanup_flags(W);
+          W.refactorize = 1;
+        }
+        cleanup_statistics(info);
+      }
+    }
+  }
+  if (zero_xyz) {
+    for (int k = threadIdx.x; k < n; k += NT)
+      P.x()[k] = 0;
+    for (int k = threadIdx.x; k < ne; k += NT) {
+      P.y()[k] = 0;
+      P.se()[k] = 0;
+    }
+    for (int k = threadIdx.x; k < nc; k += NT) {
+      P.z()[k] = 0;
+      P.si()[k] = 0;
+    }
+  }
+  // helpers.hpp:651
+  {
+    double m = 0;
+    for (int k = threadIdx.x; k < n; k += NT)
+      m = fmax(m, fabs(P.g()[k]));
+    m = R.max(m);
+    if (threadIdx.x == 0)
+      W.dual_feasibility_rhs_2 = m;
+  }
+  // helpers.hpp:652-666 -> setup_equilibration (:298-329)
+  double c;
+  if (precond == 0) {
+    c = ruiz_execute<NT>(batch, q, st, S, dl, R);
+  } else {
+    c = W.ruiz_c;
+    for (int k = threadIdx.x; k < d.ntot; k += NT)
+      S[k] = P.delta()[k];
+    __syncthreads();
+  }
+  write_scaled<NT>(batch, q, S, c, true);
+  {
+    double m = 0;
+    for (int k = threadIdx.x; k < n; k += NT)
+      m = fmax(m, fabs(P.g()[k] * S[k] * c));
+    m = R.max(m);
+    if (threadIdx.x == 0) {
+      W.correction_guess_rhs_g = m;
+      W.ruiz_c = c;
+      if (is_init)
+        W.is_initialized = 1;
+    }
+  }
+}
+
+// ===========================================================================
+//                               SOLVE
+// ===========================================================================
+template<int NT>
+struct Solver
+{
+  const Batch& batch;
+  const long q;
+  const Dims d;
+  const QpRef P;
+  Lds L;
+  Reducer<NT> R;
+  const pqp_settings& st;
+  pqp_info info; // working copy, written back at exit
+  int n_c;       // active inequality count
+  int r;         // n_eq + n_c : size of the dual block
+  bool schur_dirty;
+  double ruiz_c;
+  double dual_feasibility_rhs_2;
+  long long t_mark;
+
+  __device__ __forceinline__ Solver(const Batch& b, long q_, lptr lds_base)
+    : batch(b)
+    , q(q_)
+    , d(b.d)
+    , P(b, q_)
+    , R(nullptr)
+    , st(b.settings[q_])
+  {
+    lds_carve(L, lds_base, d, NT);
+    R = Reducer<NT>(L.red);
+    t_mark = 0;
+    n_c = 0;
+    r = d.n_eq;
+    schur_dirty = true;
+  }
+
+  // phase timers / event counters: thread 0 only, accumulated in LDS
+  __device__ __forceinline__ void tic()
+  {
+    if (threadIdx.x == 0)
+      t_mark = clock64();
+  }
+  __device__ __forceinline__ void toc(int which)
+  {
+    if (threadIdx.x == 0) {
+      long long t = clock64();
+      L.stat[which] += t - t_mark;
+      t_mark = t;
+    }
+  }
+  __device__ __forceinline__ void count(int which, long long v = 1)
+  {
+    if (threadIdx.x == 0)
+      L.stat[which] += v;
+  }
+
+  // ---- small helpers --------------------------------------------------------
+  __device__ __forceinline__ void vzero(lptr v, int len)
+  {
+    for (int k = threadIdx.x; k < len; k += NT)
+      v[k] = 0;
+  }
+  __device__ __forceinline__ void vcopy(lptr dst, clptr src, int len)
+  {
+    for (int k = threadIdx.x; k < len; k += NT)
+      dst[k] = src[k];
+  }
+  __device__ __forceinline__ void vload(lptr dst, cgptr src, int len)
+  {
+    for (int k = threadIdx.x; k < len; k += NT)
+      dst[k] = src[k];
+  }
+  __device__ __forceinline__ void vstore(gptr dst, clptr src, int len)
+  {
+    for (int k = threadIdx.x; k < len; k += NT)
+      dst[k] = src[k];
+  }
+  __device__ __forceinline__ bool flag_up(int i) const { return (L.aflags[i] & 1) != 0; }
+  __device__ __forceinline__ bool flag_low(int i) const { return (L.aflags[i] & 2) != 0; }
+  __device__ __forceinline__ int cid_of_slot(int a) const
+  {
+    return (a < d.n_eq) ? a : d.n_eq + L.act[a - d.n_eq];
+  }
+  // plain mat-vec through the shared routine
+  __device__ __forceinline__ void mv(cgptr M, int ld, int K, int J, clptr v, lptr out)
+  {
+    gemv<NT>(M, ld, K, J, v, out, L.part, nullptr, 0, nullptr, 0);
+  }
+
+  // ---- primal block ---------------------------------------------------------
+  // H_s + rho I = L D L^T and the explicit L^{-1} (reference helpers.hpp:252-264 for
+  // the assembled block, ldlt.hpp:718-744 for the factorisation it feeds)
+  __device__ __forceinline__ void factor_primal_block()
+  {
+    const int n = d.n;
+    const double rho = info.rho;
+    if (d.hessian == PQP_HESSIAN_DENSE) {
+      gptr F = P.F();
+      cgptr Hs = P.Hs();
+      for (int o = threadIdx.x; o < n * n; o += NT) {
+        int rr = o / n, k = o - rr * n;
+        F[o] = Hs[o] + ((rr == k) ? rho : 0.0);
+      }
+      __syncthreads();
+      ldlt_factor<NT>(F, n, n, L.dF, L.top);
+      tri_inverse<NT>(F, n, n, P.WL(), P.WU());
+    } else {
+      // diagonal / zero Hessian: L = I
+      cgptr Hs = P.Hs();
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.dF[k] = ((d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] : 0.0) + rho;
+      __syncthreads();
+    }
+    vstore(P.dF(), L.dF, n);
+    for (int k = threadIdx.x; k < d.nd; k += NT)
+      L.zvalid[k] = 0;
+    __syncthreads();
+  }
+
+  // out = L^{-1} v  /  out = L^{-T} v   (LDS vectors, may alias)
+  __device__ __forceinline__ void apply_Linv(clptr v, lptr out, bool transposed)
+  {
+    if (d.hessian == PQP_HESSIAN_DENSE) {
+      mv(transposed ? (cgptr)P.WL() : (cgptr)P.WU(), d.n, d.n, d.n, v, out);
+    } else if (v != out) {
+      vcopy(out, v, d.n);
+      __syncthreads();
+    }
+  }
+
+  // z_cid = L^{-1} b_cid and the Gram row of cid against every validated constraint
+  __device__ __forceinline__ void validate_constraint(int cid)
+  {
+    const int n = d.n, nd = d.nd;
+    // row of B = [A_s; C_s; diag(i_scaled)]
+    if (cid < d.n_eq) {
+      vload(L.t1, P.As() + (long)cid * n, n);
+    } else if (cid < d.n_eq + d.n_in) {
+      vload(L.t1, P.Cs() + (long)(cid - d.n_eq) * n, n);
+    } else {
+      int j = cid - d.n_eq - d.n_in;
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.t1[k] = (k == j) ? L.isc[k] : 0.0;
+    }
+    __syncthreads();
+    apply_Linv(L.t1, L.t1, false);
+    {
+      gptr Zr = P.Zr(), Zc = P.Zc();
+      for (int j = threadIdx.x; j < n; j += NT) {
+        double s = L.t1[j];
+        Zr[(long)cid * n + j] = s;
+        Zc[(long)j * nd + cid] = s;
+        L.t1[j] = s / L.dF[j];
+      }
+    }
+    if (threadIdx.x == 0)
+      L.zvalid[cid] = 1;
+    __syncthreads();
+    mv(P.Zc(), nd, n, nd, L.t1, L.t2);
+    {
+      gptr G = P.G();
+      for (int j = threadIdx.x; j < nd; j += NT)
+        if (L.zvalid[j]) {
+          double s = L.t2[j];
+          G[(long)cid * nd + j] = s;
+          G[(long)j * nd + cid] = s;
+        }
+    }
+    __syncthreads();
+    count(ST_N_NEW_ROWS);
+  }
+
+  // ---- dual Schur block: gather M_J + G_JJ in slot order and factorise it -----
+  __device__ __forceinline__ void factor_schur()
+  {
+    const int nd = d.nd;
+    const int rr = r;
+    cgptr G = P.G();
+    gptr LS = P.LS();
+    for (int o = threadIdx.x; o < rr * rr; o += NT) {
+      int a = o / rr, b = o - a * rr;
+      int ca = cid_of_slot(a), cb = cid_of_slot(b);
+      double v = G[(long)ca * nd + cb];
+      if (a == b)
+        v += (a < d.n_eq) ? info.mu_eq : info.mu_in;
+      LS[(long)a * nd + b] = v;
+    }
+    __syncthreads();
+    ldlt_factor<NT>(LS, nd, rr, L.dS, L.top);
+    schur_dirty = false;
+    count(ST_N_SCHUR_FACT);
+  }
+
+  // Solve K [sx; sd] = [bx; bd] in place, K = [[H_s+rho I, B_J^T],[B_J, -M_J]].
+  // (reference solver.hpp:320-335 -> ldlt.hpp:767-782)
+  __device__ __forceinline__ void kkt_solve_in_place(lptr bx, lptr bd)
+  {
+    const int n = d.n, nd = d.nd;
+    const int rr = r;
+    apply_Linv(bx, L.t1, false); // t = L^{-1} bx
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.t2[k] = L.t1[k] / L.dF[k];
+    __syncthreads();
+    if (rr > 0) {
+      // s_a = z_a . (t / D) - bd_a     (gather of the active columns of Zc)
+      gemv<NT>(P.Zc(), nd, n, rr, L.t2, L.t2, L.part, nullptr, 0, L.act, d.n_eq);
+      for (int a = threadIdx.x; a < rr; a += NT)
+        bd[a] = L.t2[a] - bd[a];
+      __syncthreads();
+      // (M + G) dvec = s
+      ldlt_solve<NT>(P.LS(), nd, rr, L.dS, bd, L.top);
+      // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
+      gemv<NT>(P.Zr(), n, rr, n, bd, L.t2, L.part, L.act, d.n_eq, nullptr, 0);
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.t1[k] = (L.t1[k] - L.t2[k]) / L.dF[k];
+      __syncthreads();
+    } else {
+      vcopy(L.t1, L.t2, n);
+      __syncthreads();
+    }
+    apply_Linv(L.t1, bx, true); // x = L^{-T} (.)
+    count(ST_N_KKT_SOLVES);
+  }
+
+  // err = rhs - K * sol for sol = (L.dx, L.sd); by-products Hdx, Adx, ATdy, the
+  // ACTIVE part of C^T dz in CTdz and C dx for all rows in Cdx (solver.hpp:243-318)
+  __device__ __forceinline__ void kkt_residual()
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
+    const double rho = info.rho;
+    for (int i = threadIdx.x; i < nc; i += NT) {
+      int s = L.slot_of[i];
+      L.zfull[i] = (s >= 0) ? L.sd[ne + s] : 0.0;
+    }
+    __syncthreads();
+    if (d.hessian == PQP_HESSIAN_DENSE) {
+      mv(P.Hs(), n, n, n, L.dx, L.Hdx);
+    } else {
+      cgptr Hs = P.Hs();
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.Hdx[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.dx[k] : 0.0;
+    }
+    if (ne > 0) {
+      mv(P.As(), n, ne, n, L.sd, L.ATdy);
+      mv(P.ATs(), ne, n, ne, L.dx, L.Adx);
+    } else {
+      vzero(L.ATdy, n);
+    }
+    if (ni > 0) {
+      mv(P.Cs(), n, ni, n, L.zfull, L.CTdz);
+      mv(P.CTs(), ni, n, ni, L.dx, L.Cdx);
+    } else {
+      vzero(L.CTdz, n);
+    }
+    __syncthreads();
+    if (d.box) {
+      for (int k = threadIdx.x; k < n; k += NT) {
+        L.CTdz[k] += L.zfull[ni + k] * L.isc[k];
+        L.Cdx[ni + k] = L.dx[k] * L.isc[k];
+      }
+      __syncthreads();
+    }
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.ex[k] = L.rx[k] - rho * L.dx[k] - L.Hdx[k] - L.ATdy[k] - L.CTdz[k];
+    for (int k = threadIdx.x; k < ne; k += NT)
+      L.ed[k] = L.rd[k] - L.Adx[k] + L.sd[k] * info.mu_eq;
+    for (int i = threadIdx.x; i < nc; i += NT) {
+      int s = L.slot_of[i];
+      if (s >= 0)
+        L.ed[ne + s] = L.rd[ne + s] - (L.Cdx[i] - L.sd[ne + s] * info.mu_in);
+    }
+    __syncthreads();
+  }
+
+  __device__ __forceinline__ double err_norm()
+  {
+    double m = 0;
+    for (int k = threadIdx.x; k < d.n; k += NT)
+      m = fmax(m, fabs(L.ex[k]));
+    for (int k = threadIdx.x; k < r; k += NT)
+      m = fmax(m, fabs(L.ed[k]));
+    return R.max(m);
+  }
+
+  // reference solver.hpp:406-541: solve + iterative refinement on the unfactorised
+  // operator.  The refactorisation fallback (:474-532) has nothing to rebuild here:
+  // the Schur block is re-factorised from G on every change and never drifts.
+  // In: rhs in (L.rx, L.rd).  Out: solution in (L.dx, L.sd).
+  __device__ __forceinline__ void iterative_solve(double eps)
+  {
+    const int n = d.n;
+    vzero(L.dx, n);
+    vzero(L.sd, r);
+    vcopy(L.ex, L.rx, n);
+    vcopy(L.ed, L.rd, r);
+    __syncthreads();
+    long it = 0, it_stability = 0;
+    double preverr = 0, cur = 0;
+    while (true) {
+      tic();
+      kkt_solve_in_place(L.ex, L.ed);
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.dx[k] += L.ex[k];
+      for (int k = threadIdx.x; k < r; k += NT)
+        L.sd[k] += L.ed[k];
+      __syncthreads();
+      toc(ST_CYC_KKT_SOLVE);
+      kkt_residual();
+      toc(ST_CYC_RESIDUAL);
+      ++it;
+      cur = err_norm();
+      if (it > 1) {
+        if (cur > preverr)
+          it_stability += 1;
+        else
+          it_stability = 0;
+        if (it_stability == 2)
+          break;
+      }
+      preverr = cur;
+      if (!(cur >= eps))
+        break;
+      if (it >= st.nb_iterative_refinement)
+        break;
+    }
+    info.iterative_residual = cur;
+  }
+
+  // new active set from L.aflags (bit2 = wanted active): rebuilds the slot map in
+  // ascending constraint order, validates rows that enter the factorisation for the
+  // first time and re-factorises the Schur block when anything changed.
+  // (reference linesearch.hpp:549-786 does the same job by editing its LDL^T)
+  __device__ __forceinline__ void apply_active_set()
+  {
+    const int nc = d.nc, ne = d.n_eq;
+    tic();
+    bool changed_local = false;
+    int total = 0;
+    for (int base = 0; base < nc; base += NT) {
+      int i = base + threadIdx.x;
+      bool want = (i < nc) && ((L.aflags[i] & 4) != 0);
+      bool had = (i < nc) && (L.slot_of[i] >= 0);
+      if (want != had)
+        changed_local = true;
+      int tot;
+      int rank = block_rank<NT>(want, L.icnt, tot);
+      if (want) {
+        L.slot_of[i] = total + rank;
+        L.act[total + rank] = i;
+      } else if (i < nc) {
+        L.slot_of[i] = -1;
+      }
+      total += tot;
+    }
+    double ch = R.max(changed_local ? 1.0 : 0.0);
+    n_c = total;
+    r = ne + n_c;
+    if (ch != 0.0)
+      schur_dirty = true;
+    for (int a = 0; a < r; ++a) {
+      int cid = cid_of_slot(a);
+      if (!L.zvalid[cid])
+        validate_constraint(cid);
+    }
+    toc(ST_CYC_ZG);
+    if (schur_dirty && r > 0)
+      factor_schur();
+    toc(ST_CYC_SCHUR);
+  }
+
+  // reference utils.hpp:164-252
+  __device__ __forceinline__ void global_primal_residual(double& lhs, double& eq_rhs_0, double& in_rhs_0,
+                                                         double& eq_lhs, double& in_lhs)
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in;
+    double m_eq0 = 0, m_in0 = 0, m_eql = 0, m_inl = 0;
+    if (ne > 0)
+      mv(P.ATs(), ne, n, ne, L.x, L.se);
+    if (ni > 0)
+      mv(P.CTs(), ni, n, ni, L.x, L.rup);
+    {
+      cgptr de = P.dlt_eq();
+      cgptr bb = P.bvec();
+      for (int j = threadIdx.x; j < ne; j += NT) {
+        double v = L.se[j] / de[j]; // unscaled A x
+        m_eq0 = fmax(m_eq0, fabs(v));
+        v -= bb[j];
+        m_eql = fmax(m_eql, fabs(v));
+        L.se[j] = v;
+      }
+      cgptr di = P.dlt_in();
+      cgptr uu = P.u(), ll = P.l();
+      for (int j = threadIdx.x; j < ni; j += NT) {
+        double v = L.rup[j] / di[j]; // unscaled C x
+        L.rup[j] = v;
+        m_in0 = fmax(m_in0, fabs(v));
+        double pu = v - uu[j], pl = v - ll[j];
+        double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
+        L.si[j] = sv;
+        m_inl = fmax(m_inl, fabs(sv));
+      }
+    }
+    if (d.box) {
+      cgptr dx = P.dlt_x();
+      cgptr ub = P.u_box(), lb = P.l_box();
+      for (int k = threadIdx.x; k < n; k += NT) {
+        double v = L.x[k] * dx[k]; // unscaled x
+        L.rup[ni + k] = v;
+        double pu = v - ub[k], pl = v - lb[k];
+        double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
+        L.si[ni + k] = sv;
+        m_inl = fmax(m_inl, fabs(sv));
+        m_in0 = fmax(m_in0, fabs(L.x[k] - sv)); // utils.hpp:225-229 (as written)
+        m_in0 = fmax(m_in0, fabs(L.x[k]));      // utils.hpp:230-231
+      }
+    }
+    R.max3(m_eq0, m_in0, m_eql);
+    eq_rhs_0 = m_eq0;
+    in_rhs_0 = m_in0;
+    eq_lhs = m_eql;
+    in_lhs = R.max(m_inl);
+    lhs = fmax(eq_lhs, in_lhs);
+    if (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE) {
+      // utils.hpp:241-248 : || A^T se + C^T si ||_inf on the unscaled model
+      __syncthreads();
+      vzero(L.t1, n);
+      vzero(L.t2, n);
+      __syncthreads();
+      if (ne > 0)
+        mv(P.A(), n, ne, n, L.se, L.t1);
+      if (ni > 0)
+        mv(P.C(), n, ni, n, L.si, L.t2);
+      double m = 0;
+      for (int k = threadIdx.x; k < n; k += NT)
+        m = fmax(m, fabs(L.t1[k] + L.t2[k]));
+      lhs = R.max(m);
+    }
+    {
+      cgptr de = P.dlt_eq();
+      for (int k = threadIdx.x; k < ne; k += NT)
+        L.se[k] *= de[k];
+    }
+    __syncthreads();
+  }
+
+  // reference utils.hpp:437-587
+  __device__ __forceinline__ void global_dual_residual(double& lhs, double& rhs_0, double& rhs_1,
+                                                       double& rhs_3, double& rhs_duality_gap,
+                                                       double& duality_gap)
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in;
+    const double c = ruiz_c;
+    cgptr dx = P.dlt_x();
+    double m0 = 0, m1 = 0, m3 = 0, ml = 0;
+    double xHx = 0, gx = 0;
+    // H x -> t1, A^T y -> ATdy-free scratch (t2), C^T z -> CTzin-free... use t1/t2/zfull? keep
+    // three distinct n-vectors: t1, t2 and ex (free outside the Newton loop)
+    if (d.hessian == PQP_HESSIAN_DENSE) {
+      mv(P.Hs(), n, n, n, L.x, L.t1);
+    } else {
+      cgptr Hs = P.Hs();
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.t1[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x[k] : 0.0;
+    }
+    if (ne > 0)
+      mv(P.As(), n, ne, n, L.y, L.t2);
+    else
+      vzero(L.t2, n);
+    if (ni > 0)
+      mv(P.Cs(), n, ni, n, L.z, L.ex);
+    else
+      vzero(L.ex, n);
+    __syncthreads();
+    {
+      cgptr g = P.g();
+      for (int k = threadIdx.x; k < n; k += NT) {
+        const double sc = dx[k] * c;
+        double hx = L.t1[k], aty = L.t2[k], ctz = L.ex[k];
+        double v = hx / sc; // unscaled H x (utils.hpp:469-471)
+        m0 = fmax(m0, fabs(v));
+        double xu = L.x[k] * dx[k];
+        xHx += v * xu;
+        gx += g[k] * xu;
+        m1 = fmax(m1, fabs(aty / sc));
+        double m3k = fabs(ctz / sc);
+        if (d.box) {
+          double zb = L.z[ni + k] * L.isc[k];
+          ctz += zb;
+          m3k = fmax(m3k, fabs(zb / sc));
+        }
+        m3 = fmax(m3, m3k);
+        double dr = L.gs[k] + hx + aty + ctz;
+        L.dres[k] = dr;
+        ml = fmax(ml, fabs(dr / sc));
+      }
+    }
+    R.max3(m0, m1, m3);
+    rhs_0 = (d.hessian == PQP_HESSIAN_ZERO) ? 0.0 : m0;
+    rhs_1 = m1;
+    rhs_3 = m3;
+    lhs = R.max(ml);
+    // duality gap terms (utils.hpp:482-586)
+    double by = 0, zu = 0, zl = 0, zub = 0, zlb = 0;
+    const double ib = 1.3407807929942596e+154; // sqrt(DBL_MAX), helpers/common.hpp:17-25
+    {
+      cgptr de = P.dlt_eq();
+      cgptr bb = P.bvec();
+      for (int k = threadIdx.x; k < ne; k += NT)
+        by += bb[k] * (L.y[k] * de[k] / c);
+      cgptr di = P.dlt_in();
+      cgptr uu = P.u(), ll = P.l();
+      for (int k = threadIdx.x; k < ni; k += NT) {
+        double zi = L.z[k] * di[k] / c;
+        double uk = uu[k] < ib ? uu[k] : ib;
+        double lk = ll[k] > -ib ? ll[k] : -ib;
+        if (flag_up(k))
+          zu += zi * uk;
+        if (flag_low(k))
+          zl += zi * lk;
+      }
+      if (d.box) {
+        cgptr db = P.dlt_box();
+        cgptr ub = P.u_box(), lb = P.l_box();
+        for (int k = threadIdx.x; k < n; k += NT) {
+          double zi = db[k] * L.z[ni + k] / c;
+          double uk = ub[k] < ib ? ub[k] : ib;
+          double lk = lb[k] > -ib ? lb[k] : -ib;
+          if (flag_up(ni + k))
+            zub += zi * uk;
+          if (flag_low(ni + k))
+            zlb += zi * lk;
+        }
+      }
+    }
+    R.sum4(gx, xHx, by, zu);
+    R.sum2(zl, zub);
+    zlb = R.sum(zlb);
+    duality_gap = gx;
+    rhs_duality_gap = fabs(gx);
+    if (d.hessian != PQP_HESSIAN_ZERO) {
+      duality_gap += xHx;
+      rhs_duality_gap = fmax(rhs_duality_gap, fabs(xHx));
+    }
+    rhs_duality_gap = fmax(rhs_duality_gap, fabs(by));
+    duality_gap += by;
+    rhs_duality_gap = fmax(rhs_duality_gap, fabs(zu));
+    duality_gap += zu;
+    rhs_duality_gap = fmax(rhs_duality_gap, fabs(zl));
+    duality_gap += zl;
+    if (d.box) {
+      rhs_duality_gap = fmax(rhs_duality_gap, fabs(zub));
+      duality_gap += zub;
+      rhs_duality_gap = fmax(rhs_duality_gap, fabs(zlb));
+      duality_gap += zlb;
+    }
+  }
+
+  // ---- exact line search (reference linesearch.hpp:320-538; merit terms GPDAL
+  // :49-167 / PDAL :178-311).  The inequality part of (a, b) for one alpha, as a
+  // serial loop over the constraints run by the thread that owns that alpha.
+  __device__ __forceinline__ void ls_ineq_terms(double alpha, double& a_in, double& b_in)
+  {
+    const int nc = d.nc;
+    const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
+    double sa = 0, sb = 0, sa2 = 0, sb2 = 0;
+    for (int i = 0; i < nc; ++i) {
+      double cdx = L.Cdx[i];
+      double up0 = L.rup[i], lo0 = L.si[i];
+      bool up = (up0 + cdx * alpha) > 0.;
+      bool lo = (lo0 + cdx * alpha) < 0.;
+      double e = (up || lo) ? cdx : 0.0;
+      double apz = (up ? up0 : 0.0) + (lo ? lo0 : 0.0);
+      sa = fma(e, e, sa);
+      sb = fma(apz, e, sb);
+      if (!gpdal) {
+        double e2 = e - L.dz[i] * info.mu_in;
+        double apz2 = apz - L.z[i] * info.mu_in;
+        sa2 = fma(e2, e2, sa2);
+        sb2 = fma(e2, apz2, sb2);
+      }
+    }
+    if (gpdal) {
+      a_in = info.mu_in_inv * sa / st.alpha_gpdal;
+      b_in = info.mu_in_inv * sb / st.alpha_gpdal;
+    } else {
+      a_in = info.mu_in_inv * sa + info.nu * info.mu_in_inv * sa2;
+      b_in = info.mu_in_inv * sb + info.nu * info.mu_in_inv * sb2;
+    }
+  }
+
+  __device__ __forceinline__ double primal_dual_ls()
+  {
+    const int n = d.n, ne = d.n_eq, nc = d.nc;
+    const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
+    // alpha-independent coefficients
+    double s_dxHdx = 0, s_adx2 = 0, s_dx2 = 0, s_e2 = 0;
+    double s_xHdx = 0, s_errdx = 0, s_adxres = 0, s_eres = 0;
+    double s_dz2 = 0, s_dzz = 0;
+    for (int k = threadIdx.x; k < n; k += NT) {
+      double dxk = L.dx[k];
+      s_dxHdx += dxk * L.Hdx[k];
+      s_dx2 += dxk * dxk;
+      s_xHdx += L.x[k] * L.Hdx[k];
+      s_errdx += (info.rho * (L.x[k] - L.xp[k]) + L.gs[k]) * dxk;
+    }
+    for (int k = threadIdx.x; k < ne; k += NT) {
+      double adx = L.Adx[k];
+      double e = adx - L.dy[k] * info.mu_eq;
+      s_adx2 += adx * adx;
+      s_e2 += e * e;
+      s_adxres += adx * (L.se[k] + L.y[k] * info.mu_eq);
+      s_eres += e * L.se[k];
+    }
+    for (int k = threadIdx.x; k < nc; k += NT) {
+      s_dz2 += L.dz[k] * L.dz[k];
+      s_dzz += L.dz[k] * L.z[k];
+    }
+    R.sum4(s_dxHdx, s_adx2, s_dx2, s_e2);
+    R.sum4(s_xHdx, s_errdx, s_adxres, s_eres);
+    R.sum2(s_dz2, s_dzz);
+    const double nu = gpdal ? 1.0 : info.nu;
+    double a0 = s_dxHdx + info.mu_eq_inv * s_adx2 + info.rho * s_dx2 + s_e2 * info.mu_eq_inv * nu;
+    double b0 = s_xHdx + s_errdx + info.mu_eq_inv * s_adxres + nu * info.mu_eq_inv * s_eres;
+    if (gpdal) {
+      a0 += info.mu_in * (1. - st.alpha_gpdal) * s_dz2;
+      b0 += info.mu_in * (1. - st.alpha_gpdal) * s_dzz;
+    }
+    // breakpoints (linesearch.hpp:378-391): every breakpoint gets its own thread and
+    // its own phi'(alpha) -- no sort, no sequential walk
+    const double INF = __builtin_inf();
+    double first_pos_alpha = INF;
+    double my_alpha[2] = { -1.0, -1.0 };
+    double my_grad[2] = { 0.0, 0.0 };
+    int cnt = 0;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      int t = threadIdx.x + rep * NT;
+      if (t < 2 * nc) {
+        int i = t >> 1;
+        double cdx = L.Cdx[i];
+        double al = -1.0;
+        if (cdx != 0.) {
+          double num = (t & 1) ? L.si[i] : L.rup[i];
+          al = -num / (cdx + MACHINE_EPS);
+        }
+        if (al > MACHINE_EPS) {
+          double ai, bi;
+          ls_ineq_terms(al, ai, bi);
+          double gr = (a0 + ai) * al + (b0 + bi);
+          my_alpha[rep] = al;
+          my_grad[rep] = gr;
+          ++cnt;
+          if (!(gr < 0) && al < first_pos_alpha)
+            first_pos_alpha = al;
+        }
+      }
+    }
+    count(ST_N_LS_BREAKPOINTS, cnt);
+    // smallest breakpoint with a non-negative slope: the scan of :427-468 stops there
+    const double afp = R.min(first_pos_alpha);
+    const double cntd = R.sum((double)cnt);
+    if (cntd == 0.0) { // :405-419
+      double ai, bi;
+      ls_ineq_terms(0.0, ai, bi);
+      return -(b0 + bi) / (a0 + ai);
+    }
+    double gfp = -INF, aln = 0;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      if (my_alpha[rep] > 0) {
+        if (my_alpha[rep] == afp && !(my_grad[rep] < 0))
+          gfp = fmax(gfp, my_grad[rep]);
+        if (my_alpha[rep] < afp)
+          aln = fmax(aln, my_alpha[rep]); // last breakpoint strictly before it
+      }
+    }
+    gfp = R.max(gfp);
+    aln = R.max(aln);
+    double gln = -INF;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep)
+      if (my_alpha[rep] > 0 && my_alpha[rep] == aln)
+        gln = fmax(gln, my_grad[rep]);
+    gln = R.max(gln);
+    if (aln == 0.0) { // :477-495
+      double ai, bi;
+      ls_ineq_terms(0.0, ai, bi);
+      gln = b0 + bi;
+    }
+    if (!(afp < INF)) { // :496-526
+      double ai, bi;
+      ls_ineq_terms(2 * aln + 1, ai, bi);
+      return -(b0 + bi) / (a0 + ai);
+    }
+    return fabs(aln - gln * (afp - aln) / (gfp - gln)); // :534-536
+  }
+
+  // reference utils.hpp:269-324 ; mutates ATdy, CTdz, dy, dz in place
+  __device__ __forceinline__ bool primal_infeasibility_certificate()
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
+    const double c = ruiz_c;
+    double ndy = 0, ndz = 0, zero = 0;
+    for (int k = threadIdx.x; k < ne; k += NT)
+      ndy = fmax(ndy, fabs(L.dy[k]));
+    for (int k = threadIdx.x; k < nc; k += NT)
+      ndz = fmax(ndz, fabs(L.dz[k]));
+    R.max3(ndy, ndz, zero);
+    if (!(ndy != 0 || ndz != 0))
+      return false;
+    double lb1 = 0, nrm_dy = 0, nrm_dz = 0, lb2 = 0;
+    {
+      cgptr dx = P.dlt_x();
+      for (int k = threadIdx.x; k < n; k += NT) {
+        L.ATdy[k] /= dx[k] * c;
+        L.CTdz[k] /= dx[k] * c;
+        lb2 = fmax(lb2, fabs(L.ATdy[k] + L.CTdz[k]));
+      }
+      cgptr de = P.dlt_eq();
+      for (int k = threadIdx.x; k < ne; k += NT) {
+        lb1 += L.dy[k] * L.bs[k];
+        L.dy[k] = L.dy[k] * de[k] / c;
+        nrm_dy = fmax(nrm_dy, fabs(L.dy[k]));
+      }
+      cgptr di = P.dlt_in();
+      for (int k = threadIdx.x; k < ni; k += NT) {
+        double v = L.dz[k];
+        lb1 += (v > 0 ? v : 0.0) * L.us[k];
+        lb1 -= (v < 0 ? v : 0.0) * L.ls[k];
+        L.dz[k] = v * di[k] / c;
+        nrm_dz = fmax(nrm_dz, fabs(L.dz[k]));
+      }
+      if (d.box) {
+        cgptr db = P.dlt_box();
+        for (int k = threadIdx.x; k < n; k += NT) {
+          double v = L.dz[ni + k];
+          lb1 += (v > 0 ? v : 0.0) * L.ubs[k];
+          lb1 -= (v < 0 ? v : 0.0) * L.lbs[k];
+          L.dz[ni + k] = db[k] * v / c;
+          nrm_dz = fmax(nrm_dz, fabs(L.dz[ni + k]));
+        }
+      }
+    }
+    lb1 = R.sum(lb1);
+    R.max3(nrm_dy, nrm_dz, lb2);
+    double upper_bound = st.eps_primal_inf * fmax(nrm_dy, nrm_dz);
+    return lb2 <= upper_bound && lb1 <= -upper_bound;
+  }
+
+  // reference utils.hpp:343-419 ; mutates Adx, Cdx, Hdx, dx in place
+  __device__ __forceinline__ bool dual_infeasibility_certificate()
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in;
+    const double c = ruiz_c;
+    double gdx = 0, ndx = 0, nadx = 0, nhdx = 0;
+    {
+      cgptr dx = P.dlt_x();
+      for (int k = threadIdx.x; k < n; k += NT) {
+        L.Hdx[k] /= dx[k] * c;
+        nhdx = fmax(nhdx, fabs(L.Hdx[k]));
+        gdx += L.dx[k] * L.gs[k];
+        L.dx[k] *= dx[k];
+        ndx = fmax(ndx, fabs(L.dx[k]));
+      }
+      cgptr de = P.dlt_eq();
+      for (int k = threadIdx.x; k < ne; k += NT) {
+        L.Adx[k] /= de[k];
+        nadx = fmax(nadx, fabs(L.Adx[k]));
+      }
+      cgptr di = P.dlt_in();
+      for (int k = threadIdx.x; k < ni; k += NT)
+        L.Cdx[k] /= di[k];
+      if (d.box) {
+        cgptr db = P.dlt_box();
+        for (int k = threadIdx.x; k < n; k += NT)
+          L.Cdx[ni + k] /= db[k];
+      }
+    }
+    gdx = R.sum(gdx);
+    R.max3(ndx, nadx, nhdx);
+    double bound = ndx * st.eps_dual_inf;
+    double bound_neg = -bound;
+    double viol = 0; // 1 when some constraint breaks first_cond
+    for (int k = threadIdx.x; k < ni; k += NT) {
+      double v = L.Cdx[k];
+      bool ok = true;
+      if (L.us[k] <= 1.E20 && L.ls[k] >= -1.E20)
+        ok = v <= bound && v >= bound_neg;
+      else if (L.us[k] > 1.E20)
+        ok = v >= bound_neg;
+      else if (L.ls[k] < -1.E20)
+        ok = v <= bound;
+      if (!ok)
+        viol = 1;
+    }
+    if (d.box)
+      for (int k = threadIdx.x; k < n; k += NT) {
+        double v = L.dx[k];
+        bool ok = true;
+        if (L.ubs[k] <= 1.E20 && L.lbs[k] >= -1.E20)
+          ok = v <= bound && v >= bound_neg;
+        else if (L.ubs[k] > 1.E20)
+          ok = v >= bound_neg;
+        else if (L.lbs[k] < -1.E20)
+          ok = v <= bound;
+        if (!ok)
+          viol = 1;
+      }
+    viol = R.max(viol);
+    bool first_cond = (nadx <= bound) && (viol == 0);
+    bound *= c;
+    bound_neg *= c;
+    bool second_cond_alt1 = nhdx <= bound && gdx <= bound_neg;
+    return first_cond && second_cond_alt1 && ndx != 0;
+  }
+
+  // reference solver.hpp:687-743
+  __device__ __forceinline__ double inner_loop_saddle_point()
+  {
+    const int n = d.n, ne = d.n_eq, nc = d.nc;
+    const double zf = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
+    double e1 = 0, e2 = 0, e3 = 0;
+    for (int i = threadIdx.x; i < nc; i += NT) {
+      double up = L.rup[i], lo = L.si[i];
+      double v = (up > 0 ? up : 0.0) + (lo < 0 ? lo : 0.0) - zf * L.z[i] * info.mu_in;
+      e1 = fmax(e1, fabs(v));
+    }
+    for (int k = threadIdx.x; k < ne; k += NT)
+      e2 = fmax(e2, fabs(L.se[k]));
+    for (int k = threadIdx.x; k < n; k += NT)
+      e3 = fmax(e3, fabs(L.dres[k]));
+    R.max3(e1, e2, e3);
+    return fmax(e1, fmax(e2, e3));
+  }
+
+  // One linear step.  mode 0: semismooth Newton step (reference solver.hpp:754-869);
+  // mode 1: equality-constrained initial guess (helpers.hpp:199-228);
+  // mode 2: only install the active set encoded in L.aflags (solver.hpp:1231-1240).
+  __device__ __forceinline__ void linear_step(int mode, double eps)
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
+    const double zfac = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
+    if (mode == 0) {
+      for (int i = threadIdx.x; i < nc; i += NT) {
+        int up = L.rup[i] >= 0 ? 1 : 0;
+        int lo = L.si[i] <= 0 ? 2 : 0;
+        L.aflags[i] = up | lo | ((up | lo) ? 4 : 0);
+      }
+    }
+    __syncthreads();
+    apply_active_set();
+    if (mode == 2)
+      return;
+    tic();
+    if (mode == 0) {
+      // right-hand side (solver.hpp:787-847)
+      for (int i = threadIdx.x; i < nc; i += NT)
+        L.zfull[i] = (L.slot_of[i] >= 0) ? 0.0 : L.z[i]; // inactive multipliers
+      __syncthreads();
+      if (ni > 0)
+        mv(P.Cs(), n, ni, n, L.zfull, L.CTzin);
+      else
+        vzero(L.CTzin, n);
+      __syncthreads();
+      for (int k = threadIdx.x; k < n; k += NT) {
+        double s = L.CTzin[k];
+        if (d.box) {
+          s += L.zfull[ni + k] * L.isc[k];
+          L.CTzin[k] = s;
+        }
+        L.rx[k] = -L.dres[k] + s;
+      }
+      for (int k = threadIdx.x; k < ne; k += NT)
+        L.rd[k] = -L.se[k];
+      for (int i = threadIdx.x; i < nc; i += NT) {
+        int s = L.slot_of[i];
+        if (s >= 0) {
+          double v = 0;
+          if (flag_up(i))
+            v = -L.rup[i] + L.z[i] * info.mu_in * zfac;
+          else if (flag_low(i))
+            v = -L.si[i] + L.z[i] * info.mu_in * zfac;
+          L.rd[ne + s] = v;
+        }
+      }
+    } else {
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.rx[k] = -L.gs[k];
+      for (int k = threadIdx.x; k < ne; k += NT)
+        L.rd[k] = L.bs[k];
+    }
+    __syncthreads();
+    toc(ST_CYC_NEWTON_MISC);
+    iterative_solve(eps);
+    if (mode == 1) {
+      vcopy(L.x, L.dx, n);
+      vcopy(L.y, L.sd, ne);
+      __syncthreads();
+      return;
+    }
+    // un-permute: dz_i = solution of its slot, or -z_i when inactive (:860-868);
+    // C^T dz = (active part, from the last residual) - (inactive multipliers' part)
+    vcopy(L.dy, L.sd, ne);
+    for (int i = threadIdx.x; i < nc; i += NT) {
+      int s = L.slot_of[i];
+      L.dz[i] = (s >= 0) ? L.sd[ne + s] : -L.z[i];
+    }
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.CTdz[k] -= L.CTzin[k];
+    __syncthreads();
+  }
+
+  // reference solver.hpp:882-1077
+  __device__ __forceinline__ void newton_semi_smooth(double eps_int)
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
+    for (long iter = 0; iter <= st.max_iter_in; ++iter) {
+      if (iter == st.max_iter_in) {
+        info.iter += st.max_iter_in + 1;
+        break;
+      }
+      count(ST_N_NEWTON);
+      linear_step(0, eps_int);
+      tic();
+      if (st.merit_function_type == PQP_MERIT_GPDAL) {
+        for (int i = threadIdx.x; i < nc; i += NT)
+          L.Cdx[i] += (st.alpha_gpdal - 1.) * info.mu_in * L.dz[i];
+        __syncthreads();
+      }
+      double alpha = 1.0;
+      if (ni > 0 || d.box)
+        alpha = primal_dual_ls();
+      toc(ST_CYC_LINESEARCH);
+      {
+        double m = 0;
+        for (int k = threadIdx.x; k < n; k += NT)
+          m = fmax(m, fabs(alpha * L.dx[k]));
+        for (int k = threadIdx.x; k < ne; k += NT)
+          m = fmax(m, fabs(alpha * L.dy[k]));
+        for (int k = threadIdx.x; k < nc; k += NT)
+          m = fmax(m, fabs(alpha * L.dz[k]));
+        m = R.max(m);
+        if (m < 1.E-11 && iter > 0) {
+          info.iter += iter + 1;
+          break;
+        }
+      }
+      for (int k = threadIdx.x; k < n; k += NT) {
+        L.x[k] += alpha * L.dx[k];
+        L.dres[k] += alpha * (info.rho * L.dx[k] + L.Hdx[k] + L.ATdy[k] + L.CTdz[k]);
+      }
+      for (int i = threadIdx.x; i < nc; i += NT) {
+        L.rup[i] += alpha * L.Cdx[i];
+        L.si[i] += alpha * L.Cdx[i];
+        L.z[i] += alpha * L.dz[i];
+      }
+      for (int k = threadIdx.x; k < ne; k += NT) {
+        L.se[k] += alpha * (L.Adx[k] - info.mu_eq * L.dy[k]);
+        L.y[k] += alpha * L.dy[k];
+      }
+      __syncthreads();
+      double err_in = inner_loop_saddle_point();
+      bool stop = false;
+      if (iter % st.frequence_infeasibility_check == 0 || st.primal_infeasibility_solving) {
+        bool is_primal_infeasible = primal_infeasibility_certificate();
+        bool is_dual_infeasible = dual_infeasibility_certificate();
+        if (is_primal_infeasible) {
+          info.status = PQP_PRIMAL_INFEASIBLE;
+          if (!st.primal_infeasibility_solving) {
+            info.iter += iter + 1;
+            stop = true;
+          }
+        } else if (is_dual_infeasible) {
+          info.status = PQP_DUAL_INFEASIBLE;
+          info.iter += iter + 1;
+          stop = true;
+        }
+      }
+      toc(ST_CYC_NEWTON_MISC);
+      if (stop)
+        break;
+      if (err_in <= eps_int) {
+        info.iter += iter + 1;
+        break;
+      }
+    }
+  }
+
+  // scale a warm start into the equilibrated space (solver.hpp:1137-1146 etc.)
+  __device__ __forceinline__ void scale_warm_start()
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in;
+    cgptr dx = P.dlt_x(), de = P.dlt_eq(), di = P.dlt_in();
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.x[k] /= dx[k];
+    for (int k = threadIdx.x; k < ne; k += NT)
+      L.y[k] = L.y[k] / de[k] * ruiz_c;
+    for (int k = threadIdx.x; k < ni; k += NT)
+      L.z[k] = L.z[k] / di[k] * ruiz_c;
+    if (d.box) {
+      cgptr db = P.dlt_box();
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.z[ni + k] = L.z[ni + k] / db[k] * ruiz_c;
+    }
+    __syncthreads();
+  }
+
+  // ---- reference solver.hpp:1088-1843 ---------------------------------------
+  __device__ __forceinline__ void solve()
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
+    State W = *P.state();
+    info = *P.info();
+    ruiz_c = W.ruiz_c;
+    dual_feasibility_rhs_2 = W.dual_feasibility_rhs_2;
+    for (int k = threadIdx.x; k < ST_COUNT; k += NT)
+      L.stat[k] = 0;
+    const long long t_start = (threadIdx.x == 0) ? clock64() : 0;
+    // results -> LDS (the warm-start modes read them)
+    vload(L.x, P.x(), n);
+    vload(L.y, P.y(), ne);
+    vload(L.z, P.z(), nc);
+    for (int i = threadIdx.x; i < nc; i += NT) {
+      L.aflags[i] = 0;
+      L.slot_of[i] = -1;
+    }
+    for (int k = threadIdx.x; k < d.nd; k += NT)
+      L.zvalid[k] = 0;
+    __syncthreads();
+
+    // --- what this call has to do (solver.hpp:1125-1376), decided once so that the
+    // heavy phases below have a single call site each
+    const int ig = st.initial_guess;
+    const bool wswpr = (ig == PQP_WARM_START_WITH_PREVIOUS_RESULT);
+    const bool dirty = W.dirty != 0;
+    bool do_rescale = dirty && !wswpr;
+    bool do_factor;      // setup_factorization
+    bool do_scale_ws;    // scale x,y,z into the equilibrated space
+    bool do_aset_from_z; // active set from z != 0
+    bool do_eq_guess = false;
+    bool do_restore = false;
+    if (dirty) {
+      if (ig == PQP_EQUALITY_CONSTRAINED_INITIAL_GUESS || ig == PQP_NO_INITIAL_GUESS) {
+        vzero(L.x, n); // results.cleanup
+        vzero(L.y, ne);
+        vzero(L.z, nc);
+        cold_start(info, st);
+      } else if (wswpr) {
+        cleanup_statistics(info);
+      } else {
+        cold_start(info, st);
+      }
+    }
+    if (ig == PQP_EQUALITY_CONSTRAINED_INITIAL_GUESS) {
+      do_factor = true;
+      do_scale_ws = false;
+      do_aset_from_z = false;
+      do_eq_guess = true;
+    } else if (ig == PQP_NO_INITIAL_GUESS) {
+      do_factor = true;
+      do_scale_ws = false;
+      do_aset_from_z = false;
+    } else if (ig == PQP_COLD_START_WITH_PREVIOUS_RESULT || ig == PQP_WARM_START) {
+      do_factor = true;
+      do_scale_ws = true;
+      do_aset_from_z = true;
+    } else { // WARM_START_WITH_PREVIOUS_RESULT
+      do_scale_ws = true;
+      if (!dirty && W.refactorize) {
+        do_factor = true;
+        do_aset_from_z = true;
+      } else if (!W.factor_valid) {
+        // nothing usable in HBM (e.g. update() before any solve): rebuild
+        do_factor = true;
+        do_aset_from_z = true;
+      } else {
+        do_factor = false;
+        do_aset_from_z = false;
+        do_restore = true;
+      }
+    }
+    __syncthreads();
+    if (do_rescale) {
+      // re-apply the stored equilibration (solver.hpp:1192-1214); u, l unclamped
+      tic();
+      lptr S = L.rx; // rx (n) and rd (nd) are contiguous: ntot doubles, free here
+      vload(S, P.delta(), d.ntot);
+      __syncthreads();
+      write_scaled<NT>(batch, q, S, ruiz_c, false);
+      toc(ST_CYC_SCALE);
+    }
+    vload(L.gs, P.gs(), n);
+    vload(L.bs, P.bs(), ne);
+    vload(L.us, P.us(), ni);
+    vload(L.ls, P.ls(), ni);
+    if (d.box) {
+      vload(L.ubs, P.ubs(), n);
+      vload(L.lbs, P.lbs(), n);
+      vload(L.isc, P.is(), n);
+    }
+    __syncthreads();
+    if (do_scale_ws)
+      scale_warm_start();
+    if (do_factor) {
+      tic();
+      factor_primal_block();
+      toc(ST_CYC_FACTOR_H);
+      n_c = 0;
+      r = ne;
+      schur_dirty = true;
+    }
+    if (do_restore) {
+      // WARM_START_WITH_PREVIOUS_RESULT on an unchanged model: reuse the block
+      // factorisation the previous solve left in HBM (solver.hpp:1173-1187, 1343-1375)
+      vload(L.dF, P.dF(), n);
+      vload(L.dS, P.dS(), d.nd);
+      {
+        const PQP_GLOBAL int* zv = P.zvalid();
+        for (int k = threadIdx.x; k < d.nd; k += NT)
+          L.zvalid[k] = zv[k];
+      }
+      n_c = W.n_c;
+      r = ne + n_c;
+      __syncthreads();
+      {
+        const PQP_GLOBAL int* ga = P.act();
+        for (int j = threadIdx.x; j < n_c; j += NT) {
+          int i = ga[j];
+          L.act[j] = i;
+          L.slot_of[i] = j;
+        }
+      }
+      __syncthreads();
+      schur_dirty = !(W.ls_valid && W.mu_eq_fact == info.mu_eq && W.mu_in_fact == info.mu_in);
+    }
+    if (do_aset_from_z || do_eq_guess) {
+      if (do_aset_from_z) {
+        for (int i = threadIdx.x; i < nc; i += NT)
+          L.aflags[i] = (L.z[i] != 0) ? 4 : 0;
+      }
+      linear_step(do_eq_guess ? 1 : 2, 1.0);
+    }
+
+    // BCL state (solver.hpp:1378-1395)
+    const double bcl_eta_ext_init = pow(0.1, st.alpha_bcl);
+    double bcl_eta_ext = bcl_eta_ext_init;
+    double bcl_eta_in = 1;
+    const double eps_in_min = fmin(st.eps_abs, 1.E-9);
+    double primal_feasibility_eq_rhs_0 = 0, primal_feasibility_in_rhs_0 = 0;
+    double dual_feasibility_rhs_0 = 0, dual_feasibility_rhs_1 = 0, dual_feasibility_rhs_3 = 0;
+    double primal_feasibility_lhs = 0, primal_feasibility_eq_lhs = 0, primal_feasibility_in_lhs = 0;
+    double dual_feasibility_lhs = 0;
+    double duality_gap = 0, rhs_duality_gap = 0;
+    double scaled_eps = st.eps_abs;
+    // The loop body evaluates the residuals at three places per outer iteration in the
+    // reference (top, after the inner loop, before the mu update).  `stage` walks
+    // through them so that each residual routine is instantiated once.
+    double primal_feasibility_lhs_new = 0, dual_feasibility_lhs_new = 0;
+    double new_bcl_mu_in = 0, new_bcl_mu_eq = 0, new_bcl_mu_in_inv = 0, new_bcl_mu_eq_inv = 0;
+    bool is_primal_feasible = false, is_dual_feasible = false;
+    long iter = 0;
+    int stage = 0; // 0: top of loop, 1: after the Newton loop, 2: before the mu update
+    bool done = (st.max_iter <= 0);
+    while (!done) {
+      tic();
+      double pl = 0, dl = 0;
+      const bool want_primal = (stage != 2);
+      const bool want_dual_pre = (stage != 1);
+      if (want_primal)
+        global_primal_residual(pl, primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0,
+                               primal_feasibility_eq_lhs, primal_feasibility_in_lhs);
+      bool want_dual = want_dual_pre;
+      if (stage == 1) {
+        primal_feasibility_lhs_new = pl;
+        is_primal_feasible =
+          primal_feasibility_lhs_new <=
+          (scaled_eps + st.eps_rel * fmax(primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0));
+        info.pri_res = primal_feasibility_lhs_new;
+        want_dual = is_primal_feasible;
+      }
+      if (want_dual)
+        global_dual_residual(dl, dual_feasibility_rhs_0, dual_feasibility_rhs_1, dual_feasibility_rhs_3,
+                             rhs_duality_gap, duality_gap);
+      toc(ST_CYC_GLOBAL_RES);
+      const double rhs_dua_rel =
+        st.eps_rel * fmax(fmax(dual_feasibility_rhs_3, dual_feasibility_rhs_0),
+                          fmax(dual_feasibility_rhs_1, dual_feasibility_rhs_2));
+      if (stage == 0) {
+        primal_feasibility_lhs = pl;
+        dual_feasibility_lhs = dl;
+        info.pri_res = primal_feasibility_lhs;
+        info.dua_res = dual_feasibility_lhs;
+        info.duality_gap = duality_gap;
+        new_bcl_mu_in = info.mu_in;
+        new_bcl_mu_eq = info.mu_eq;
+        new_bcl_mu_in_inv = info.mu_in_inv;
+        new_bcl_mu_eq_inv = info.mu_eq_inv;
+        double rhs_pri = scaled_eps;
+        if (st.eps_rel != 0)
+          rhs_pri += st.eps_rel * fmax(primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0);
+        is_primal_feasible = primal_feasibility_lhs <= rhs_pri;
+        double rhs_dua = st.eps_abs;
+        if (st.eps_rel != 0)
+          rhs_dua += rhs_dua_rel;
+        is_dual_feasible = dual_feasibility_lhs <= rhs_dua;
+        if (is_primal_feasible && is_dual_feasible) {
+          if (st.check_duality_gap) {
+            if (fabs(info.duality_gap) <= st.eps_duality_gap_abs + st.eps_duality_gap_rel * rhs_duality_gap) {
+              info.status = (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)
+                              ? PQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE
+                              : PQP_SOLVED;
+              break;
+            }
+          } else {
+            info.status = PQP_SOLVED;
+            break;
+          }
+        }
+        info.iter_ext += 1;
+        vcopy(L.xp, L.x, n);
+        vcopy(L.yp, L.y, ne);
+        vcopy(L.zp, L.z, nc);
+        // shifted inequality residuals (solver.hpp:1523-1559)
+        {
+          cgptr di = P.dlt_in();
+          cgptr db = P.dlt_box();
+          for (int i = threadIdx.x; i < nc; i += NT) {
+            double sc = (i < ni) ? di[i] : db[i - ni];
+            double v = L.rup[i] * sc + L.z[i] * info.mu_in;
+            if (st.merit_function_type == PQP_MERIT_GPDAL)
+              v += (st.alpha_gpdal - 1.) * info.mu_in * L.z[i];
+            double ub = (i < ni) ? L.us[i] : L.ubs[i - ni];
+            double lb = (i < ni) ? L.ls[i] : L.lbs[i - ni];
+            L.rup[i] = v - ub;
+            L.si[i] = v - lb;
+          }
+        }
+        __syncthreads();
+
+        newton_semi_smooth(bcl_eta_in);
+
+        if ((info.status == PQP_PRIMAL_INFEASIBLE && !st.primal_infeasibility_solving) ||
+            info.status == PQP_DUAL_INFEASIBLE) {
+          vcopy(L.x, L.dx, n); // certificates (solver.hpp:1572-1580)
+          vcopy(L.y, L.dy, ne);
+          vcopy(L.z, L.dz, nc);
+          __syncthreads();
+          break;
+        }
+        if (scaled_eps == st.eps_abs && st.primal_infeasibility_solving &&
+            info.status == PQP_PRIMAL_INFEASIBLE) {
+          // solver.hpp:1581-1595 : || A^T 1 + C^T 1 (+ i_scaled) ||_inf * eps_abs
+          lptr ones = L.zfull; // nc >= n_in; n_eq ones taken from L.sd
+          for (int k = threadIdx.x; k < ni; k += NT)
+            ones[k] = 1.0;
+          for (int k = threadIdx.x; k < ne; k += NT)
+            L.sd[k] = 1.0;
+          vzero(L.t1, n);
+          vzero(L.t2, n);
+          __syncthreads();
+          if (ne > 0)
+            mv(P.A(), n, ne, n, L.sd, L.t1);
+          if (ni > 0)
+            mv(P.C(), n, ni, n, ones, L.t2);
+          double m = 0;
+          for (int k = threadIdx.x; k < n; k += NT)
+            m = fmax(m, fabs(L.t1[k] + L.t2[k] + (d.box ? L.isc[k] : 0.0)));
+          scaled_eps = R.max(m) * st.eps_abs;
+        }
+        stage = 1;
+        continue;
+      }
+      if (stage == 1) {
+        if (is_primal_feasible) {
+          dual_feasibility_lhs_new = dl;
+          info.dua_res = dual_feasibility_lhs_new;
+          info.duality_gap = duality_gap;
+          is_dual_feasible = dual_feasibility_lhs_new <= (st.eps_abs + rhs_dua_rel);
+          if (is_dual_feasible) {
+            bool gap_ok = true;
+            if (st.check_duality_gap)
+              gap_ok = fabs(info.duality_gap) <=
+                       st.eps_duality_gap_abs + st.eps_duality_gap_rel * rhs_duality_gap;
+            if (gap_ok)
+              info.status = (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)
+                              ? PQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE
+                              : PQP_SOLVED;
+          }
+        }
+        if (st.bcl_update) { // solver.hpp:564-614
+          if (primal_feasibility_lhs_new <= bcl_eta_ext || info.iter > st.safe_guard) {
+            bcl_eta_ext *= pow(info.mu_in, st.beta_bcl);
+            bcl_eta_in = fmax(bcl_eta_in * info.mu_in, eps_in_min);
+          } else {
+            vcopy(L.y, L.yp, ne);
+            vcopy(L.z, L.zp, nc);
+            __syncthreads();
+            new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
+            new_bcl_mu_eq = fmax(info.mu_eq * st.mu_update_factor, st.mu_min_eq);
+            new_bcl_mu_in_inv = fmin(info.mu_in_inv * st.mu_update_inv_factor, st.mu_max_in_inv);
+            new_bcl_mu_eq_inv = fmin(info.mu_eq_inv * st.mu_update_inv_factor, st.mu_max_eq_inv);
+            bcl_eta_ext = bcl_eta_ext_init * pow(new_bcl_mu_in, st.alpha_bcl);
+            bcl_eta_in = fmax(new_bcl_mu_in, eps_in_min);
+          }
+        } else { // Martinez, solver.hpp:637-677
+          bcl_eta_in = fmax(bcl_eta_in * 0.1, eps_in_min);
+          if (!(primal_feasibility_lhs_new <= 0.95 * primal_feasibility_lhs)) {
+            new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
+            new_bcl_mu_eq = fmax(info.mu_eq * st.mu_update_factor, st.mu_min_eq);
+            new_bcl_mu_in_inv = fmin(info.mu_in_inv * st.mu_update_inv_factor, st.mu_max_in_inv);
+            new_bcl_mu_eq_inv = fmin(info.mu_eq_inv * st.mu_update_inv_factor, st.mu_max_eq_inv);
+          }
+        }
+        stage = 2;
+        continue;
+      }
+      // stage 2 (solver.hpp:1693-1746)
+      dual_feasibility_lhs_new = dl;
+      info.dua_res = dual_feasibility_lhs_new;
+      info.duality_gap = duality_gap;
+      if (primal_feasibility_lhs_new >= primal_feasibility_lhs &&
+          dual_feasibility_lhs_new >= dual_feasibility_lhs && info.mu_in <= 1e-5) {
+        new_bcl_mu_in = st.cold_reset_mu_in; // cold restart
+        new_bcl_mu_eq = st.cold_reset_mu_eq;
+        new_bcl_mu_in_inv = st.cold_reset_mu_in_inv;
+        new_bcl_mu_eq_inv = st.cold_reset_mu_eq_inv;
+      }
+      if (info.mu_in != new_bcl_mu_in || info.mu_eq != new_bcl_mu_eq) {
+        ++info.mu_updates;
+        // mu_update (solver.hpp:128-232): here a diagonal shift of the Schur block,
+        // re-factorised lazily by the next linear step
+        if (ne + n_c > 0)
+          schur_dirty = true;
+      }
+      info.mu_eq = new_bcl_mu_eq;
+      info.mu_in = new_bcl_mu_in;
+      info.mu_eq_inv = new_bcl_mu_eq_inv;
+      info.mu_in_inv = new_bcl_mu_in_inv;
+      stage = 0;
+      ++iter;
+      if (iter >= st.max_iter)
+        done = true;
+    }
+
+    // unscale the solution (solver.hpp:1749-1767)
+    {
+      cgptr dx = P.dlt_x(), de = P.dlt_eq(), di = P.dlt_in();
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.x[k] *= dx[k];
+      for (int k = threadIdx.x; k < ne; k += NT)
+        L.y[k] = L.y[k] * de[k] / ruiz_c;
+      for (int k = threadIdx.x; k < ni; k += NT)
+        L.z[k] = L.z[k] * di[k] / ruiz_c;
+      if (d.box) {
+        cgptr db = P.dlt_box();
+        for (int k = threadIdx.x; k < n; k += NT)
+          L.z[ni + k] = db[k] * L.z[ni + k] / ruiz_c;
+      }
+      if (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE) {
+        for (int k = threadIdx.x; k < ne; k += NT)
+          L.se[k] /= de[k];
+        for (int k = threadIdx.x; k < ni; k += NT)
+          L.si[k] /= di[k];
+        if (d.box) {
+          cgptr db = P.dlt_box();
+          for (int k = threadIdx.x; k < n; k += NT)
+            L.si[ni + k] /= db[k];
+        }
+      }
+    }
+    __syncthreads();
+    // objective on the unscaled model (solver.hpp:1771-1780)
+    {
+      double obj = 0;
+      cgptr g = P.g();
+      if (d.hessian == PQP_HESSIAN_DENSE) {
+        mv(P.H(), n, n, n, L.x, L.t1);
+        for (int k = threadIdx.x; k < n; k += NT)
+          obj += 0.5 * L.t1[k] * L.x[k] + g[k] * L.x[k];
+      } else {
+        cgptr H = P.H();
+        for (int k = threadIdx.x; k < n; k += NT)
+          obj += 0.5 * L.x[k] * L.x[k] * H[(long)k * n + k] + g[k] * L.x[k];
+      }
+      info.objValue = R.sum(obj);
+    }
+    // write back
+    vstore(P.x(), L.x, n);
+    vstore(P.y(), L.y, ne);
+    vstore(P.z(), L.z, nc);
+    vstore(P.se(), L.se, ne);
+    vstore(P.si(), L.si, nc);
+    vstore(P.dS(), L.dS, d.nd);
+    {
+      PQP_GLOBAL int* ga = P.act();
+      PQP_GLOBAL int* zv = P.zvalid();
+      for (int i = threadIdx.x; i < nc; i += NT)
+        ga[i] = (i < n_c) ? L.act[i] : -1;
+      for (int k = threadIdx.x; k < d.nd; k += NT)
+        zv[k] = L.zvalid[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      *P.info() = info;
+      W.dirty = 1;
+      W.is_initialized = 1;
+      W.n_c = n_c;
+      W.factor_valid = 1;
+      W.ls_valid = schur_dirty ? 0 : 1;
+      W.mu_eq_fact = info.mu_eq;
+      W.mu_in_fact = info.mu_in;
+      W.rho_fact = info.rho;
+      *P.state() = W;
+      L.stat[ST_N_ACTIVE_FINAL] = n_c;
+      L.stat[ST_CYC_TOTAL] = clock64() - t_start;
+      PQP_GLOBAL long long* gs = P.stats();
+      for (int k = 0; k < ST_COUNT; ++k)
+        gs[k] = L.stat[k];
+    }
+  }
+};
+
+template<int NT>
+__device__ __forceinline__ void
+solve_body(const Batch& batch, long q, lptr lds_base)
+{
+  Solver<NT> S(batch, q, lds_base);
+  S.solve();
+}
+
+} // namespace pqp
+
+#endif
