@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -64,9 +65,10 @@ pqp_setup_kernel(pqp::Batch batch)
   pqp::setup_body<NT>(batch, (long)blockIdx.x, (pqp::lptr)smem);
 }
 
-// 1024 threads per CU resident (4 waves per SIMD -> at most 128 VGPRs per lane)
-template<int NT>
-__global__ __launch_bounds__(NT, (NT >= 1024 ? 4 : 4)) void
+// WPS = waves per SIMD the register allocator must leave room for (512 / WPS VGPRs per
+// lane): the knob that trades spills against resident workgroups per CU.
+template<int NT, int WPS>
+__global__ __launch_bounds__(NT, WPS) void
 pqp_solve_kernel(pqp::Batch batch)
 {
   HIP_DYNAMIC_SHARED(double, smem)
@@ -78,6 +80,7 @@ struct pqp_batch
   pqp::Batch dev{};
   int device = 0;
   int nt = 256;
+  int wps = 4; // register budget of the solve kernel: 512 / wps VGPRs (env PQP_WAVES_PER_SIMD)
   int backend = PQP_BACKEND_PRIMAL_DUAL_LDLT;
   size_t lds_solve = 0, lds_setup = 0;
   std::vector<pqp_settings> settings;
@@ -114,22 +117,22 @@ launch_setup(pqp_batch* h)
   if (h->lds_setup > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_setup_kernel<NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_setup));
-  hipLaunchKernelGGL(pqp_setup_kernel<NT>, dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, nullptr,
+  hipLaunchKernelGGL((pqp_setup_kernel<NT>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, nullptr,
                      h->dev);
   HIP_TRY(hipGetLastError());
   return PQP_OK;
 }
 
-template<int NT>
+template<int NT, int WPS>
 int
 launch_solve(pqp_batch* h)
 {
   if (h->lds_solve > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
   HIP_TRY(hipEventRecord(h->ev0, nullptr));
-  hipLaunchKernelGGL(pqp_solve_kernel<NT>, dim3((unsigned)h->dev.B), dim3(NT), h->lds_solve, nullptr,
-                     h->dev);
+  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_solve,
+                     nullptr, h->dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, nullptr));
   return PQP_OK;
@@ -201,11 +204,18 @@ dispatch_solve(pqp_batch* h)
 {
   switch (h->nt) {
     case 256:
-      return launch_solve<256>(h);
+      switch (h->wps) {
+        case 1:
+          return launch_solve<256, 1>(h);
+        case 2:
+          return launch_solve<256, 2>(h);
+        default:
+          return launch_solve<256, 4>(h);
+      }
     case 512:
-      return launch_solve<512>(h);
+      return h->wps >= 4 ? launch_solve<512, 4>(h) : launch_solve<512, 2>(h);
     default:
-      return launch_solve<1024>(h);
+      return launch_solve<1024, 4>(h);
   }
 }
 
@@ -354,6 +364,11 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   if (need > 1024 || d.nc > 1024) {
     delete h;
     return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq+n_in(+n)) > 1024 is not supported by this build");
+  }
+  if (const char* e = std::getenv("PQP_WAVES_PER_SIMD")) {
+    int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4)
+      h->wps = v;
   }
   h->lds_solve = pqp::lds_bytes(d, h->nt);
   h->lds_setup = pqp::setup_lds_bytes(d, h->nt);

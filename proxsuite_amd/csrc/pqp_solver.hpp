@@ -739,6 +739,7 @@ struct Solver
   bool schur_dirty;
   double ruiz_c;
   double dual_feasibility_rhs_2;
+  bool nonfinite;
   long long t_mark;
 
   __device__ __forceinline__ Solver(const Batch& b, long q_, lptr lds_base)
@@ -752,6 +753,7 @@ struct Solver
     lds_carve(L, lds_base, d, NT);
     R = Reducer<NT>(L.red);
     t_mark = 0;
+    nonfinite = false;
     n_c = 0;
     r = d.n_eq;
     schur_dirty = true;
@@ -1706,6 +1708,14 @@ struct Solver
         info.iter += iter + 1;
         break;
       }
+      if (!(err_in == err_in)) {
+        // non-finite iterate: the reference would spin to max_iter and report
+        // MAX_ITER_REACHED (it only asserts on NaN in debug builds, solver.hpp:1838-1840);
+        // stop here with the same status instead of occupying the device
+        info.iter += iter + 1;
+        nonfinite = true;
+        break;
+      }
     }
   }
 
@@ -1962,6 +1972,10 @@ struct Solver
 
         newton_semi_smooth(bcl_eta_in);
 
+        if (nonfinite) {
+          info.status = PQP_MAX_ITER_REACHED;
+          break;
+        }
         if ((info.status == PQP_PRIMAL_INFEASIBLE && !st.primal_infeasibility_solving) ||
             info.status == PQP_DUAL_INFEASIBLE) {
           vcopy(L.x, L.dx, n); // certificates (solver.hpp:1572-1580)

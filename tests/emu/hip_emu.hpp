@@ -366,7 +366,8 @@ enum
   hipFuncAttributeMaxDynamicSharedMemorySize = 8
 };
 
+#define HIPEMU_UNPAREN(...) __VA_ARGS__
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                \
-  hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
+  hipemu::launch((grid), (block), (shmem), [=]() { HIPEMU_UNPAREN kernel(__VA_ARGS__); })
 
 #endif

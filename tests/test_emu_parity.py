@@ -1,0 +1,69 @@
+"""`-m "not gpu"`: the HIP device sources run on the CPU SIMT emulator (tests/emu) and are
+checked against the oracle.  Validates kernel LOGIC before any GPU minute is spent; the
+numerics on the real device are covered by tests/test_gpu_parity.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from proxsuite_amd import _native as N
+from proxsuite_amd._ctypes_defs import HessianType, InitialGuess
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import build as emu_build
+    return N.NativeLib(emu_build.build())
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in N.NativeLib.SYMBOLS:
+        assert hasattr(lib.L, name), name
+
+
+def test_known_answers(lib):
+    pc.case_known_answers(lib)
+
+
+def test_ruiz(lib, oracle, randqp):
+    pc.case_ruiz(lib, oracle, randqp)
+
+
+@pytest.mark.parametrize("shape", [(10, 2, 3), (30, 7, 9), (50, 25, 50), (100, 50, 100)])
+def test_random_batch(lib, oracle, randqp, shape):
+    n, ne, ni = shape
+    pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=8 if n < 100 else 4)
+
+
+@pytest.mark.parametrize("guess", list(InitialGuess))
+def test_state_machine(lib, oracle, randqp, guess):
+    pc.case_state_machine(lib, oracle, randqp, guess)
+
+
+@pytest.mark.parametrize("hessian", [HessianType.Dense, HessianType.Diagonal])
+def test_box_constraints(lib, oracle, randqp, hessian):
+    pc.case_box_constraints(lib, oracle, randqp, seeds=8, hessian=hessian)
+
+
+@pytest.mark.parametrize("dim", [10, 40])
+def test_families(lib, oracle, randqp, dim):
+    pc.case_families(lib, oracle, randqp, dim)
+
+
+def test_maros_meszaros_small(lib):
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maros_meszaros_small.npz")
+    d = np.load(gold)
+    for name in ("HS21", "HS35", "HS76", "TAME", "ZECEVIC2", "HS118", "LOTSCHD", "GENHS28", "QPTEST"):
+        pc.case_maros_meszaros(lib, *(d["%s/%s" % (name, k)] for k in "PqAlu"))
+
+
+def test_errors(lib):
+    pc.case_errors(lib)
+
+
+def test_determinism(lib, randqp):
+    pc.case_determinism(lib, randqp)

@@ -1,0 +1,107 @@
+"""`-m gpu`: parity of the HIP path on a real MI355X, through the C-ABI of
+include/proxqp_hip.h (proxsuite_amd/csrc/libproxqp_hip.so), against the CPU oracle on the same
+seeded inputs, the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties (KKT residuals on the unscaled model, run-to-run determinism)."""
+import os
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from proxsuite_amd import _native as N
+from proxsuite_amd._ctypes_defs import HessianType, InitialGuess
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return N.load()  # raises loudly when the HIP library or the device is missing
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in N.NativeLib.SYMBOLS:
+        assert hasattr(lib.L, name), name
+    assert lib.path.endswith("libproxqp_hip.so")
+
+
+def test_known_answers(lib):
+    pc.case_known_answers(lib)
+
+
+def test_ruiz(lib, oracle, randqp):
+    pc.case_ruiz(lib, oracle, randqp)
+    pc.case_ruiz(lib, oracle, randqp, 100, 50, 100)
+
+
+@pytest.mark.parametrize("shape", [(10, 2, 3, 32), (30, 7, 9, 32), (50, 25, 50, 128), (100, 50, 100, 64),
+                                   (60, 0, 20, 16), (60, 20, 0, 16), (200, 30, 56, 8)])
+def test_random_batch(lib, oracle, randqp, shape):
+    n, ne, ni, B = shape
+    pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=B)
+
+
+def test_equality_constrained_initial_guess_batch(lib, oracle, randqp):
+    pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=32,
+                         guess=InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS)
+
+
+@pytest.mark.parametrize("guess", list(InitialGuess))
+def test_state_machine(lib, oracle, randqp, guess):
+    pc.case_state_machine(lib, oracle, randqp, guess)
+
+
+@pytest.mark.parametrize("hessian", [HessianType.Dense, HessianType.Diagonal])
+def test_box_constraints(lib, oracle, randqp, hessian):
+    pc.case_box_constraints(lib, oracle, randqp, seeds=100, hessian=hessian)
+
+
+@pytest.mark.parametrize("dim", [10, 60, 110])
+def test_families(lib, oracle, randqp, dim):
+    pc.case_families(lib, oracle, randqp, dim)
+
+
+def test_maros_meszaros_small(lib):
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maros_meszaros_small.npz")
+    d = np.load(gold)
+    for name in [str(s) for s in d["names"]]:
+        pc.case_maros_meszaros(lib, *(d["%s/%s" % (name, k)] for k in "PqAlu"))
+
+
+def test_errors(lib):
+    pc.case_errors(lib)
+
+
+def test_determinism(lib, randqp):
+    pc.case_determinism(lib, randqp, 100, 50, 100, B=64)
+
+
+def test_full_size_c2_properties(lib, oracle, randqp):
+    """BASELINE.json configs[1]: 2048 random dense QPs, n=100 n_eq=50 n_in=100.  Every QP must
+    reach SOLVED with unscaled KKT residuals <= 1e-9; a sample is compared with the oracle."""
+    pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=2048, compare=True)
+
+
+def test_c5_shape_diagonal_box(lib, oracle, randqp):
+    """BASELINE.json configs[4] shape (reduced batch): diagonal Hessian + box constraints,
+    benchmark/timings-diagonal-hessian.cpp:43-92."""
+    dim, B = 200, 16
+    H = np.zeros((B, dim, dim))
+    g = np.zeros((B, dim))
+    lb = np.zeros((B, dim))
+    ub = np.zeros((B, dim))
+    for s in range(B):
+        randqp.set_seed(s)
+        m = randqp.dense_box_constrained_qp(dim, 0, dim, 0.15, 1e-2)
+        H[s] = np.diag(np.arange(1, dim + 1, dtype=float))
+        g[s], lb[s], ub[s] = m.g, m.l, m.u
+    b = N.Batch(B, dim, 0, 0, box_constraints=True, hessian_type=int(HessianType.Diagonal), lib=lib)
+    pc.settings_all(b, eps_abs=1e-9, eps_rel=0)
+    b.init(-1, H, g, None, None, None, None, None, lb, ub)
+    b.solve()
+    x, y, z, se, si, info = b.results()
+    z0 = np.zeros(0)
+    for s in range(B):
+        pri, dua = oracle.kkt_residuals(H[s], g[s], None, None, None, z0, z0, x[s], y[s], z[s], lb[s], ub[s])
+        assert pri <= 1e-9 and dua <= 1e-9, (s, pri, dua)
+    b.close()
