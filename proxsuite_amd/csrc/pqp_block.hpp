@@ -257,6 +257,20 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int k = ks;
         if (rowmap) {
+          // gathered rows: resolve 4 row indices, then 4 independent loads
+          for (; k + 3 * KS < K; k += 4 * KS) {
+            int k1 = k + KS, k2 = k + 2 * KS, k3 = k + 3 * KS;
+            int r0 = (k < rowsplit) ? k : rowsplit + rowmap[k - rowsplit];
+            int r1 = (k1 < rowsplit) ? k1 : rowsplit + rowmap[k1 - rowsplit];
+            int r2 = (k2 < rowsplit) ? k2 : rowsplit + rowmap[k2 - rowsplit];
+            int r3 = (k3 < rowsplit) ? k3 : rowsplit + rowmap[k3 - rowsplit];
+            double m0 = col[(long)r0 * ld], m1 = col[(long)r1 * ld];
+            double m2 = col[(long)r2 * ld], m3 = col[(long)r3 * ld];
+            a0 = fma(m0, v[k], a0);
+            a1 = fma(m1, v[k1], a1);
+            a2 = fma(m2, v[k2], a2);
+            a3 = fma(m3, v[k3], a3);
+          }
           for (; k < K; k += KS) {
             int rk = (k < rowsplit) ? k : rowsplit + rowmap[k - rowsplit];
             a0 = fma(col[(long)rk * ld], v[k], a0);
@@ -264,12 +278,19 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
         } else {
           const long step = (long)KS * ld;
           cgptr p = col + (long)k * ld;
-          for (; k + 3 * KS < K; k += 4 * KS) {
-            a0 = fma(p[0], v[k], a0);
-            a1 = fma(p[step], v[k + KS], a1);
-            a2 = fma(p[2 * step], v[k + 2 * KS], a2);
-            a3 = fma(p[3 * step], v[k + 3 * KS], a3);
-            p += 4 * step;
+          // 8 independent loads issued back to back before the first use
+          for (; k + 7 * KS < K; k += 8 * KS) {
+            double m0 = p[0], m1 = p[step], m2 = p[2 * step], m3 = p[3 * step];
+            double m4 = p[4 * step], m5 = p[5 * step], m6 = p[6 * step], m7 = p[7 * step];
+            a0 = fma(m0, v[k], a0);
+            a1 = fma(m1, v[k + KS], a1);
+            a2 = fma(m2, v[k + 2 * KS], a2);
+            a3 = fma(m3, v[k + 3 * KS], a3);
+            a0 = fma(m4, v[k + 4 * KS], a0);
+            a1 = fma(m5, v[k + 5 * KS], a1);
+            a2 = fma(m6, v[k + 6 * KS], a2);
+            a3 = fma(m7, v[k + 7 * KS], a3);
+            p += 8 * step;
           }
           for (; k < K; k += KS) {
             a0 = fma(p[0], v[k], a0);
@@ -346,15 +367,42 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top)
       for (int c = 0; c < NB; ++c)
         if (c < nb && i >= j0 + c)
           p[c] = M[(long)(j0 + c) * ld + i];
-      // left-looking update with the already factorised columns k < j0
-      for (int k = 0; k < j0; ++k) {
-        cgptr rowk = M + (long)k * ld;
-        double lik = rowk[i] * d[k];
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-          if (c < nb)
-            p[c] = fma(-lik, rowk[j0 + c], p[c]);
+    }
+    // left-looking update with the factorised columns k < j0, 16 columns at a time:
+    // the 16 x 16 block W[c][kk] = L[j0+c][k0+kk] * d[k0+kk] is staged in LDS (one
+    // coalesced load per thread), every row thread pulls its own 16 L values with
+    // independent loads (one memory latency per 16 columns instead of one per column)
+    // and the 256 FMAs run out of registers x LDS broadcasts.
+    for (int k0 = 0; k0 < j0; k0 += NB) {
+      {
+        const int c = threadIdx.x / NB, kk = threadIdx.x % NB;
+        if (NT >= NB * NB) {
+          if (threadIdx.x < NB * NB)
+            top[c * NB + kk] = (c < nb) ? M[(long)(j0 + c) * ld + k0 + kk] * d[k0 + kk] : 0.0;
+        } else {
+          for (int o = threadIdx.x; o < NB * NB; o += NT) {
+            int c2 = o / NB, k2 = o % NB;
+            top[o] = (c2 < nb) ? M[(long)(j0 + c2) * ld + k0 + k2] * d[k0 + k2] : 0.0;
+          }
+        }
       }
+      __syncthreads();
+      if (row_active) {
+        double li[NB];
+        cgptr rowi = M + (long)i * ld + k0;
+#pragma unroll
+        for (int kk = 0; kk < NB; ++kk)
+          li[kk] = rowi[kk];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          double acc = p[c];
+#pragma unroll
+          for (int kk = 0; kk < NB; ++kk)
+            acc = fma(-li[kk], top[c * NB + kk], acc);
+          p[c] = acc;
+        }
+      }
+      __syncthreads();
     }
     // in-panel right-looking elimination; one barrier per column
 #pragma unroll

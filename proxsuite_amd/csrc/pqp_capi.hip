@@ -213,7 +213,9 @@ dispatch_solve(pqp_batch* h)
           return launch_solve<256, 4>(h);
       }
     case 512:
-      return h->wps >= 4 ? launch_solve<512, 4>(h) : launch_solve<512, 2>(h);
+      // (512, 4) -- a 128-VGPR budget for an 8-wave workgroup -- produced NaNs on MI355X with
+      // ROCm 7.2 (heavy spilling; parity-checked OK at (512, 2)), so it is not instantiated
+      return launch_solve<512, 2>(h);
     default:
       return launch_solve<1024, 4>(h);
   }

@@ -29,6 +29,7 @@
 namespace pqp {
 
 constexpr double MACHINE_EPS = 2.220446049250313e-16;
+constexpr int VALIDATE_BATCH = 8; // constraint rows validated per pass over L^{-1} / Z
 
 struct Dims
 {
@@ -140,7 +141,7 @@ struct Lds
   lptr dF, dS;
   lptr t1, t2, zfull;
   lptr part, red, top;
-  liptr slot_of, act, zvalid, aflags, icnt;
+  liptr slot_of, act, zvalid, aflags, icnt, vlist;
   PQP_LDS long long* stat;
 };
 
@@ -168,7 +169,7 @@ lds_doubles(const Dims& d, int nt)
 __host__ __device__ inline size_t
 lds_bytes(const Dims& d, int nt)
 {
-  size_t ints = (size_t)d.nc * 3 + d.nd + nt / WAVE + 8;
+  size_t ints = (size_t)d.nc * 3 + d.nd + nt / WAVE + 8 + VALIDATE_BATCH;
   return lds_doubles(d, nt) * sizeof(double) + ints * sizeof(int) + 64;
 }
 
@@ -233,6 +234,8 @@ lds_carve(Lds& L, lptr base, const Dims& d, int nt)
   L.aflags = q;
   q += nc;
   L.icnt = q;
+  q += nt / WAVE + 2;
+  L.vlist = q;
 }
 
 // Per-QP HBM pointers, recomputed from the kernel argument on demand (a few
@@ -853,46 +856,133 @@ struct Solver
     }
   }
 
-  // z_cid = L^{-1} b_cid and the Gram row of cid against every validated constraint
-  __device__ __forceinline__ void validate_constraint(int cid)
+  // Validate m <= VALIDATE_BATCH constraints (ids in L.vlist) in ONE pass over L^{-1}
+  // and ONE pass over Z:  z_cid = L^{-1} b_cid  (rows of Zr / columns of Zc) and the
+  // Gram rows G[cid][*] = z_cid^T D^{-1} z_* against every validated constraint.
+  // Scratch: the m x n tile T lives in the LDS vectors dx..CTzin, which are dead while
+  // the active set is being installed.
+  __device__ __forceinline__ void validate_batch(int m)
   {
-    const int n = d.n, nd = d.nd;
-    // row of B = [A_s; C_s; diag(i_scaled)]
-    if (cid < d.n_eq) {
-      vload(L.t1, P.As() + (long)cid * n, n);
-    } else if (cid < d.n_eq + d.n_in) {
-      vload(L.t1, P.Cs() + (long)(cid - d.n_eq) * n, n);
-    } else {
-      int j = cid - d.n_eq - d.n_in;
-      for (int k = threadIdx.x; k < n; k += NT)
-        L.t1[k] = (k == j) ? L.isc[k] : 0.0;
-    }
-    __syncthreads();
-    apply_Linv(L.t1, L.t1, false);
+    const int n = d.n, nd = d.nd, ne = d.n_eq, ni = d.n_in;
+    lptr T = L.dx;
     {
-      gptr Zr = P.Zr(), Zc = P.Zc();
-      for (int j = threadIdx.x; j < n; j += NT) {
-        double s = L.t1[j];
-        Zr[(long)cid * n + j] = s;
-        Zc[(long)j * nd + cid] = s;
-        L.t1[j] = s / L.dF[j];
+      cgptr As = P.As(), Cs = P.Cs();
+      for (int o = threadIdx.x; o < m * n; o += NT) {
+        int j = o / n, k = o - j * n;
+        int cid = L.vlist[j];
+        double v;
+        if (cid < ne)
+          v = As[(long)cid * n + k];
+        else if (cid < ne + ni)
+          v = Cs[(long)(cid - ne) * n + k];
+        else
+          v = (k == cid - ne - ni) ? L.isc[k] : 0.0;
+        T[o] = v;
       }
     }
-    if (threadIdx.x == 0)
-      L.zvalid[cid] = 1;
     __syncthreads();
-    mv(P.Zc(), nd, n, nd, L.t1, L.t2);
-    {
-      gptr G = P.G();
-      for (int j = threadIdx.x; j < nd; j += NT)
-        if (L.zvalid[j]) {
-          double s = L.t2[j];
-          G[(long)cid * nd + j] = s;
-          G[(long)j * nd + cid] = s;
+    double acc[VALIDATE_BATCH];
+#pragma unroll
+    for (int j = 0; j < VALIDATE_BATCH; ++j)
+      acc[j] = 0.0;
+    const int k = threadIdx.x;
+    if (k < n) {
+      if (d.hessian == PQP_HESSIAN_DENSE) {
+        cgptr WU = P.WU() + k;
+        int i = 0;
+        for (; i + 3 < n; i += 4) {
+          double w0 = WU[(long)i * n], w1 = WU[(long)(i + 1) * n];
+          double w2 = WU[(long)(i + 2) * n], w3 = WU[(long)(i + 3) * n];
+#pragma unroll
+          for (int j = 0; j < VALIDATE_BATCH; ++j)
+            if (j < m) {
+              clptr t = T + j * n + i;
+              acc[j] = fma(w0, t[0], acc[j]);
+              acc[j] = fma(w1, t[1], acc[j]);
+              acc[j] = fma(w2, t[2], acc[j]);
+              acc[j] = fma(w3, t[3], acc[j]);
+            }
         }
+        for (; i < n; ++i) {
+          double w0 = WU[(long)i * n];
+#pragma unroll
+          for (int j = 0; j < VALIDATE_BATCH; ++j)
+            if (j < m)
+              acc[j] = fma(w0, T[j * n + i], acc[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VALIDATE_BATCH; ++j)
+          if (j < m)
+            acc[j] = T[j * n + k];
+      }
     }
     __syncthreads();
-    count(ST_N_NEW_ROWS);
+    if (k < n) {
+      gptr Zr = P.Zr(), Zc = P.Zc();
+      const double dinv = 1.0 / L.dF[k];
+#pragma unroll
+      for (int j = 0; j < VALIDATE_BATCH; ++j)
+        if (j < m) {
+          int cid = L.vlist[j];
+          Zr[(long)cid * n + k] = acc[j];
+          Zc[(long)k * nd + cid] = acc[j];
+          T[j * n + k] = acc[j] * dinv;
+        }
+    }
+    if (threadIdx.x < m)
+      L.zvalid[L.vlist[threadIdx.x]] = 1;
+    __syncthreads();
+    // Gram rows: thread c owns column c of Z
+    for (int c = threadIdx.x; c < nd; c += NT) {
+#pragma unroll
+      for (int j = 0; j < VALIDATE_BATCH; ++j)
+        acc[j] = 0.0;
+      cgptr Zc = P.Zc() + c;
+      int kk = 0;
+      for (; kk + 3 < n; kk += 4) {
+        double z0 = Zc[(long)kk * nd], z1 = Zc[(long)(kk + 1) * nd];
+        double z2 = Zc[(long)(kk + 2) * nd], z3 = Zc[(long)(kk + 3) * nd];
+#pragma unroll
+        for (int j = 0; j < VALIDATE_BATCH; ++j)
+          if (j < m) {
+            clptr t = T + j * n + kk;
+            acc[j] = fma(z0, t[0], acc[j]);
+            acc[j] = fma(z1, t[1], acc[j]);
+            acc[j] = fma(z2, t[2], acc[j]);
+            acc[j] = fma(z3, t[3], acc[j]);
+          }
+      }
+      for (; kk < n; ++kk) {
+        double z0 = Zc[(long)kk * nd];
+#pragma unroll
+        for (int j = 0; j < VALIDATE_BATCH; ++j)
+          if (j < m)
+            acc[j] = fma(z0, T[j * n + kk], acc[j]);
+      }
+      if (L.zvalid[c]) {
+        gptr G = P.G();
+        // a pair of rows validated in the same pass is produced by two threads (c = cid_a
+        // for row b and c = cid_b for row a) with different rounding: one writer per pair
+        // keeps G exactly symmetric and the run bit-reproducible
+        bool c_in_batch = false;
+#pragma unroll
+        for (int j = 0; j < VALIDATE_BATCH; ++j)
+          if (j < m && L.vlist[j] == c)
+            c_in_batch = true;
+#pragma unroll
+        for (int j = 0; j < VALIDATE_BATCH; ++j)
+          if (j < m) {
+            int cid = L.vlist[j];
+            if (c_in_batch && c < cid)
+              continue;
+            G[(long)cid * nd + c] = acc[j];
+            G[(long)c * nd + cid] = acc[j];
+          }
+      }
+    }
+    __syncthreads();
+    count(ST_N_NEW_ROWS, m);
   }
 
   // ---- dual Schur block: gather M_J + G_JJ in slot order and factorise it -----
@@ -1082,10 +1172,28 @@ struct Solver
     r = ne + n_c;
     if (ch != 0.0)
       schur_dirty = true;
-    for (int a = 0; a < r; ++a) {
-      int cid = cid_of_slot(a);
-      if (!L.zvalid[cid])
-        validate_constraint(cid);
+    {
+      // rows entering the factorisation for the first time, VALIDATE_BATCH at a time
+      const int cap = (d.n + d.n_eq + d.nc + 2 * (d.n + d.nd) + d.nd + 4 * d.n + d.n_eq + d.nc) / d.n;
+      const int mb = cap < VALIDATE_BATCH ? (cap < 1 ? 1 : cap) : VALIDATE_BATCH;
+      int m = 0;
+      for (int a = 0; a < r; ++a) {
+        int cid = cid_of_slot(a);
+        if (!L.zvalid[cid]) {
+          if (threadIdx.x == 0)
+            L.vlist[m] = cid;
+          ++m;
+          if (m == mb) {
+            __syncthreads();
+            validate_batch(m);
+            m = 0;
+          }
+        }
+      }
+      if (m > 0) {
+        __syncthreads();
+        validate_batch(m);
+      }
     }
     toc(ST_CYC_ZG);
     if (schur_dirty && r > 0)
@@ -1894,14 +2002,25 @@ struct Solver
     long iter = 0;
     int stage = 0; // 0: top of loop, 1: after the Newton loop, 2: before the mu update
     bool done = (st.max_iter <= 0);
+    // The reference re-evaluates both global residuals at the top of every outer
+    // iteration although (x, y, z) have not moved since the evaluations that closed the
+    // previous one (solver.hpp:1598, 1697 -> :1402, 1414).  Those evaluations would
+    // reproduce the same numbers bit for bit, so they are skipped: `gpr_fresh` /
+    // `gdr_fresh` say that the cached values (and the LDS vectors se, rup, si / dres
+    // they leave behind) still describe the current iterate.
+    bool gpr_fresh = false, gdr_fresh = false;
+    double pl_cache = 0, dl_cache = 0;
     while (!done) {
       tic();
-      double pl = 0, dl = 0;
+      double pl = pl_cache, dl = dl_cache;
       const bool want_primal = (stage != 2);
       const bool want_dual_pre = (stage != 1);
-      if (want_primal)
+      if (want_primal && !gpr_fresh) {
         global_primal_residual(pl, primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0,
                                primal_feasibility_eq_lhs, primal_feasibility_in_lhs);
+        pl_cache = pl;
+        gpr_fresh = true;
+      }
       bool want_dual = want_dual_pre;
       if (stage == 1) {
         primal_feasibility_lhs_new = pl;
@@ -1911,9 +2030,12 @@ struct Solver
         info.pri_res = primal_feasibility_lhs_new;
         want_dual = is_primal_feasible;
       }
-      if (want_dual)
+      if (want_dual && !gdr_fresh) {
         global_dual_residual(dl, dual_feasibility_rhs_0, dual_feasibility_rhs_1, dual_feasibility_rhs_3,
                              rhs_duality_gap, duality_gap);
+        dl_cache = dl;
+        gdr_fresh = true;
+      }
       toc(ST_CYC_GLOBAL_RES);
       const double rhs_dua_rel =
         st.eps_rel * fmax(fmax(dual_feasibility_rhs_3, dual_feasibility_rhs_0),
@@ -1971,6 +2093,8 @@ struct Solver
         __syncthreads();
 
         newton_semi_smooth(bcl_eta_in);
+        gpr_fresh = false; // x, y, z moved; the shifted rup / si were consumed
+        gdr_fresh = false;
 
         if (nonfinite) {
           info.status = PQP_MAX_ITER_REACHED;
@@ -2031,6 +2155,7 @@ struct Solver
           } else {
             vcopy(L.y, L.yp, ne);
             vcopy(L.z, L.zp, nc);
+            gdr_fresh = false; // y, z were reset
             __syncthreads();
             new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
             new_bcl_mu_eq = fmax(info.mu_eq * st.mu_update_factor, st.mu_min_eq);

@@ -167,7 +167,9 @@ run_block(unsigned bx, dim3 grid, dim3 block, size_t shmem, const std::function<
     unsigned lo = w * 64, hi = std::min(block.x, lo + 64);
     b.waves[w].alive = hi - lo;
   }
-  std::vector<char> dyn(shmem + 64, 0);
+  // LDS is NOT zero-initialised on hardware: poison it (0xFF.. = NaN doubles, -1 ints) so a
+  // read of never-written LDS shows up as a wrong result here
+  std::vector<char> dyn(shmem + 64, char(0xFF));
   b.dyn_smem = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(dyn.data()) + 63) & ~uintptr_t(63));
   if (!t_stack_pool)
     t_stack_pool = new std::vector<char*>();

@@ -270,6 +270,7 @@ def case_maros_meszaros(lib, P, q, A, l, u):
     s.eps_rel = 0
     s.eps_primal_inf = 1e-12
     s.eps_dual_inf = 1e-12
+    s.max_iter = 1000  # the reference converges in < 30 outer iterations; bounds a bad run on the GPU
     for it in range(2):
         if it > 0:
             s.initial_guess = InitialGuess.WARM_START_WITH_PREVIOUS_RESULT
