@@ -44,6 +44,73 @@ typedef const PQP_GLOBAL double* cgptr;
 constexpr int WAVE = 64;
 constexpr int PQP_NB = 16; // panel width of the blocked LDL^T / substitutions
 
+// ---------------------------------------------------------------------------
+// Wave-uniform scalars.  Every thread of a workgroup computes the solver's control
+// scalars (mu, rho, BCL thresholds, residual norms, counters ...) redundantly, so
+// they are uniform by construction -- but fp64 arithmetic runs on the VALU and would
+// leave ~50 of them in VGPRs of every lane for the whole kernel.  uni() moves a value
+// to the scalar register file (v_readfirstlane), where the compiler keeps it in
+// SGPRs / spills it to VGPR *lanes* instead of scratch memory, and where it makes
+// branch conditions provably uniform (scalar branches instead of exec masking).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int
+uni(int v)
+{
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ double
+uni(double v)
+{
+  union
+  {
+    double d;
+    int i[2];
+  } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+__device__ __forceinline__ long
+uni(long v)
+{
+  union
+  {
+    long l;
+    int i[2];
+  } u;
+  u.l = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.l;
+}
+__device__ __forceinline__ bool
+uni(bool v)
+{
+  return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0;
+}
+// a double that is re-scalarised on every assignment
+struct UD
+{
+  double v;
+  __device__ __forceinline__ UD()
+    : v(0)
+  {
+  }
+  __device__ __forceinline__ UD(double x)
+    : v(uni(x))
+  {
+  }
+  __device__ __forceinline__ UD& operator=(double x)
+  {
+    v = uni(x);
+    return *this;
+  }
+  __device__ __forceinline__ operator double() const { return v; }
+  __device__ __forceinline__ UD& operator+=(double x) { return *this = v + x; }
+  __device__ __forceinline__ UD& operator*=(double x) { return *this = v * x; }
+};
+
 __device__ __forceinline__ double
 wave_sum(double v)
 {
@@ -97,7 +164,7 @@ struct Reducer
     for (int w = 0; w < NW; ++w)
       r += s[w];
     parity ^= 1;
-    return r;
+    return uni(r);
   }
   __device__ __forceinline__ double max(double v)
   {
@@ -111,7 +178,7 @@ struct Reducer
     for (int w = 1; w < NW; ++w)
       r = fmax(r, s[w]);
     parity ^= 1;
-    return r;
+    return uni(r);
   }
   __device__ __forceinline__ double min(double v)
   {
@@ -125,7 +192,7 @@ struct Reducer
     for (int w = 1; w < NW; ++w)
       r = fmin(r, s[w]);
     parity ^= 1;
-    return r;
+    return uni(r);
   }
   // two sums in one barrier
   __device__ __forceinline__ void sum2(double& a, double& b)
@@ -144,8 +211,8 @@ struct Reducer
       ra += s[w];
       rb += s[NW + w];
     }
-    a = ra;
-    b = rb;
+    a = uni(ra);
+    b = uni(rb);
     parity ^= 1;
   }
   // up to three maxima in one barrier
@@ -168,9 +235,9 @@ struct Reducer
       rb = fmax(rb, s[NW + w]);
       rc = fmax(rc, s[2 * NW + w]);
     }
-    a = ra;
-    b = rb;
-    c = rc;
+    a = uni(ra);
+    b = uni(rb);
+    c = uni(rc);
     parity ^= 1;
   }
   // four sums in one barrier
@@ -197,10 +264,10 @@ struct Reducer
       rc += s[2 * NW + w];
       rd += s[3 * NW + w];
     }
-    a = ra;
-    b = rb;
-    c = rc;
-    d = rd;
+    a = uni(ra);
+    b = uni(rb);
+    c = uni(rc);
+    d = uni(rd);
     parity ^= 1;
   }
 };
@@ -257,7 +324,23 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int k = ks;
         if (rowmap) {
-          // gathered rows: resolve 4 row indices, then 4 independent loads
+          // gathered rows: resolve the row indices, then 8 / 4 independent loads
+          for (; k + 7 * KS < K; k += 8 * KS) {
+            double m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              int ku = k + u * KS;
+              int ru = (ku < rowsplit) ? ku : rowsplit + rowmap[ku - rowsplit];
+              m[u] = col[(long)ru * ld];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+              a0 = fma(m[u], v[k + u * KS], a0);
+              a1 = fma(m[u + 1], v[k + (u + 1) * KS], a1);
+              a2 = fma(m[u + 2], v[k + (u + 2) * KS], a2);
+              a3 = fma(m[u + 3], v[k + (u + 3) * KS], a3);
+            }
+          }
           for (; k + 3 * KS < K; k += 4 * KS) {
             int k1 = k + KS, k2 = k + 2 * KS, k3 = k + 3 * KS;
             int r0 = (k < rowsplit) ? k : rowsplit + rowmap[k - rowsplit];
@@ -278,7 +361,22 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
         } else {
           const long step = (long)KS * ld;
           cgptr p = col + (long)k * ld;
-          // 8 independent loads issued back to back before the first use
+          // 16, then 8, independent loads issued back to back before their first use: the
+          // kernel is bound by HBM round trips, so bytes in flight per lane is the lever
+          for (; k + 15 * KS < K; k += 16 * KS) {
+            double m[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+              m[u] = p[u * step];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+              a0 = fma(m[u], v[k + u * KS], a0);
+              a1 = fma(m[u + 1], v[k + (u + 1) * KS], a1);
+              a2 = fma(m[u + 2], v[k + (u + 2) * KS], a2);
+              a3 = fma(m[u + 3], v[k + (u + 3) * KS], a3);
+            }
+            p += 16 * step;
+          }
           for (; k + 7 * KS < K; k += 8 * KS) {
             double m0 = p[0], m1 = p[step], m2 = p[2 * step], m3 = p[3 * step];
             double m4 = p[4 * step], m5 = p[5 * step], m6 = p[6 * step], m7 = p[7 * step];
@@ -336,25 +434,35 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
 // ---------------------------------------------------------------------------
 // Blocked left-looking LDL^T of a symmetric m x m matrix stored FULL row-major
 // in HBM (leading dimension ld, m <= NT: thread i owns row i of the panel in
-// registers).  On exit (mirrored storage):
-//   M[k][i], k<i, outside the diagonal blocks : L[i][k]     (upper part = L^T)
-//   M[i][k], k<i, outside the diagonal blocks : L[i][k]     (lower part = L)
-//   M[j][j]                                   : d_j  (also d[j] in LDS)
+// registers).  Only the UPPER triangle of the input is read.  On exit:
+//   M[k][i], k<i : L[i][k]   (upper part = L^T; every load/store of the
+//                             factorisation is coalesced along i)
+//   M[j][j]      : d_j       (also d[j] in LDS)
+// FULL = true additionally leaves (for tri_inverse, primal block only)
+//   M[i][k], k<i, outside the diagonal blocks : L[i][k]  (lower mirror)
 //   diagonal 16x16 blocks: strict lower = inv(L_bb), strict upper = inv(L_bb)^T
-// so that both triangular sweeps are row-coalesced axpy passes and the
-// dependent chain inside a diagonal block collapses to a 16x16 mat-vec.
 // Restates what the reference's factorization computes
 // (reference include/proxsuite/linalg/dense/factorize.hpp:89-148, 215-280:
 // D from the diagonal recurrence, L = unit lower) with a static pivot order.
-// `top` is LDS scratch of PQP_NB*PQP_NB + PQP_NB*PQP_NB doubles.
+// `top` is LDS scratch of 2*PQP_NB*PQP_NB doubles; `prof` (optional, LDS) receives
+// the cycles of the five sub-phases.
 // ---------------------------------------------------------------------------
-template<int NT>
+template<int NT, bool FULL>
 __device__ PQP_CALL void
-ldlt_factor(gptr M, int ld, int m, lptr d, lptr top)
+ldlt_factor(gptr M, int ld, int m, lptr d, lptr top, PQP_LDS long long* prof = nullptr)
 {
   constexpr int NB = PQP_NB;
   const int i = threadIdx.x;
   lptr tl = top + NB * NB; // normalised top block (unit lower), for the inverse
+  long long t0 = 0;
+#define PQP_PROF(slot)                                                                            \
+  if (prof && threadIdx.x == 0) {                                                                  \
+    long long t1 = clock64();                                                                      \
+    prof[slot] += t1 - t0;                                                                         \
+    t0 = t1;                                                                                       \
+  }
+  if (prof && threadIdx.x == 0)
+    t0 = clock64();
   for (int j0 = 0; j0 < m; j0 += NB) {
     const int nb = (m - j0 < NB) ? (m - j0) : NB;
     double p[NB];
@@ -368,42 +476,39 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top)
         if (c < nb && i >= j0 + c)
           p[c] = M[(long)(j0 + c) * ld + i];
     }
-    // left-looking update with the factorised columns k < j0, 16 columns at a time:
-    // the 16 x 16 block W[c][kk] = L[j0+c][k0+kk] * d[k0+kk] is staged in LDS (one
-    // coalesced load per thread), every row thread pulls its own 16 L values with
-    // independent loads (one memory latency per 16 columns instead of one per column)
-    // and the 256 FMAs run out of registers x LDS broadcasts.
-    for (int k0 = 0; k0 < j0; k0 += NB) {
-      {
-        const int c = threadIdx.x / NB, kk = threadIdx.x % NB;
-        if (NT >= NB * NB) {
-          if (threadIdx.x < NB * NB)
-            top[c * NB + kk] = (c < nb) ? M[(long)(j0 + c) * ld + k0 + kk] * d[k0 + kk] : 0.0;
-        } else {
-          for (int o = threadIdx.x; o < NB * NB; o += NT) {
-            int c2 = o / NB, k2 = o % NB;
-            top[o] = (c2 < nb) ? M[(long)(j0 + c2) * ld + k0 + k2] * d[k0 + k2] : 0.0;
-          }
-        }
+    PQP_PROF(0)
+    // left-looking update with the factorised columns k < j0, 16 columns at a time.
+    // Both operands come from the upper mirror: the thread's own 16 values
+    // L[i][k0+kk] = M[k0+kk][i] (coalesced along i) and the 16 x 16 block
+    // W[c][kk] = L[j0+c][k0+kk] * d[k0+kk] staged through LDS.  All loads of a chunk
+    // are issued before its barrier: one HBM round trip per 16 columns.
+    constexpr int KC = 8; // columns per chunk: li[KC] stays live across the barrier
+    for (int k0 = 0; k0 < j0; k0 += KC) {
+      double li[KC];
+      if (row_active) {
+        cgptr col = M + (long)k0 * ld + i;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+          li[kk] = col[(long)kk * ld];
+      }
+      for (int o = threadIdx.x; o < NB * KC; o += NT) {
+        const int kk = o / NB, c = o % NB;
+        top[c * KC + kk] = (c < nb) ? M[(long)(k0 + kk) * ld + j0 + c] * d[k0 + kk] : 0.0;
       }
       __syncthreads();
       if (row_active) {
-        double li[NB];
-        cgptr rowi = M + (long)i * ld + k0;
-#pragma unroll
-        for (int kk = 0; kk < NB; ++kk)
-          li[kk] = rowi[kk];
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
           double acc = p[c];
 #pragma unroll
-          for (int kk = 0; kk < NB; ++kk)
-            acc = fma(-li[kk], top[c * NB + kk], acc);
+          for (int kk = 0; kk < KC; ++kk)
+            acc = fma(-li[kk], top[c * KC + kk], acc);
           p[c] = acc;
         }
       }
       __syncthreads();
     }
+    PQP_PROF(1)
     // in-panel right-looking elimination; one barrier per column
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
@@ -422,7 +527,8 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top)
         }
       }
     }
-    // write back: diagonal, upper mirror (coalesced), lower rows, LDS copy of T
+    PQP_PROF(2)
+    // write back: diagonal + upper mirror (coalesced along i)
     if (row_active) {
 #pragma unroll
       for (int c = 0; c < NB; ++c) {
@@ -431,51 +537,62 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top)
             d[i] = p[c];
             M[(long)i * ld + i] = p[c];
           } else if (i > j0 + c) {
-            if (i >= j0 + nb) {
+            if (!FULL || i >= j0 + nb)
               M[(long)(j0 + c) * ld + i] = p[c];
-              M[(long)i * ld + (j0 + c)] = p[c];
-            } else {
-              tl[(i - j0) * NB + c] = p[c];
+            if (FULL) {
+              if (i >= j0 + nb)
+                M[(long)i * ld + (j0 + c)] = p[c];
+              else
+                tl[(i - j0) * NB + c] = p[c];
             }
           }
         }
       }
     }
     __syncthreads();
-    // inverse of the unit-lower diagonal block: thread c solves column c
-    if (i >= j0 && i < j0 + nb) {
-      const int c = i - j0;
-      double xcol[NB];
+    PQP_PROF(3)
+    if (FULL) {
+      // inverse of the unit-lower diagonal block: thread c solves column c
+      if (i >= j0 && i < j0 + nb) {
+        const int c = i - j0;
+        double xcol[NB];
 #pragma unroll
-      for (int r = 0; r < NB; ++r)
-        xcol[r] = (r == c) ? 1.0 : 0.0;
+        for (int r = 0; r < NB; ++r)
+          xcol[r] = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int r = 1; r < NB; ++r) {
-        if (r < nb && r > c) {
-          double acc = 0;
+        for (int r = 1; r < NB; ++r) {
+          if (r < nb && r > c) {
+            double acc = 0;
 #pragma unroll
-          for (int q = 0; q < NB; ++q)
-            if (q >= c && q < r)
-              acc = fma(tl[r * NB + q], xcol[q], acc);
-          xcol[r] = -acc;
+            for (int q = 0; q < NB; ++q)
+              if (q >= c && q < r)
+                acc = fma(tl[r * NB + q], xcol[q], acc);
+            xcol[r] = -acc;
+          }
         }
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+          if (r < nb && r > c) {
+            M[(long)(j0 + r) * ld + (j0 + c)] = xcol[r]; // inv(L_bb)[r][c]
+            M[(long)(j0 + c) * ld + (j0 + r)] = xcol[r]; // its transpose
+          }
       }
-#pragma unroll
-      for (int r = 0; r < NB; ++r)
-        if (r < nb && r > c) {
-          M[(long)(j0 + r) * ld + (j0 + c)] = xcol[r]; // inv(L_bb)[r][c]
-          M[(long)(j0 + c) * ld + (j0 + r)] = xcol[r]; // its transpose
-        }
+      __syncthreads();
     }
-    __syncthreads();
+    PQP_PROF(4)
   }
+#undef PQP_PROF
 }
 
 // ---------------------------------------------------------------------------
 // Solve (L D L^T) x = v in place for an LDS vector v (length m <= NT) using the
-// mirrored factor produced by ldlt_factor.  Restates reference
+// upper-mirror factor of ldlt_factor<NT, false>.  Restates reference
 // include/proxsuite/linalg/dense/solve.hpp:15-26 (forward unit-lower sweep,
-// diagonal scaling, backward sweep).  `blk` is LDS scratch of 2*PQP_NB doubles.
+// diagonal scaling, backward sweep).  Per 16-row block: the in-block
+// substitution runs inside one wavefront with lane shuffles (no LDS, no
+// barrier), the block's 16 results are broadcast through LDS (double-buffered:
+// ONE barrier per block) and every other row applies its 16 coalesced updates,
+// whose loads were issued before the barrier.  `blk`: 2*PQP_NB doubles of LDS.
 // ---------------------------------------------------------------------------
 template<int NT>
 __device__ PQP_CALL void
@@ -483,31 +600,45 @@ ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
 {
   constexpr int NB = PQP_NB;
   const int a = threadIdx.x;
-  lptr yb = blk + NB;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x / WAVE;
   double val = (a < m) ? v[a] : 0.0;
+  int buf = 0;
   // forward: L y = v
   for (int j0 = 0; j0 < m; j0 += NB) {
     const int nb = (m - j0 < NB) ? (m - j0) : NB;
-    const bool inblk = (a >= j0 && a < j0 + nb);
-    if (inblk)
-      blk[a - j0] = val;
-    __syncthreads();
-    if (inblk) {
-      const int c = a - j0;
-      cgptr row = M + (long)a * ld + j0;
-      double y = blk[c];
-      for (int c2 = 0; c2 < c; ++c2)
-        y = fma(row[c2], blk[c2], y);
-      val = y;
-      yb[c] = y;
+    const int c = a - j0; // position inside / below the block
+    double u[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      u[q] = 0.0;
+    if (c > 0 && a < m) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+        if (q < nb && q < c)
+          u[q] = M[(long)(j0 + q) * ld + a]; // L[a][j0+q]
+    }
+    if (wid == j0 / WAVE) {
+      const int base = j0 & (WAVE - 1);
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        double yq = __shfl(val, base + q);
+        if (q < nb && c > q && c < nb)
+          val = fma(-u[q], yq, val);
+      }
+      if (c >= 0 && c < nb)
+        blk[buf * NB + c] = val;
     }
     __syncthreads();
-    if (a >= j0 + nb && a < m) {
+    if (c >= nb && a < m) {
       double acc = val;
-      for (int c = 0; c < nb; ++c)
-        acc = fma(-M[(long)(j0 + c) * ld + a], yb[c], acc);
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+        if (q < nb)
+          acc = fma(-u[q], blk[buf * NB + q], acc);
       val = acc;
     }
+    buf ^= 1;
   }
   if (a < m)
     val /= d[a];
@@ -515,26 +646,41 @@ ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
   const int last = ((m - 1) / NB) * NB;
   for (int j0 = last; j0 >= 0; j0 -= NB) {
     const int nb = (m - j0 < NB) ? (m - j0) : NB;
-    const bool inblk = (a >= j0 && a < j0 + nb);
-    if (inblk)
-      blk[a - j0] = val;
-    __syncthreads();
-    if (inblk) {
-      const int c = a - j0;
+    const int c = a - j0;
+    double u[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      u[q] = 0.0;
+    if (a < j0 + nb && a < m) {
+      // own row a, columns j0 .. j0+nb-1:  L[j0+q][a] = M[a][j0+q]  (q > c inside the block)
       cgptr row = M + (long)a * ld + j0;
-      double x = blk[c];
-      for (int c2 = c + 1; c2 < nb; ++c2)
-        x = fma(row[c2], blk[c2], x);
-      val = x;
-      yb[c] = x;
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+        if (q < nb && q > c)
+          u[q] = row[q];
+    }
+    if (wid == j0 / WAVE) {
+      const int base = j0 & (WAVE - 1);
+#pragma unroll
+      for (int qq = 0; qq < NB; ++qq) {
+        const int q = NB - 1 - qq;
+        double xq = __shfl(val, base + q);
+        if (q < nb && c >= 0 && c < q)
+          val = fma(-u[q], xq, val);
+      }
+      if (c >= 0 && c < nb)
+        blk[buf * NB + c] = val;
     }
     __syncthreads();
-    if (a < j0) {
+    if (c < 0) {
       double acc = val;
-      for (int c = 0; c < nb; ++c)
-        acc = fma(-M[(long)(j0 + c) * ld + a], yb[c], acc);
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+        if (q < nb)
+          acc = fma(-u[q], blk[buf * NB + q], acc);
       val = acc;
     }
+    buf ^= 1;
   }
   if (a < m)
     v[a] = val;
@@ -626,7 +772,7 @@ block_rank(bool flag, liptr cnt, int& total)
       off += c;
     tot += c;
   }
-  total = tot;
+  total = uni(tot);
   __syncthreads();
   return off + before;
 }

@@ -209,6 +209,8 @@ dispatch_solve(pqp_batch* h)
           return launch_solve<256, 1>(h);
         case 2:
           return launch_solve<256, 2>(h);
+        case 3:
+          return launch_solve<256, 3>(h);
         default:
           return launch_solve<256, 4>(h);
       }
@@ -369,7 +371,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   }
   if (const char* e = std::getenv("PQP_WAVES_PER_SIMD")) {
     int v = std::atoi(e);
-    if (v == 1 || v == 2 || v == 4)
+    if (v >= 1 && v <= 4)
       h->wps = v;
   }
   h->lds_solve = pqp::lds_bytes(d, h->nt);

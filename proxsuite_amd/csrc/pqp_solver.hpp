@@ -94,6 +94,14 @@ enum
   ST_N_KKT_SOLVES,
   ST_N_LS_BREAKPOINTS,
   ST_N_ACTIVE_FINAL,
+  ST_CYC_F_LOAD, // ldlt_factor of the Schur block: panel load
+  ST_CYC_F_UPDATE,
+  ST_CYC_F_PANEL,
+  ST_CYC_F_WRITEBACK,
+  ST_CYC_F_TINV,
+  ST_CYC_S_GATHER,
+  ST_CYC_SOLVE_LDLT,
+  ST_SPARE,
   ST_COUNT
 };
 
@@ -319,9 +327,67 @@ absent(double v)
   return v != v;
 }
 
+// working copy of pqp_info whose doubles live in scalar registers (see UD)
+struct UInfo
+{
+  UD mu_eq, mu_eq_inv, mu_in, mu_in_inv, rho, nu;
+  long iter, iter_ext, mu_updates, rho_updates;
+  UD setup_time, solve_time, run_time, objValue, pri_res, dua_res, duality_gap, iterative_residual,
+    minimal_H_eigenvalue_estimate;
+  int status;
+  __device__ __forceinline__ void load(const pqp_info& o)
+  {
+    mu_eq = o.mu_eq;
+    mu_eq_inv = o.mu_eq_inv;
+    mu_in = o.mu_in;
+    mu_in_inv = o.mu_in_inv;
+    rho = o.rho;
+    nu = o.nu;
+    iter = uni((long)o.iter);
+    iter_ext = uni((long)o.iter_ext);
+    mu_updates = uni((long)o.mu_updates);
+    rho_updates = uni((long)o.rho_updates);
+    setup_time = o.setup_time;
+    solve_time = o.solve_time;
+    run_time = o.run_time;
+    objValue = o.objValue;
+    pri_res = o.pri_res;
+    dua_res = o.dua_res;
+    duality_gap = o.duality_gap;
+    iterative_residual = o.iterative_residual;
+    minimal_H_eigenvalue_estimate = o.minimal_H_eigenvalue_estimate;
+    status = uni((int)o.status);
+  }
+  __device__ __forceinline__ void store(pqp_info& o) const
+  {
+    o.mu_eq = mu_eq;
+    o.mu_eq_inv = mu_eq_inv;
+    o.mu_in = mu_in;
+    o.mu_in_inv = mu_in_inv;
+    o.rho = rho;
+    o.nu = nu;
+    o.iter = iter;
+    o.iter_ext = iter_ext;
+    o.mu_updates = mu_updates;
+    o.rho_updates = rho_updates;
+    o.setup_time = setup_time;
+    o.solve_time = solve_time;
+    o.run_time = run_time;
+    o.objValue = objValue;
+    o.pri_res = pri_res;
+    o.dua_res = dua_res;
+    o.duality_gap = duality_gap;
+    o.iterative_residual = iterative_residual;
+    o.minimal_H_eigenvalue_estimate = minimal_H_eigenvalue_estimate;
+    o.status = status;
+    o._pad = 0;
+  }
+};
+
 // reference results.hpp:157-174
+template<typename Info>
 __device__ __forceinline__ void
-cleanup_statistics(pqp_info& i)
+cleanup_statistics(Info& i)
 {
   i.run_time = 0;
   i.setup_time = 0;
@@ -338,8 +404,9 @@ cleanup_statistics(pqp_info& i)
   i.status = PQP_MAX_ITER_REACHED;
 }
 // reference results.hpp:175-194
+template<typename Info>
 __device__ __forceinline__ void
-cold_start(pqp_info& i, const pqp_settings& s)
+cold_start(Info& i, const pqp_settings& s)
 {
   i.nu = 1.;
   i.rho = s.default_rho;
@@ -736,12 +803,12 @@ struct Solver
   Lds L;
   Reducer<NT> R;
   const pqp_settings& st;
-  pqp_info info; // working copy, written back at exit
+  UInfo info; // working copy (scalar registers), written back at exit
   int n_c;       // active inequality count
   int r;         // n_eq + n_c : size of the dual block
   bool schur_dirty;
-  double ruiz_c;
-  double dual_feasibility_rhs_2;
+  UD ruiz_c;
+  UD dual_feasibility_rhs_2;
   bool nonfinite;
   long long t_mark;
 
@@ -830,7 +897,7 @@ struct Solver
         F[o] = Hs[o] + ((rr == k) ? rho : 0.0);
       }
       __syncthreads();
-      ldlt_factor<NT>(F, n, n, L.dF, L.top);
+      ldlt_factor<NT, true>(F, n, n, L.dF, L.top);
       tri_inverse<NT>(F, n, n, P.WL(), P.WU());
     } else {
       // diagonal / zero Hessian: L = I
@@ -890,6 +957,20 @@ struct Solver
       if (d.hessian == PQP_HESSIAN_DENSE) {
         cgptr WU = P.WU() + k;
         int i = 0;
+        for (; i + 7 < n; i += 8) {
+          double w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            w[u] = WU[(long)(i + u) * n];
+#pragma unroll
+          for (int j = 0; j < VALIDATE_BATCH; ++j)
+            if (j < m) {
+              clptr t = T + j * n + i;
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                acc[j] = fma(w[u], t[u], acc[j]);
+            }
+        }
         for (; i + 3 < n; i += 4) {
           double w0 = WU[(long)i * n], w1 = WU[(long)(i + 1) * n];
           double w2 = WU[(long)(i + 2) * n], w3 = WU[(long)(i + 3) * n];
@@ -940,6 +1021,20 @@ struct Solver
         acc[j] = 0.0;
       cgptr Zc = P.Zc() + c;
       int kk = 0;
+      for (; kk + 7 < n; kk += 8) {
+        double zz[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          zz[u] = Zc[(long)(kk + u) * nd];
+#pragma unroll
+        for (int j = 0; j < VALIDATE_BATCH; ++j)
+          if (j < m) {
+            clptr t = T + j * n + kk;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              acc[j] = fma(zz[u], t[u], acc[j]);
+          }
+      }
       for (; kk + 3 < n; kk += 4) {
         double z0 = Zc[(long)kk * nd], z1 = Zc[(long)(kk + 1) * nd];
         double z2 = Zc[(long)(kk + 2) * nd], z3 = Zc[(long)(kk + 3) * nd];
@@ -992,16 +1087,34 @@ struct Solver
     const int rr = r;
     cgptr G = P.G();
     gptr LS = P.LS();
-    for (int o = threadIdx.x; o < rr * rr; o += NT) {
-      int a = o / rr, b = o - a * rr;
-      int ca = cid_of_slot(a), cb = cid_of_slot(b);
-      double v = G[(long)ca * nd + cb];
-      if (a == b)
-        v += (a < d.n_eq) ? info.mu_eq : info.mu_in;
-      LS[(long)a * nd + b] = v;
+    // gathered loads are batched 8 deep ahead of the stores (G and LS are distinct
+    // buffers, but the compiler cannot know and would serialise load/store pairs)
+    for (int base = 0; base < rr * rr; base += 8 * NT) {
+      double v[8];
+      long dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int o = base + u * NT + threadIdx.x;
+        dst[u] = -1;
+        v[u] = 0;
+        if (o < rr * rr) {
+          int a = o / rr, b = o - a * rr;
+          int ca = cid_of_slot(a), cb = cid_of_slot(b);
+          v[u] = G[(long)ca * nd + cb];
+          if (a == b)
+            v[u] += (a < d.n_eq) ? info.mu_eq : info.mu_in;
+          dst[u] = (long)a * nd + b;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0)
+          LS[dst[u]] = v[u];
     }
     __syncthreads();
-    ldlt_factor<NT>(LS, nd, rr, L.dS, L.top);
+    toc(ST_CYC_S_GATHER);
+    ldlt_factor<NT, false>(LS, nd, rr, L.dS, L.top, L.stat + ST_CYC_F_LOAD);
+    tic();
     schur_dirty = false;
     count(ST_N_SCHUR_FACT);
   }
@@ -1023,7 +1136,9 @@ struct Solver
         bd[a] = L.t2[a] - bd[a];
       __syncthreads();
       // (M + G) dvec = s
+      toc(ST_CYC_KKT_SOLVE);
       ldlt_solve<NT>(P.LS(), nd, rr, L.dS, bd, L.top);
+      toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
       gemv<NT>(P.Zr(), n, rr, n, bd, L.t2, L.part, L.act, d.n_eq, nullptr, 0);
       for (int k = threadIdx.x; k < n; k += NT)
@@ -1110,7 +1225,7 @@ struct Solver
     vcopy(L.ed, L.rd, r);
     __syncthreads();
     long it = 0, it_stability = 0;
-    double preverr = 0, cur = 0;
+    UD preverr = 0, cur = 0;
     while (true) {
       tic();
       kkt_solve_in_place(L.ex, L.ed);
@@ -1202,8 +1317,8 @@ struct Solver
   }
 
   // reference utils.hpp:164-252
-  __device__ __forceinline__ void global_primal_residual(double& lhs, double& eq_rhs_0, double& in_rhs_0,
-                                                         double& eq_lhs, double& in_lhs)
+  __device__ __forceinline__ void global_primal_residual(UD& lhs, UD& eq_rhs_0, UD& in_rhs_0, UD& eq_lhs,
+                                                         UD& in_lhs)
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     double m_eq0 = 0, m_in0 = 0, m_eql = 0, m_inl = 0;
@@ -1277,9 +1392,8 @@ struct Solver
   }
 
   // reference utils.hpp:437-587
-  __device__ __forceinline__ void global_dual_residual(double& lhs, double& rhs_0, double& rhs_1,
-                                                       double& rhs_3, double& rhs_duality_gap,
-                                                       double& duality_gap)
+  __device__ __forceinline__ void global_dual_residual(UD& lhs, UD& rhs_0, UD& rhs_1, UD& rhs_3,
+                                                       UD& rhs_duality_gap, UD& duality_gap)
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     const double c = ruiz_c;
@@ -1451,7 +1565,7 @@ struct Solver
     R.sum4(s_dxHdx, s_adx2, s_dx2, s_e2);
     R.sum4(s_xHdx, s_errdx, s_adxres, s_eres);
     R.sum2(s_dz2, s_dzz);
-    const double nu = gpdal ? 1.0 : info.nu;
+    const double nu = gpdal ? 1.0 : double(info.nu);
     double a0 = s_dxHdx + info.mu_eq_inv * s_adx2 + info.rho * s_dx2 + s_e2 * info.mu_eq_inv * nu;
     double b0 = s_xHdx + s_errdx + info.mu_eq_inv * s_adxres + nu * info.mu_eq_inv * s_eres;
     if (gpdal) {
@@ -1760,7 +1874,7 @@ struct Solver
           L.Cdx[i] += (st.alpha_gpdal - 1.) * info.mu_in * L.dz[i];
         __syncthreads();
       }
-      double alpha = 1.0;
+      UD alpha = 1.0;
       if (ni > 0 || d.box)
         alpha = primal_dual_ls();
       toc(ST_CYC_LINESEARCH);
@@ -1792,7 +1906,7 @@ struct Solver
         L.y[k] += alpha * L.dy[k];
       }
       __syncthreads();
-      double err_in = inner_loop_saddle_point();
+      const UD err_in = inner_loop_saddle_point();
       bool stop = false;
       if (iter % st.frequence_infeasibility_check == 0 || st.primal_infeasibility_solving) {
         bool is_primal_infeasible = primal_infeasibility_certificate();
@@ -1851,7 +1965,7 @@ struct Solver
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
     State W = *P.state();
-    info = *P.info();
+    info.load(*P.info());
     ruiz_c = W.ruiz_c;
     dual_feasibility_rhs_2 = W.dual_feasibility_rhs_2;
     for (int k = threadIdx.x; k < ST_COUNT; k += NT)
@@ -1983,21 +2097,21 @@ struct Solver
     }
 
     // BCL state (solver.hpp:1378-1395)
-    const double bcl_eta_ext_init = pow(0.1, st.alpha_bcl);
-    double bcl_eta_ext = bcl_eta_ext_init;
-    double bcl_eta_in = 1;
-    const double eps_in_min = fmin(st.eps_abs, 1.E-9);
-    double primal_feasibility_eq_rhs_0 = 0, primal_feasibility_in_rhs_0 = 0;
-    double dual_feasibility_rhs_0 = 0, dual_feasibility_rhs_1 = 0, dual_feasibility_rhs_3 = 0;
-    double primal_feasibility_lhs = 0, primal_feasibility_eq_lhs = 0, primal_feasibility_in_lhs = 0;
-    double dual_feasibility_lhs = 0;
-    double duality_gap = 0, rhs_duality_gap = 0;
-    double scaled_eps = st.eps_abs;
+    const UD bcl_eta_ext_init = pow(0.1, st.alpha_bcl);
+    UD bcl_eta_ext = bcl_eta_ext_init;
+    UD bcl_eta_in = 1;
+    const UD eps_in_min = fmin(st.eps_abs, 1.E-9);
+    UD primal_feasibility_eq_rhs_0 = 0, primal_feasibility_in_rhs_0 = 0;
+    UD dual_feasibility_rhs_0 = 0, dual_feasibility_rhs_1 = 0, dual_feasibility_rhs_3 = 0;
+    UD primal_feasibility_lhs = 0, primal_feasibility_eq_lhs = 0, primal_feasibility_in_lhs = 0;
+    UD dual_feasibility_lhs = 0;
+    UD duality_gap = 0, rhs_duality_gap = 0;
+    UD scaled_eps = st.eps_abs;
     // The loop body evaluates the residuals at three places per outer iteration in the
     // reference (top, after the inner loop, before the mu update).  `stage` walks
     // through them so that each residual routine is instantiated once.
-    double primal_feasibility_lhs_new = 0, dual_feasibility_lhs_new = 0;
-    double new_bcl_mu_in = 0, new_bcl_mu_eq = 0, new_bcl_mu_in_inv = 0, new_bcl_mu_eq_inv = 0;
+    UD primal_feasibility_lhs_new = 0, dual_feasibility_lhs_new = 0;
+    UD new_bcl_mu_in = 0, new_bcl_mu_eq = 0, new_bcl_mu_in_inv = 0, new_bcl_mu_eq_inv = 0;
     bool is_primal_feasible = false, is_dual_feasible = false;
     long iter = 0;
     int stage = 0; // 0: top of loop, 1: after the Newton loop, 2: before the mu update
@@ -2009,10 +2123,10 @@ struct Solver
     // `gdr_fresh` say that the cached values (and the LDS vectors se, rup, si / dres
     // they leave behind) still describe the current iterate.
     bool gpr_fresh = false, gdr_fresh = false;
-    double pl_cache = 0, dl_cache = 0;
+    UD pl_cache = 0, dl_cache = 0;
     while (!done) {
       tic();
-      double pl = pl_cache, dl = dl_cache;
+      UD pl = pl_cache, dl = dl_cache;
       const bool want_primal = (stage != 2);
       const bool want_dual_pre = (stage != 1);
       if (want_primal && !gpr_fresh) {
@@ -2037,7 +2151,7 @@ struct Solver
         gdr_fresh = true;
       }
       toc(ST_CYC_GLOBAL_RES);
-      const double rhs_dua_rel =
+      const UD rhs_dua_rel =
         st.eps_rel * fmax(fmax(dual_feasibility_rhs_3, dual_feasibility_rhs_0),
                           fmax(dual_feasibility_rhs_1, dual_feasibility_rhs_2));
       if (stage == 0) {
@@ -2050,11 +2164,11 @@ struct Solver
         new_bcl_mu_eq = info.mu_eq;
         new_bcl_mu_in_inv = info.mu_in_inv;
         new_bcl_mu_eq_inv = info.mu_eq_inv;
-        double rhs_pri = scaled_eps;
+        UD rhs_pri = scaled_eps;
         if (st.eps_rel != 0)
           rhs_pri += st.eps_rel * fmax(primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0);
         is_primal_feasible = primal_feasibility_lhs <= rhs_pri;
-        double rhs_dua = st.eps_abs;
+        UD rhs_dua = st.eps_abs;
         if (st.eps_rel != 0)
           rhs_dua += rhs_dua_rel;
         is_dual_feasible = dual_feasibility_lhs <= rhs_dua;
@@ -2263,7 +2377,7 @@ struct Solver
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      *P.info() = info;
+      info.store(*P.info());
       W.dirty = 1;
       W.is_initialized = 1;
       W.n_c = n_c;

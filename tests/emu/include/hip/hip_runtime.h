@@ -7,5 +7,7 @@
 #define PQP_LDS
 #define PQP_GLOBAL
 #define PQP_CALL inline
+// scalarisation is the identity on the host
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #include "../../hip_emu.hpp"
 #endif
