@@ -93,6 +93,15 @@ int pqp_batch_flush(pqp_batch* h);
  * QP::solve() on every QP of the batch, one workgroup per QP.  Synchronous. */
 int pqp_batch_solve(pqp_batch* h);
 
+/* QP::solve() on the QPs [first, first + count) only (reference dense/wrapper.hpp:922-939;
+ * `qps.get(i).solve()` in bindings/python/proxsuite/torch/qplayer.py:160-162 is
+ * count == 1).  pqp_batch_solve(h) == pqp_batch_solve_range(h, 0, B). */
+int pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count);
+
+/* HIP stream (hipStream_t, passed as void*) the setup and solve kernels are launched on;
+ * NULL (the default) is the null stream.  Calls stay synchronous with respect to the host. */
+int pqp_batch_set_stream(pqp_batch* h, void* stream);
+
 /* QP::results (x, y, z, se, si, info); any output pointer may be NULL. */
 int pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z, double* se,
                           double* si, pqp_info* info);

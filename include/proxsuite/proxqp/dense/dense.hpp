@@ -1,0 +1,8 @@
+// proxsuite/proxqp/dense/dense.hpp -- umbrella header of the dense ProxQP API, MI355X build
+// (reference include/proxsuite/proxqp/dense/dense.hpp).
+#ifndef PROXSUITE_AMD_PROXQP_DENSE_DENSE_HPP
+#define PROXSUITE_AMD_PROXQP_DENSE_DENSE_HPP
+
+#include "proxsuite/proxqp/dense/wrapper.hpp"
+
+#endif

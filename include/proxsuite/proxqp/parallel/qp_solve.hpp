@@ -1,0 +1,67 @@
+// proxsuite/proxqp/parallel/qp_solve.hpp -- dense::solve_in_parallel on MI355X.
+//
+// The reference runs `qp.solve()` for every QP under `#pragma omp parallel for
+// schedule(dynamic)` (include/proxsuite/proxqp/parallel/qp_solve.hpp:17-59).  Here the unit of
+// parallelism is one GPU workgroup per QP: a BatchQP is solved with ONE kernel launch per
+// device pool (pqp_batch_solve_range, include/proxqp_hip.h), followed by one bulk copy of the
+// results.  `num_threads` is accepted for source compatibility and ignored.
+#ifndef PROXSUITE_AMD_PROXQP_PARALLEL_QPSOLVE_HPP
+#define PROXSUITE_AMD_PROXQP_PARALLEL_QPSOLVE_HPP
+
+#include <cstring>
+
+#include "proxsuite/proxqp/dense/wrapper.hpp"
+
+namespace proxsuite {
+namespace proxqp {
+namespace dense {
+
+template<typename T>
+void
+solve_in_parallel(BatchQP<T>& qps, const optional<usize> /*num_threads*/ = nullopt)
+{
+  for (const auto& e : qps.pools()) {
+    const detail::Pool& p = *e.pool;
+    if (p.used == 0)
+      continue;
+    for (isize idx : e.members)
+      qps[idx].push_settings();
+    detail::check(pqp_batch_solve_range(p.h, 0, p.used));
+    // one device-to-host copy per array for the whole pool, then scatter
+    const usize B = usize(p.capacity);
+    std::vector<T> x(B * usize(p.dim)), y(B * usize(p.n_eq)), z(B * usize(p.n_c)), se(B * usize(p.n_eq)),
+      si(B * usize(p.n_c));
+    std::vector<pqp_info> info(B);
+    detail::check(pqp_batch_get_results(p.h, -1, x.data(), y.data(), z.data(), se.data(), si.data(), info.data()));
+    for (usize s = 0; s < e.members.size(); ++s) {
+      QP<T>& q = qps[e.members[s]];
+      auto put = [s](Vec<T>& dst, const std::vector<T>& src) {
+        if (dst.size())
+          std::memcpy(dst.data(), src.data() + s * usize(dst.size()), usize(dst.size()) * sizeof(T));
+      };
+      put(q.results.x, x);
+      put(q.results.y, y);
+      put(q.results.z, z);
+      put(q.results.se, se);
+      put(q.results.si, si);
+      q.results.info.from_c(info[s]);
+      q.pull_settings();
+    }
+  }
+}
+
+// std::vector of standalone QPs (reference qp_solve.hpp:17-39): every QP is its own pool of
+// one, so this is a loop of single-workgroup launches.  Use BatchQP for throughput.
+template<typename T>
+void
+solve_in_parallel(std::vector<QP<T>>& qps, const optional<usize> /*num_threads*/ = nullopt)
+{
+  for (auto& qp : qps)
+    qp.solve();
+}
+
+} // namespace dense
+} // namespace proxqp
+} // namespace proxsuite
+
+#endif

@@ -35,7 +35,7 @@ class NativeLib:
     SYMBOLS = ("pqp_last_error", "pqp_device_count", "pqp_batch_create", "pqp_batch_destroy",
                "pqp_batch_size", "pqp_batch_dense_backend", "pqp_batch_settings", "pqp_batch_init",
                "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_flush",
-               "pqp_batch_solve", "pqp_batch_get_results", "pqp_batch_result_device_ptrs",
+               "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_set_stream", "pqp_batch_get_results", "pqp_batch_result_device_ptrs",
                "pqp_batch_get_scaled", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
                "pqp_batch_launch_config")
 
@@ -59,6 +59,8 @@ class NativeLib:
         L.pqp_batch_cleanup.argtypes = [vp, C.c_int64]
         L.pqp_batch_flush.argtypes = [vp]
         L.pqp_batch_solve.argtypes = [vp]
+        L.pqp_batch_solve_range.argtypes = [vp, C.c_int64, C.c_int64]
+        L.pqp_batch_set_stream.argtypes = [vp, vp]
         L.pqp_batch_get_results.argtypes = [vp, C.c_int64] + [_DP] * 5 + [C.POINTER(pqp_info)]
         L.pqp_batch_result_device_ptrs.argtypes = [vp] + [C.POINTER(_DP)] * 3
         L.pqp_batch_get_scaled.argtypes = [vp, C.c_int64] + [_DP] * 9
@@ -201,8 +203,15 @@ class Batch:
     def flush(self):
         self.lib.check(self.lib.L.pqp_batch_flush(self._h))
 
-    def solve(self):
-        self.lib.check(self.lib.L.pqp_batch_solve(self._h))
+    def solve(self, first=None, count=None):
+        if first is None:
+            self.lib.check(self.lib.L.pqp_batch_solve(self._h))
+        else:
+            self.lib.check(self.lib.L.pqp_batch_solve_range(self._h, int(first), int(1 if count is None else count)))
+
+    def set_stream(self, stream):
+        """`stream`: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        self.lib.check(self.lib.L.pqp_batch_set_stream(self._h, C.c_void_p(int(stream) if stream else None)))
 
     @property
     def last_solve_ms(self):
@@ -220,6 +229,34 @@ class Batch:
         ip = C.cast(info, C.POINTER(pqp_info)) if idx < 0 else C.byref(info)
         self.lib.check(self.lib.L.pqp_batch_get_results(self._h, int(idx), p(x), p(y), p(z), p(se), p(si), ip))
         return x, y, z, se, si, info
+
+    def results_into(self, x=None, y=None, z=None, se=None, si=None, idx=-1):
+        """Copy results straight into caller buffers (numpy arrays or torch tensors, host or
+        ROCm device; fp64 contiguous).  A device tensor makes this a device-to-device copy."""
+        pre = (self.B,) if idx < 0 else ()
+        want = dict(x=pre + (self.n,), y=pre + (self.n_eq,), z=pre + (self.n_c,), se=pre + (self.n_eq,),
+                    si=pre + (self.n_c,))
+        ptrs = []
+        for name, buf in (("x", x), ("y", y), ("z", z), ("se", se), ("si", si)):
+            if buf is None or (hasattr(buf, "numel") and buf.numel() == 0) or (hasattr(buf, "size") and not callable(buf.size) and buf.size == 0):
+                ptrs.append(None)
+                continue
+            if hasattr(buf, "data_ptr"):
+                import torch
+                if buf.dtype != torch.float64 or not buf.is_contiguous() or tuple(buf.shape) != want[name]:
+                    raise ValueError("results_into: %s must be a contiguous float64 tensor of shape %s" % (name, want[name]))
+                ptrs.append(C.cast(buf.data_ptr(), _DP))
+            else:
+                if buf.dtype != np.float64 or not buf.flags.c_contiguous or tuple(buf.shape) != want[name]:
+                    raise ValueError("results_into: %s must be a C-contiguous float64 array of shape %s" % (name, want[name]))
+                ptrs.append(buf.ctypes.data_as(_DP))
+        self.lib.check(self.lib.L.pqp_batch_get_results(self._h, int(idx), *ptrs, None))
+
+    def infos(self):
+        info = (pqp_info * self.B)()
+        self.lib.check(self.lib.L.pqp_batch_get_results(self._h, -1, None, None, None, None, None,
+                                                        C.cast(info, C.POINTER(pqp_info))))
+        return info
 
     def scaled(self, idx):
         n, ne, ni = self.n, self.n_eq, self.n_in

@@ -69,10 +69,10 @@ pqp_setup_kernel(pqp::Batch batch)
 // lane): the knob that trades spills against resident workgroups per CU.
 template<int NT, int WPS>
 __global__ __launch_bounds__(NT, WPS) void
-pqp_solve_kernel(pqp::Batch batch)
+pqp_solve_kernel(pqp::Batch batch, long first)
 {
   HIP_DYNAMIC_SHARED(double, smem)
-  pqp::solve_body<NT>(batch, (long)blockIdx.x, (pqp::lptr)smem);
+  pqp::solve_body<NT>(batch, first + (long)blockIdx.x, (pqp::lptr)smem);
 }
 
 struct pqp_batch
@@ -93,6 +93,8 @@ struct pqp_batch
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
+  hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
+  long range_first = 0, range_count = 0;
 };
 
 namespace {
@@ -117,7 +119,7 @@ launch_setup(pqp_batch* h)
   if (h->lds_setup > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_setup_kernel<NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_setup));
-  hipLaunchKernelGGL((pqp_setup_kernel<NT>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, nullptr,
+  hipLaunchKernelGGL((pqp_setup_kernel<NT>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, h->stream,
                      h->dev);
   HIP_TRY(hipGetLastError());
   return PQP_OK;
@@ -130,11 +132,11 @@ launch_solve(pqp_batch* h)
   if (h->lds_solve > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
-  HIP_TRY(hipEventRecord(h->ev0, nullptr));
-  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_solve,
-                     nullptr, h->dev);
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
+                     h->stream, h->dev, h->range_first);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(h->ev1, nullptr));
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
   return PQP_OK;
 }
 
@@ -601,12 +603,35 @@ pqp_batch_flush(pqp_batch* h)
 }
 
 int
+pqp_batch_set_stream(pqp_batch* h, void* stream)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  h->stream = static_cast<hipStream_t>(stream);
+  return PQP_OK;
+}
+
+int
 pqp_batch_solve(pqp_batch* h)
 {
   if (!h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
-  if (h->dev.B == 0)
+  return pqp_batch_solve_range(h, 0, h->dev.B);
+}
+
+int
+pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (first < 0 || count < 0 || first + count > h->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "solve range [" + std::to_string(first) + ", " +
+                                            std::to_string(first + count) + ") outside the batch of " +
+                                            std::to_string(h->dev.B) + " QPs");
+  if (count == 0)
     return PQP_OK;
+  h->range_first = first;
+  h->range_count = count;
   HIP_TRY(hipSetDevice(h->device));
   if (int rc = pqp_batch_flush(h))
     return rc;
@@ -615,10 +640,9 @@ pqp_batch_solve(pqp_batch* h)
   if (int rc = dispatch_solve(h))
     return rc;
   HIP_TRY(hipEventSynchronize(h->ev1));
-  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
-  std::fill(h->is_initialized.begin(), h->is_initialized.end(), char(1));
+  std::fill(h->is_initialized.begin() + first, h->is_initialized.begin() + first + count, char(1));
   return PQP_OK;
 }
 

@@ -1,0 +1,386 @@
+"""`proxsuite.proxqp.dense` rebuilt on the MI355X batch solver (libproxqp_hip.so).
+
+Same names, argument order, defaults and error behaviour as the reference's nanobind module
+(reference bindings/python/src/expose-qpobject.hpp:60-230, expose-qpvector.hpp:22-39,
+expose-parallel.hpp:27-46, expose-solve.hpp) for the dense ProxQP path:
+
+    QP(n, n_eq, n_in, box_constraints=False, hessian_type=Dense, dense_backend=Automatic)
+        .init(...) .update(...) .solve([x, y, z]) .cleanup() .settings .results .model
+    BatchQP(batch_size) .init_qp_in_place(n, n_eq, n_in) .insert(qp) .get(i) .size()
+    VectorQP()          .append(qp)
+    solve_in_parallel(qps, num_threads=None)
+    solve(H, g, A, b, C, l, u, ...)
+
+What differs is where the work happens.  A `BatchQP` owns device-resident *pools*: one
+C-ABI batch handle per problem signature (n, n_eq, n_in, box, Hessian type, backend), sized
+`batch_size`; `init_qp_in_place` hands out a `QP` that is a (pool, slot) view, and
+`solve_in_parallel` is ONE kernel launch per pool with one workgroup per QP.  A standalone
+`QP` is a pool of one.  Every numerical step runs in the HIP kernels; this file only moves
+arguments.  There is no CPU fallback: constructing a QP without the HIP library or without
+a GPU raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _native
+from .._ctypes_defs import (DenseBackend, HessianType, InitialGuess, MeritFunctionType, QPSolverOutput,
+                            pqp_info, pqp_settings)
+
+__all__ = ["QP", "BatchQP", "VectorQP", "solve_in_parallel", "solve", "DenseBackend", "HessianType",
+           "InitialGuess", "QPSolverOutput", "MeritFunctionType", "Settings", "Results", "Info", "Model"]
+
+_BOOL_SETTINGS = ("verbose", "update_preconditioner", "compute_preconditioner", "compute_timings",
+                  "check_duality_gap", "bcl_update", "primal_infeasibility_solving")
+_ENUM_SETTINGS = {"initial_guess": InitialGuess, "merit_function_type": MeritFunctionType}
+_SETTING_NAMES = tuple(n for n, _ in pqp_settings._fields_ if n != "_pad")
+_INFO_NAMES = tuple(n for n, _ in pqp_info._fields_ if n != "_pad")
+
+
+class Settings:
+    """`qp.settings` (reference settings.hpp:95-315): a live view of the host-side
+    pqp_settings record of one QP; it is re-read at every solve, as in the reference."""
+
+    __slots__ = ("_s",)
+
+    def __init__(self, raw):
+        object.__setattr__(self, "_s", raw)
+
+    def __getattr__(self, name):
+        if name not in _SETTING_NAMES:
+            raise AttributeError(name)
+        v = getattr(self._s, name)
+        if name in _BOOL_SETTINGS:
+            return bool(v)
+        if name in _ENUM_SETTINGS:
+            return _ENUM_SETTINGS[name](v)
+        return v
+
+    def __setattr__(self, name, value):
+        if name not in _SETTING_NAMES:
+            raise AttributeError("Settings has no field %r" % name)
+        setattr(self._s, name, int(value) if (name in _BOOL_SETTINGS or name in _ENUM_SETTINGS) else value)
+
+    def __repr__(self):
+        return "Settings(" + ", ".join("%s=%r" % (n, getattr(self, n)) for n in _SETTING_NAMES) + ")"
+
+
+class Info:
+    """`qp.results.info` (reference results.hpp:27-74)."""
+
+    __slots__ = ("_i",)
+
+    def __init__(self, raw):
+        object.__setattr__(self, "_i", raw)
+
+    def __getattr__(self, name):
+        if name in ("sparse_backend",):
+            raise AttributeError("sparse_backend belongs to the sparse solver")
+        if name not in _INFO_NAMES:
+            raise AttributeError(name)
+        v = getattr(self._i, name)
+        return QPSolverOutput(v) if name == "status" else v
+
+    def __repr__(self):
+        return "Info(" + ", ".join("%s=%r" % (n, getattr(self, n)) for n in _INFO_NAMES) + ")"
+
+
+class Results:
+    """`qp.results` (reference results.hpp:76-204): x, y, z, se, si, info."""
+
+    __slots__ = ("x", "y", "z", "se", "si", "info")
+
+    def __init__(self, x, y, z, se, si, info):
+        self.x, self.y, self.z, self.se, self.si, self.info = x, y, z, se, si, Info(info)
+
+
+class Model:
+    """`qp.model` (reference dense/model.hpp:24-63): the last data handed to init/update."""
+
+    def __init__(self, dim, n_eq, n_in, box):
+        self.dim, self.n_eq, self.n_in = dim, n_eq, n_in
+        self.n_total = dim + n_eq + n_in
+        self.H = np.zeros((dim, dim))
+        self.g = np.zeros(dim)
+        self.A = np.zeros((n_eq, dim))
+        self.b = np.zeros(n_eq)
+        self.C = np.zeros((n_in, dim))
+        self.l = np.zeros(n_in)
+        self.u = np.zeros(n_in)
+        if box:
+            self.l_box = np.zeros(dim)
+            self.u_box = np.zeros(dim)
+
+    def is_valid(self, box_constraints=False):
+        return bool(np.allclose(self.H, self.H.T))
+
+
+class _Pool:
+    """One device batch handle: `capacity` slots of one problem signature."""
+
+    def __init__(self, capacity, n, n_eq, n_in, box, hessian_type, dense_backend, device):
+        self.batch = _native.Batch(capacity, n, n_eq, n_in, box_constraints=box, hessian_type=int(hessian_type),
+                                   dense_backend=int(dense_backend), device=device)
+        self.capacity = capacity
+        self.used = 0
+        self._epoch = 0
+        self._cache_epoch = -1
+        self._cache = None
+
+    def touch(self):
+        self._epoch += 1
+
+    def fetch(self):
+        if self._cache_epoch != self._epoch:
+            self._cache = self.batch.results(-1)
+            self._cache_epoch = self._epoch
+        return self._cache
+
+    def solve(self, first=None, count=None):
+        if first is None:
+            first, count = 0, self.used
+        if count:
+            self.batch.solve(first, count)
+        self.touch()
+
+
+_INF_BOUND = 1.0e20
+
+
+def _host(a):
+    if a is None:
+        return None
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    a = np.asarray(a, dtype=np.float64)
+    return None if a.size == 0 else a
+
+
+class QP:
+    """reference dense/wrapper.hpp:114-963 (python: expose-qpobject.hpp:60-230)."""
+
+    def __init__(self, n=0, n_eq=0, n_in=0, box_constraints=False, hessian_type=HessianType.Dense,
+                 dense_backend=DenseBackend.Automatic, *, device=0, _pool=None, _slot=0):
+        # the reference has 8 constructor overloads; python exposes this single keyword form
+        if isinstance(box_constraints, (HessianType, DenseBackend)):
+            raise TypeError("box_constraints must be a bool (use keywords for hessian_type / dense_backend)")
+        n, n_eq, n_in = int(n), int(n_eq), int(n_in)
+        if n <= 0:
+            # reference dense/model.hpp:65-68 (PROXSUITE_THROW_PRETTY -> std::invalid_argument)
+            raise ValueError("wrong argument size: the dimension wrt the primal variable x should be strictly positive.")
+        self._box = bool(box_constraints)
+        self._hessian = HessianType(hessian_type)
+        if _pool is None:
+            _pool = _Pool(1, n, n_eq, n_in, self._box, self._hessian, DenseBackend(dense_backend), device)
+            _pool.used = 1
+            _slot = 0
+        self._pool, self._slot = _pool, _slot
+        self._backend = DenseBackend(_pool.batch.dense_backend)
+        self.model = Model(n, n_eq, n_in, self._box)
+        self.settings = Settings(_pool.batch.settings(_slot))
+
+    # -- introspection (wrapper.hpp:334-336)
+    def is_box_constrained(self):
+        return self._box
+
+    def which_dense_backend(self):
+        return self._backend
+
+    def which_hessian_type(self):
+        return self._hessian
+
+    # -- helpers
+    def _split_tail(self, args, kw, flag_name, flag_default):
+        """The reference overloads: (..., u, flag, rho, mu_eq, mu_in, min_eig) without boxes and
+        (..., u, l_box, u_box, flag, rho, mu_eq, mu_in, min_eig) with them."""
+        names = ["l_box", "u_box", flag_name, "rho", "mu_eq", "mu_in", "manual_minimal_H_eigenvalue"]
+        if args and isinstance(args[0], (bool, np.bool_)):
+            names = names[2:]  # the overload without boxes: the first extra positional is the flag
+        if len(args) > len(names):
+            raise TypeError("too many positional arguments")
+        vals = dict(zip(names, args))
+        for k, v in kw.items():
+            if k not in ("l_box", "u_box", flag_name, "rho", "mu_eq", "mu_in", "manual_minimal_H_eigenvalue"):
+                raise TypeError("unexpected keyword argument %r" % k)
+            if k in vals:
+                raise TypeError("got multiple values for argument %r" % k)
+            vals[k] = v
+        vals.setdefault(flag_name, flag_default)
+        if self._box and "l_box" not in vals and "u_box" not in vals:
+            # the overload without boxes on a box-constrained QP (reference wrapper.hpp:367-372 / :736-741)
+            raise ValueError("wrong model setup: the QP object is designed with box constraints, but is used "
+                             "without lower or upper box inequalities.")
+        l_box, u_box = _host(vals.get("l_box")), _host(vals.get("u_box"))
+        if not self._box and (l_box is not None or u_box is not None):
+            # reference dense/wrapper.hpp:542-546 / :846-850
+            raise ValueError("wrong model setup: the QP object was initialized without box constraints, "
+                             "but is used with box constraints inputs.")
+        return (l_box, u_box, bool(vals[flag_name]), vals.get("rho"), vals.get("mu_eq"), vals.get("mu_in"),
+                vals.get("manual_minimal_H_eigenvalue"))
+
+    def _remember(self, **arrays):
+        m = self.model
+        for k, a in arrays.items():
+            if a is not None:
+                tgt = getattr(m, k)
+                if a.shape == tgt.shape:
+                    if k in ("l", "l_box"):
+                        a = np.maximum(a, -_INF_BOUND)
+                    elif k in ("u", "u_box"):
+                        a = np.minimum(a, _INF_BOUND)
+                    setattr(m, k, np.array(a, dtype=np.float64))
+
+    def init(self, H=None, g=None, A=None, b=None, C=None, l=None, u=None, *args, **kw):
+        """QP::init (reference dense/wrapper.hpp:354-498 and, with boxes, :520-703)."""
+        l_box, u_box, flag, rho, mu_eq, mu_in, min_eig = self._split_tail(args, kw, "compute_preconditioner", True)
+        H, g, A, b, C, l, u = map(_host, (H, g, A, b, C, l, u))
+        self._pool.batch.init(self._slot, H, g, A, b, C, l, u, l_box, u_box, flag, rho, mu_eq, mu_in, min_eig)
+        self._remember(H=H, g=g, A=A, b=b, C=C, l=l, u=u, l_box=l_box, u_box=u_box)
+        self._pool.touch()
+
+    def update(self, H=None, g=None, A=None, b=None, C=None, l=None, u=None, *args, **kw):
+        """QP::update (reference dense/wrapper.hpp:723-807 / :831-918)."""
+        l_box, u_box, flag, rho, mu_eq, mu_in, min_eig = self._split_tail(args, kw, "update_preconditioner", False)
+        H, g, A, b, C, l, u = map(_host, (H, g, A, b, C, l, u))
+        self._pool.batch.update(self._slot, H, g, A, b, C, l, u, l_box, u_box, flag, rho, mu_eq, mu_in, min_eig)
+        self._remember(H=H, g=g, A=A, b=b, C=C, l=l, u=u, l_box=l_box, u_box=u_box)
+        self._pool.touch()
+
+    def solve(self, x=None, y=None, z=None):
+        """QP::solve() / QP::solve(x, y, z) (reference dense/wrapper.hpp:922-957)."""
+        x, y, z = _host(x), _host(y), _host(z)
+        if x is not None or y is not None or z is not None:
+            self._pool.batch.warm_start(self._slot, x, y, z)
+        self._pool.solve(self._slot, 1)
+
+    def cleanup(self):
+        """QP::cleanup (reference dense/wrapper.hpp:958-962)."""
+        self._pool.batch.cleanup(self._slot)
+        self._pool.touch()
+
+    @property
+    def results(self) -> Results:
+        x, y, z, se, si, info = self._pool.fetch()
+        s = self._slot
+        return Results(x[s], y[s], z[s], se[s], si[s], info[s])
+
+
+class BatchQP:
+    """reference dense/wrapper.hpp:1253-1311 (python: expose-qpvector.hpp:22-39).
+
+    `batch_size` is the capacity of each device pool (the reference reserves a vector of that
+    size).  QPs of different sizes may share a BatchQP: each signature gets its own pool."""
+
+    def __init__(self, batch_size=0, *, device=0):
+        self._capacity = max(int(batch_size), 1)
+        self._device = device
+        self._pools = {}   # signature -> [pools]
+        self._qps = []
+
+    def init_qp_in_place(self, dim, n_eq, n_in, box_constraints=False, hessian_type=HessianType.Dense,
+                         dense_backend=DenseBackend.Automatic) -> QP:
+        key = (int(dim), int(n_eq), int(n_in), bool(box_constraints), int(hessian_type), int(dense_backend))
+        if key[0] <= 0:
+            raise ValueError("wrong argument size: the dimension wrt the primal variable x should be strictly positive.")
+        chain = self._pools.setdefault(key, [])
+        if not chain or chain[-1].used == chain[-1].capacity:
+            chain.append(_Pool(self._capacity, key[0], key[1], key[2], key[3], key[4], key[5], self._device))
+        pool = chain[-1]
+        qp = QP(key[0], key[1], key[2], key[3], HessianType(key[4]), DenseBackend(key[5]), _pool=pool,
+                _slot=pool.used)
+        pool.used += 1
+        self._qps.append(qp)
+        return qp
+
+    def insert(self, qp: QP):
+        """Copies `qp` (model, settings) into a new slot.  The reference's insert forgets to bump
+        m_size (dense/wrapper.hpp:1288), which hides the inserted QP from size() and
+        solve_in_parallel; here it counts."""
+        m = qp.model
+        new = self.init_qp_in_place(m.dim, m.n_eq, m.n_in, qp._box, qp._hessian, qp._backend)
+        for name in _SETTING_NAMES:
+            setattr(new.settings._s, name, getattr(qp.settings._s, name))
+        extra = dict(l_box=m.l_box, u_box=m.u_box) if qp._box else {}
+        new.init(m.H, m.g, m.A if m.n_eq else None, m.b if m.n_eq else None, m.C if m.n_in else None,
+                 m.l if m.n_in else None, m.u if m.n_in else None,
+                 compute_preconditioner=qp.settings.compute_preconditioner, **extra)
+        return new
+
+    def get(self, i) -> QP:
+        return self._qps[i]
+
+    __getitem__ = get
+
+    def size(self):
+        return len(self._qps)
+
+    __len__ = size
+
+    def __iter__(self):
+        return iter(self._qps)
+
+    def _all_pools(self):
+        return [p for chain in self._pools.values() for p in chain]
+
+
+class VectorQP(list):
+    """`std::vector<dense::QP<T>>` of the reference (expose-parallel.hpp:27-31).  Prefer BatchQP:
+    QPs collected here are standalone pools of one and are launched one kernel each."""
+
+    def append(self, qp):
+        if not isinstance(qp, QP):
+            raise TypeError("VectorQP holds dense.QP objects")
+        super().append(qp)
+
+
+def solve_in_parallel(qps, num_threads=None):
+    """dense::solve_in_parallel (reference parallel/qp_solve.hpp:17-59; python
+    expose-parallel.hpp:33-46).  `num_threads` is accepted for compatibility; the degree of
+    parallelism is one workgroup per QP over the whole device."""
+    if isinstance(qps, BatchQP):
+        for pool in qps._all_pools():
+            pool.solve()
+        return
+    pools = {}
+    for qp in qps:
+        pools.setdefault(id(qp._pool), (qp._pool, []))[1].append(qp._slot)
+    for pool, slots in pools.values():
+        slots.sort()
+        # contiguous runs become one launch each
+        start = prev = slots[0]
+        for s in slots[1:] + [None]:
+            if s is not None and s == prev + 1:
+                prev = s
+                continue
+            pool.solve(start, prev - start + 1)
+            start = prev = s
+
+
+def solve(H=None, g=None, A=None, b=None, C=None, l=None, u=None, x=None, y=None, z=None, eps_abs=None,
+          eps_rel=None, rho=None, mu_eq=None, mu_in=None, verbose=None, compute_preconditioner=True,
+          compute_timings=False, max_iter=None, initial_guess=InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS,
+          check_duality_gap=False, eps_duality_gap_abs=None, eps_duality_gap_rel=None,
+          primal_infeasibility_solving=False, default_H_eigenvalue_estimate=None, l_box=None, u_box=None):
+    """One-shot `dense::solve` (reference dense/wrapper.hpp:1000-1092 and, with boxes, :1133-1236)."""
+    H_, A_, C_ = _host(H), _host(A), _host(C)
+    n = H_.shape[0] if H_ is not None else (len(g) if g is not None else 0)
+    n_eq = A_.shape[0] if A_ is not None else 0
+    n_in = C_.shape[0] if C_ is not None else 0
+    box = l_box is not None or u_box is not None
+    qp = QP(n, n_eq, n_in, box, HessianType.Dense, DenseBackend.PrimalDualLDLT)
+    st = qp.settings
+    st.initial_guess = initial_guess
+    st.check_duality_gap = check_duality_gap
+    for name, v in (("eps_abs", eps_abs), ("eps_rel", eps_rel), ("verbose", verbose), ("max_iter", max_iter),
+                    ("eps_duality_gap_abs", eps_duality_gap_abs), ("eps_duality_gap_rel", eps_duality_gap_rel)):
+        if v is not None:
+            setattr(st, name, v)
+    st.compute_timings = compute_timings
+    st.primal_infeasibility_solving = primal_infeasibility_solving
+    kw = dict(compute_preconditioner=compute_preconditioner, rho=rho, mu_eq=mu_eq, mu_in=mu_in,
+              manual_minimal_H_eigenvalue=default_H_eigenvalue_estimate)
+    if box:
+        kw.update(l_box=l_box, u_box=u_box)
+    qp.init(H_, g, A_, b, C_, l, u, **kw)
+    qp.solve(x, y, z)
+    return qp.results

@@ -1,0 +1,124 @@
+"""QPFunction: the forward of `proxsuite.torch.qplayer.QPFunction` on MI355X.
+
+Mirrors reference bindings/python/proxsuite/torch/qplayer.py:12-167 (feasible QPs) and
+:255-369 (closest-feasible QPs, `structural_feasibility=False`): same factory arguments,
+same solver settings (max_iter = maxIter, max_iter_in = 100, rho = 5e-5 with
+refactor_rho_threshold = rho, eps_abs = eps), same outputs.  The reference loops over the
+batch in Python, copies every matrix to numpy, and calls init/solve per QP; here the whole
+batch goes through ONE pqp_batch_init (pointers of the torch tensors, host or ROCm, are
+handed to the C-ABI as they are), ONE solve launch with one workgroup per QP, and the
+results are copied device-to-device into the output tensors.
+
+The backward pass (reference qplayer.py:172-253, dense/compute_ECJ.hpp) is the next row of
+the scope table and is not built yet: it raises.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from .. import _native
+from .._ctypes_defs import DenseBackend, HessianType
+
+
+def _extract_nbatch(*params_and_dims):
+    for param, dim in params_and_dims:
+        if param.ndimension() == dim:
+            return param.size(0)
+    return 1
+
+
+def _expand(X, nbatch, ndim):
+    # reference bindings/python/proxsuite/torch/utils.py:57-63
+    if X.ndimension() in (0, ndim) or X.nelement() == 0:
+        return X
+    if X.ndimension() == ndim - 1:
+        return X.unsqueeze(0).expand(*([nbatch] + list(X.size())))
+    raise RuntimeError("Unexpected number of dimensions.")
+
+
+def _dense64(t):
+    return t.detach().to(torch.float64).contiguous()
+
+
+def _solve_batch(Q, p, A, b, G, l, u, eps, max_iter, infeasible):
+    nbatch, nineq, nz = G.size()
+    neq = A.size(1) if A.nelement() > 0 else 0
+    assert neq > 0 or nineq > 0
+    dev = Q.device
+    index = dev.index if dev.type == "cuda" and dev.index is not None else 0
+    batch = _native.Batch(nbatch, nz, neq, nineq, box_constraints=False, hessian_type=int(HessianType.Dense),
+                          dense_backend=int(DenseBackend.Automatic), device=index)
+    rho = 5.0e-5
+    for i in range(nbatch):
+        st = batch.settings(i)
+        st.primal_infeasibility_solving = int(infeasible)
+        st.max_iter = max_iter
+        st.max_iter_in = 100
+        st.default_rho = rho
+        st.refactor_rho_threshold = rho  # no refactorization
+        st.eps_abs = eps
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()  # inputs may still be in flight on torch's stream
+    batch.init(-1, _dense64(Q), _dense64(p), _dense64(A) if neq else None, _dense64(b) if neq else None,
+               _dense64(G) if nineq else None, _dense64(l) if nineq else None, _dense64(u) if nineq else None,
+               rho=rho)
+    batch.solve()
+    opts = dict(dtype=torch.float64, device=dev)
+    x = torch.empty((nbatch, nz), **opts)
+    y = torch.empty((nbatch, neq), **opts)
+    z = torch.empty((nbatch, nineq), **opts)
+    se = torch.empty((nbatch, neq), **opts)
+    si = torch.empty((nbatch, nineq), **opts)
+    batch.results_into(x, y, z, se, si)
+    return batch, x, y, z, se, si
+
+
+def QPFunction(eps=1e-9, maxIter=1000, eps_backward=1.0e-4, rho_backward=1.0e-6, mu_backward=1.0e-6,
+               omp_parallel=False, structural_feasibility=True):
+    """Factory with the reference's signature (qplayer.py:12-20).  `omp_parallel` is accepted and
+    ignored: the batch is always solved in one launch."""
+
+    class QPFunctionFn(Function):
+        @staticmethod
+        def forward(ctx, Q_, p_, A_, b_, G_, l_, u_):
+            nbatch = _extract_nbatch((Q_, 3), (p_, 2), (A_, 3), (b_, 2), (G_, 3), (l_, 2), (u_, 2))
+            Q, p, G = _expand(Q_, nbatch, 3), _expand(p_, nbatch, 2), _expand(G_, nbatch, 3)
+            u, l = _expand(u_, nbatch, 2), _expand(l_, nbatch, 2)
+            A, b = _expand(A_, nbatch, 3), _expand(b_, nbatch, 2)
+            batch, x, y, z, _, _ = _solve_batch(Q, p, A, b, G, l, u, eps, maxIter, infeasible=False)
+            ctx.batch = batch
+            return x.to(Q.dtype), y.to(Q.dtype), z.to(Q.dtype)
+
+        @staticmethod
+        def backward(ctx, dl_dzhat, dl_dlams, dl_dnus):
+            raise NotImplementedError(
+                "QPFunction backward (reference dense/compute_ECJ.hpp:29-189) is not part of this "
+                "round's scope (SURVEY.md section 8(f), rank 1)")
+
+    class QPFunctionFn_infeas(Function):
+        @staticmethod
+        def forward(ctx, Q_, p_, A_, b_, G_, l_, u_):
+            n_in, nz = G_.size()[-2:]
+            nbatch = _extract_nbatch((Q_, 3), (p_, 2), (A_, 3), (b_, 2), (G_, 3), (l_, 2), (u_, 2))
+            Q, p, G = _expand(Q_, nbatch, 3), _expand(p_, nbatch, 2), _expand(G_, nbatch, 3)
+            u, l = _expand(u_, nbatch, 2), _expand(l_, nbatch, 2)
+            A, b = _expand(A_, nbatch, 3), _expand(b_, nbatch, 2)
+            # single-sided restatement, as the reference does (qplayer.py:270-271)
+            h = torch.cat((-l, u), dim=1)
+            G1 = torch.cat((-G, G), dim=1)
+            lo = torch.full_like(h, -1.0e20)
+            batch, x, y, z, se, si = _solve_batch(Q, p, A, b, G1, lo, h, eps, maxIter, infeasible=True)
+            ctx.batch = batch
+            nus_sol = -z[:, :n_in] + z[:, n_in:]
+            s_i = -si[:, :n_in] + si[:, n_in:]
+            t = Q.dtype
+            return x.to(t), y.to(t), nus_sol.to(t), se.to(t), s_i.to(t)
+
+        @staticmethod
+        def backward(ctx, dl_dzhat, dl_dlams, dl_dnus, dl_ds_e, dl_ds_i):
+            raise NotImplementedError(
+                "QPFunction backward (reference dense/compute_ECJ.hpp:134-189) is not part of this "
+                "round's scope (SURVEY.md section 8(f), rank 1)")
+
+    return QPFunctionFn.apply if structural_feasibility else QPFunctionFn_infeas.apply

@@ -1,0 +1,199 @@
+"""Cases for the Python surface (proxsuite_amd.proxqp.dense, proxsuite_amd.torch) shared by the
+emulator suite (CPU, tests/test_emu_api.py) and the GPU suite (tests/test_gpu_api.py).  They read
+like the reference's python tests (test/src/dense_qp_wrapper.py, parallel_qp_solve.py,
+qplayer tests) and check results against the oracle."""
+import numpy as np
+
+from proxsuite_amd.utils import random_qp as rq
+
+
+def _qp_data(randqp, n, ne, ni, seed):
+    randqp.set_seed(seed)
+    m = randqp.dense_strongly_convex_qp(n, ne, ni, 0.15, 1e-2)
+    return dict(H=m.H, g=m.g, A=m.A, b=m.b, C=m.C, l=m.l, u=m.u)
+
+
+def _kkt(oracle_mod, d, x, y, z):
+    return oracle_mod.kkt_residuals(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"], x, y, z)
+
+
+def case_qp_object(dense, oracle, randqp):
+    """init / solve / update / warm re-solve on a standalone QP (reference
+    test/src/dense_qp_wrapper.py: test_case_update_rho .. test_case_warm_start_with_previous_result)."""
+    n, ne, ni = 10, 3, 4
+    d = _qp_data(randqp, n, ne, ni, 1)
+    qp = dense.QP(n, ne, ni)
+    assert not qp.is_box_constrained()
+    assert qp.which_hessian_type() == dense.HessianType.Dense
+    assert qp.which_dense_backend() in (dense.DenseBackend.PrimalDualLDLT, dense.DenseBackend.PrimalLDLT)
+    qp.settings.eps_abs = 1e-9
+    qp.settings.eps_rel = 0
+    assert qp.settings.initial_guess == dense.InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS
+    assert qp.settings.verbose is False
+    assert qp.results.info.status == dense.QPSolverOutput.PROXQP_NOT_RUN  # results.hpp:101
+    qp.init(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"])
+    # setup() -> cleanup_statistics() presets MAX_ITER_REACHED (results.hpp:172)
+    assert qp.results.info.status == dense.QPSolverOutput.PROXQP_MAX_ITER_REACHED
+    qp.solve()
+    r = qp.results
+    assert r.info.status == dense.QPSolverOutput.PROXQP_SOLVED
+    pri, dua = _kkt(oracle, d, r.x, r.y, r.z)
+    assert max(pri, dua) <= 1e-9
+    assert r.x.shape == (n,) and r.y.shape == (ne,) and r.z.shape == (ni,)
+    np.testing.assert_allclose(qp.model.H, d["H"])
+    # oracle agreement incl. iteration counts
+    o = oracle.QP(n, ne, ni)
+    o.settings.eps_abs = 1e-9
+    o.settings.eps_rel = 0
+    o.init(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"])
+    o.solve()
+    np.testing.assert_allclose(r.x, o.results.x, atol=1e-9)
+    assert r.info.iter == o.results.info.iter and r.info.iter_ext == o.results.info.iter_ext
+    # update g and re-solve with the previous result (default guess after a first solve)
+    g2 = d["g"] * 1.5
+    qp.settings.initial_guess = dense.InitialGuess.WARM_START_WITH_PREVIOUS_RESULT
+    qp.update(g=g2)
+    qp.solve()
+    d2 = dict(d, g=g2)
+    r2 = qp.results
+    assert max(_kkt(oracle, d2, r2.x, r2.y, r2.z)) <= 1e-9
+    np.testing.assert_allclose(qp.model.g, g2)
+    # warm start from the solution: zero iterations (reference test/src/cvxpy.cpp:104-160)
+    qp.solve(r2.x, r2.y, r2.z)
+    assert qp.settings.initial_guess == dense.InitialGuess.WARM_START
+    assert qp.results.info.iter <= 1
+    # positional overload with the preconditioner flag and rho (reference wrapper.hpp:354)
+    qp.init(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"], True, 1e-7, 1e-4, 1e-2)
+    assert qp.results.info.rho == 1e-7 and qp.results.info.mu_eq == 1e-4 and qp.results.info.mu_in == 1e-2
+    qp.cleanup()
+    assert np.all(qp.results.x == 0)
+
+
+def case_errors(dense):
+    """argument checks of the reference (wrapper.hpp:380-451, :542-546; model.hpp:65-68)."""
+    import pytest
+    with pytest.raises(ValueError):
+        dense.QP(0, 0, 0)
+    qp = dense.QP(4, 1, 2)
+    with pytest.raises(ValueError):
+        qp.init(np.eye(3), np.zeros(4), None, None, None, None, None)
+    with pytest.raises(ValueError):
+        qp.init(np.eye(4), np.zeros(4), np.zeros((1, 4)), np.zeros(1), np.zeros((2, 4)), np.zeros(2), np.zeros(2),
+                l_box=np.zeros(4), u_box=np.ones(4))
+    with pytest.raises(AttributeError):
+        qp.settings.no_such_field = 1
+
+
+def case_box(dense, oracle, randqp):
+    n, ni = 8, 3
+    rng = np.random.default_rng(0)
+    M = rng.standard_normal((n, n))
+    H = M @ M.T + np.eye(n)
+    g = rng.standard_normal(n)
+    C = rng.standard_normal((ni, n))
+    xs = rng.standard_normal(n)
+    l, u = C @ xs - 1.0, C @ xs + 1.0
+    lb, ub = xs - 0.3, xs + 0.3
+    qp = dense.QP(n, 0, ni, True)
+    assert qp.is_box_constrained()
+    qp.settings.eps_abs = 1e-9
+    qp.init(H, g, None, None, C, l, u, lb, ub)
+    qp.solve()
+    r = qp.results
+    assert r.info.status == dense.QPSolverOutput.PROXQP_SOLVED
+    assert r.z.shape == (ni + n,)
+    # reference test dense_qp_wrapper.cpp:6889-6900: z = [z_in; z_box]; check KKT with the stacked C
+    pri, dua = oracle.kkt_residuals(H, g, np.zeros((0, n)), np.zeros(0), C, l, u, r.x, r.y, r.z, lb, ub)
+    assert max(pri, dua) <= 1e-9
+    # one-shot solve with boxes gives the same answer
+    r2 = dense.solve(H, g, None, None, C, l, u, eps_abs=1e-9, l_box=lb, u_box=ub)
+    np.testing.assert_allclose(r2.x, r.x, atol=1e-8)
+
+
+def case_batch_and_parallel(dense, oracle, randqp, B=6):
+    """reference test/src/parallel_qp_solve.py / examples/python/solve_dense_qp_in_parallel.py:
+    BatchQP.init_qp_in_place + solve_in_parallel == QP-by-QP solves; mixed sizes allowed."""
+    shapes = [(10, 3, 4)] * B + [(6, 0, 5), (6, 0, 5)]
+    qps = dense.BatchQP(B)
+    datas = []
+    for i, (n, ne, ni) in enumerate(shapes):
+        d = _qp_data(randqp, n, ne, ni, i)
+        qp = qps.init_qp_in_place(n, ne, ni)
+        qp.settings.eps_abs = 1e-9
+        qp.settings.initial_guess = dense.InitialGuess.NO_INITIAL_GUESS
+        qp.init(d["H"], d["g"], d["A"] if ne else None, d["b"] if ne else None, d["C"], d["l"], d["u"])
+        datas.append(d)
+    assert qps.size() == len(shapes)
+    dense.solve_in_parallel(qps, num_threads=4)
+    xs = []
+    for i, d in enumerate(datas):
+        r = qps.get(i).results
+        assert r.info.status == dense.QPSolverOutput.PROXQP_SOLVED
+        assert max(_kkt(oracle, d, r.x, r.y, r.z)) <= 1e-9
+        xs.append(np.array(r.x))
+    # serial, standalone QPs collected in a VectorQP (reference test/src/parallel_qp_solve.cpp:33-76)
+    vec = dense.VectorQP()
+    for (n, ne, ni), d in zip(shapes, datas):
+        qp = dense.QP(n, ne, ni)
+        qp.settings.eps_abs = 1e-9
+        qp.settings.initial_guess = dense.InitialGuess.NO_INITIAL_GUESS
+        qp.init(d["H"], d["g"], d["A"] if ne else None, d["b"] if ne else None, d["C"], d["l"], d["u"])
+        vec.append(qp)
+    dense.solve_in_parallel(vec)
+    for x, qp in zip(xs, vec):
+        assert np.array_equal(x, qp.results.x)  # same kernel, same order of operations: bit-identical
+    # a single QP of the batch re-solved alone (qps.get(i).solve(), qplayer.py:160-162)
+    q3 = qps.get(3)
+    q3.solve()
+    assert np.array_equal(q3.results.x, xs[3])
+    assert np.array_equal(qps.get(2).results.x, xs[2])
+    # insert() copies a QP into the batch
+    new = qps.insert(vec[0])
+    assert qps.size() == len(shapes) + 1
+    new.solve()
+    np.testing.assert_allclose(new.results.x, xs[0], atol=1e-9)
+
+
+def case_one_shot_solve(dense, oracle, randqp):
+    n, ne, ni = 12, 4, 6
+    d = _qp_data(randqp, n, ne, ni, 5)
+    r = dense.solve(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"], eps_abs=1e-9, eps_rel=0)
+    assert r.info.status == dense.QPSolverOutput.PROXQP_SOLVED
+    assert max(_kkt(oracle, d, r.x, r.y, r.z)) <= 1e-9
+    # warm-started one-shot call
+    r2 = dense.solve(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"], r.x, r.y, r.z, eps_abs=1e-9)
+    assert r2.info.iter <= 1
+
+
+def case_qpfunction(QPFunction, oracle, randqp, device="cpu", B=5):
+    """forward of the QPLayer (reference bindings/python/proxsuite/torch/qplayer.py:103-167) against
+    QP-by-QP oracle solves configured the way the reference configures them."""
+    import torch
+    n, ne, ni = 10, 3, 6
+    ds = [_qp_data(randqp, n, ne, ni, 100 + i) for i in range(B)]
+    t = lambda k: torch.tensor(np.stack([d[k] for d in ds]), dtype=torch.float64, device=device)
+    Q, p, A, b, G, u = t("H"), t("g"), t("A"), t("b"), t("C"), t("u")
+    l = torch.full_like(u, -1.0e20)
+    x, lam, nu = QPFunction(eps=1e-9, maxIter=1000)(Q, p, A, b, G, l, u)
+    assert x.shape == (B, n) and lam.shape == (B, ne) and nu.shape == (B, ni)
+    assert x.device.type == torch.device(device).type
+    for i, d in enumerate(ds):
+        o = oracle.QP(n, ne, ni)
+        o.settings.max_iter = 1000
+        o.settings.max_iter_in = 100
+        o.settings.default_rho = 5e-5
+        o.settings.refactor_rho_threshold = 5e-5
+        o.settings.eps_abs = 1e-9
+        o.init(d["H"], d["g"], d["A"], d["b"], d["C"], np.full(ni, -1e20), d["u"], rho=5e-5)
+        o.solve()
+        ox, oy, oz = o.results.x, o.results.y, o.results.z
+        np.testing.assert_allclose(x[i].cpu().numpy(), ox, atol=1e-8)
+        np.testing.assert_allclose(lam[i].cpu().numpy(), oy, atol=1e-7)
+        np.testing.assert_allclose(nu[i].cpu().numpy(), oz, atol=1e-7)
+    # un-batched parameters are broadcast (utils.py expandParam): shared Q, batched p
+    x2, _, _ = QPFunction(eps=1e-9)(Q[0], p, A[0], b[0], G[0], l[0], u[0])
+    np.testing.assert_allclose(x2[0].cpu().numpy(), x[0].cpu().numpy(), atol=1e-9)
+    # closest-feasible variant returns 5 tensors with double-sided multipliers
+    out = QPFunction(eps=1e-9, structural_feasibility=False)(Q, p, A, b, G, l, u)
+    assert len(out) == 5 and out[2].shape == (B, ni) and out[4].shape == (B, ni)
+    np.testing.assert_allclose(out[0].cpu().numpy(), x.cpu().numpy(), atol=1e-6)

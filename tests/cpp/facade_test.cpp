@@ -1,0 +1,196 @@
+// Exercises the C++17 facade (include/proxsuite/...) the way the reference's own programs do:
+// benchmark/timings-parallel.cpp:178-220 (BatchQP + solve_in_parallel), test/src/
+// dense_qp_wrapper.cpp (init / update / warm start), test/src/parallel_qp_solve.cpp:33-76
+// (parallel == serial), test/src/dense_qp_solve.cpp (one-shot solve).  Linked against
+// libproxqp_hip.so on the GPU box and against the SIMT-emulator build of the same device
+// sources (tests/emu/libpqp_emu.so) in the CPU test-suite.  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include <proxsuite/proxqp/dense/dense.hpp>
+#include <proxsuite/proxqp/parallel/qp_solve.hpp>
+#include <proxsuite/proxqp/utils/random_qp_problems.hpp>
+
+using namespace proxsuite::proxqp;
+using T = double;
+
+static int failures = 0;
+#define CHECK(cond)                                                                                  \
+  do {                                                                                               \
+    if (!(cond)) {                                                                                   \
+      std::printf("CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond);                            \
+      ++failures;                                                                                    \
+    }                                                                                                \
+  } while (0)
+
+// unscaled residuals, as every reference test computes them (dense_qp_with_eq_and_in.cpp:46-56)
+static void
+residuals(const dense::Model<T>& m, const Results<T>& r, T& pri, T& dua)
+{
+  pri = 0;
+  dua = 0;
+  for (isize i = 0; i < m.n_eq; ++i) {
+    T s = -m.b[i];
+    for (isize j = 0; j < m.dim; ++j)
+      s += m.A(i, j) * r.x[j];
+    pri = std::max(pri, std::fabs(s));
+  }
+  for (isize i = 0; i < m.n_in; ++i) {
+    T s = 0;
+    for (isize j = 0; j < m.dim; ++j)
+      s += m.C(i, j) * r.x[j];
+    pri = std::max(pri, std::max(T(0), s - m.u[i]) + std::max(T(0), m.l[i] - s));
+  }
+  for (isize j = 0; j < m.dim; ++j) {
+    T s = m.g[j];
+    for (isize k = 0; k < m.dim; ++k)
+      s += m.H(j, k) * r.x[k];
+    for (isize i = 0; i < m.n_eq; ++i)
+      s += m.A(i, j) * r.y[i];
+    for (isize i = 0; i < m.n_in; ++i)
+      s += m.C(i, j) * r.z[i];
+    dua = std::max(dua, std::fabs(s));
+  }
+}
+
+int
+main(int argc, char** argv)
+{
+  const isize dim = 10, n_eq = 3, n_in = 4;
+  const int num_qps = argc > 1 ? std::atoi(argv[1]) : 6;
+  const T eps_abs = 1e-9, sparsity_factor = 0.15, strong_convexity_factor = 1e-2;
+
+  // --- timings-parallel.cpp:178-220: BatchQP, init in place, solve in parallel
+  dense::BatchQP<T> qps_vector = dense::BatchQP<T>(usize(num_qps));
+  std::vector<dense::Model<T>> models;
+  for (int i = 0; i < num_qps; i++) {
+    utils::rand::set_seed(uint64_t(i));
+    dense::Model<T> qp_random = utils::dense_strongly_convex_qp(dim, n_eq, n_in, sparsity_factor, strong_convexity_factor);
+    auto& qp = qps_vector.init_qp_in_place(dim, n_eq, n_in);
+    qp.settings.eps_abs = eps_abs;
+    qp.settings.eps_rel = 0;
+    qp.settings.initial_guess = InitialGuessStatus::NO_INITIAL_GUESS;
+    qp.init(qp_random.H, qp_random.g, qp_random.A, qp_random.b, qp_random.C, qp_random.l, qp_random.u);
+    CHECK(qp.results.info.status == QPSolverOutput::PROXQP_MAX_ITER_REACHED); // preset by setup (results.hpp:172)
+    models.push_back(qp_random);
+  }
+  CHECK(qps_vector.size() == num_qps);
+  dense::solve_in_parallel(qps_vector, 4);
+  for (int i = 0; i < num_qps; i++) {
+    T pri, dua;
+    residuals(models[usize(i)], qps_vector[i].results, pri, dua);
+    CHECK(qps_vector[i].results.info.status == QPSolverOutput::PROXQP_SOLVED);
+    CHECK(pri <= eps_abs);
+    CHECK(dua <= eps_abs);
+  }
+
+  // --- parallel_qp_solve.cpp:33-76: a std::vector of QPs solved one by one gives the same x
+  std::vector<dense::QP<T>> qps;
+  for (int i = 0; i < num_qps; i++) {
+    dense::QP<T> qp{ dim, n_eq, n_in };
+    qp.settings.eps_abs = eps_abs;
+    qp.settings.eps_rel = 0;
+    qp.settings.initial_guess = InitialGuessStatus::NO_INITIAL_GUESS;
+    const auto& m = models[usize(i)];
+    qp.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+    qps.push_back(std::move(qp));
+  }
+  dense::solve_in_parallel(qps);
+  for (int i = 0; i < num_qps; i++)
+    for (isize j = 0; j < dim; ++j)
+      CHECK(qps[usize(i)].results.x[j] == qps_vector[i].results.x[j]);
+
+  // --- dense_qp_wrapper.cpp style: update g, warm start with the previous result, then from (x,y,z)
+  {
+    dense::QP<T>& qp = qps[0];
+    dense::Model<T> m = models[0];
+    for (isize j = 0; j < dim; ++j)
+      m.g[j] *= 1.5;
+    qp.settings.initial_guess = InitialGuessStatus::WARM_START_WITH_PREVIOUS_RESULT;
+    qp.update(nullopt, m.g, nullopt, nullopt, nullopt, nullopt, nullopt);
+    qp.solve();
+    T pri, dua;
+    residuals(m, qp.results, pri, dua);
+    CHECK(pri <= eps_abs && dua <= eps_abs);
+    CHECK(qp.model.g[0] == m.g[0]);
+    Results<T> prev = qp.results;
+    qp.solve(prev.x, prev.y, prev.z);
+    CHECK(qp.settings.initial_guess == InitialGuessStatus::WARM_START); // helpers.hpp:727
+    CHECK(qp.results.info.iter <= 1);
+    // proximal parameters given at init (wrapper.hpp:354)
+    qp.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u, true, T(1e-7), T(1e-4), T(1e-2));
+    CHECK(qp.results.info.rho == 1e-7 && qp.results.info.mu_eq == 1e-4 && qp.results.info.mu_in == 1e-2);
+    qp.cleanup();
+    CHECK(qp.results.x[0] == 0);
+  }
+
+  // --- one-shot solve (dense_qp_solve.cpp)
+  {
+    const auto& m = models[1];
+    Results<T> r = dense::solve<T>(m.H, m.g, m.A, m.b, m.C, m.l, m.u, nullopt, nullopt, nullopt, eps_abs, T(0));
+    T pri, dua;
+    residuals(m, r, pri, dua);
+    CHECK(r.info.status == QPSolverOutput::PROXQP_SOLVED);
+    CHECK(pri <= eps_abs && dua <= eps_abs);
+  }
+
+  // --- box constraints: z = [z_in; z_box] (dense_qp_wrapper.cpp:6889-6900)
+  {
+    dense::QP<T> qp(dim, 0, n_in, true);
+    CHECK(qp.is_box_constrained());
+    const auto& m = models[2];
+    dense::Vec<T> lb(dim, -0.5), ub(dim, 0.5);
+    qp.settings.eps_abs = eps_abs;
+    qp.init(m.H, m.g, nullopt, nullopt, m.C, m.l, m.u, lb, ub);
+    qp.solve();
+    CHECK(qp.results.info.status == QPSolverOutput::PROXQP_SOLVED);
+    CHECK(qp.results.z.size() == n_in + dim);
+    for (isize j = 0; j < dim; ++j)
+      CHECK(qp.results.x[j] <= 0.5 + 1e-9 && qp.results.x[j] >= -0.5 - 1e-9);
+    bool threw = false;
+    try {
+      qp.init(m.H, m.g, nullopt, nullopt, m.C, m.l, m.u); // box QP without boxes (wrapper.hpp:367-372)
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
+  // --- argument errors are std::invalid_argument (wrapper.hpp:380-451, model.hpp:65-68)
+  {
+    bool threw = false;
+    try {
+      dense::QP<T> bad(0, 0, 0);
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    CHECK(threw);
+    threw = false;
+    dense::QP<T> qp(4, 1, 2);
+    dense::Mat<T> H3(3, 3);
+    dense::Vec<T> g4(4);
+    try {
+      qp.init(H3, g4, nullopt, nullopt, nullopt, nullopt, nullopt);
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
+  // --- strided (column-major) input is repacked: H^T of a symmetric H is H
+  {
+    const auto& m = models[3];
+    dense::QP<T> qp(dim, n_eq, n_in);
+    qp.settings.eps_abs = eps_abs;
+    dense::MatRef<T> Hcm(m.H.data(), dim, dim, 1, dim);
+    qp.init(Hcm, m.g, m.A, m.b, m.C, m.l, m.u);
+    qp.solve();
+    T pri, dua;
+    residuals(m, qp.results, pri, dua);
+    CHECK(pri <= eps_abs && dua <= eps_abs);
+  }
+
+  std::printf("facade_test: %d failure(s)\n", failures);
+  return failures == 0 ? 0 : 1;
+}

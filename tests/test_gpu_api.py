@@ -1,0 +1,46 @@
+"""`-m gpu`: the Python surface (proxsuite_amd.proxqp.dense, proxsuite_amd.torch) on the real
+MI355X library, same cases as tests/test_emu_api.py, plus ROCm-tensor inputs for the QPLayer."""
+import pytest
+
+import api_cases as ac
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dense():
+    from proxsuite_amd import _native as N
+    N.load()  # fails loudly if libproxqp_hip.so or the GPU is missing
+    from proxsuite_amd.proxqp import dense as d
+    return d
+
+
+def test_qp_object(dense, oracle, randqp):
+    ac.case_qp_object(dense, oracle, randqp)
+
+
+def test_errors(dense):
+    ac.case_errors(dense)
+
+
+def test_box(dense, oracle, randqp):
+    ac.case_box(dense, oracle, randqp)
+
+
+def test_batch_and_parallel(dense, oracle, randqp):
+    ac.case_batch_and_parallel(dense, oracle, randqp)
+
+
+def test_one_shot_solve(dense, oracle, randqp):
+    ac.case_one_shot_solve(dense, oracle, randqp)
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_qpfunction_forward(dense, oracle, randqp, device):
+    from proxsuite_amd.torch import QPFunction
+    ac.case_qpfunction(QPFunction, oracle, randqp, device=device)
+
+
+def test_omp_get_max_threads(dense):
+    from proxsuite_amd import proxqp
+    assert proxqp.omp_get_max_threads() >= 256
