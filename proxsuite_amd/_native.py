@@ -93,6 +93,13 @@ def load() -> NativeLib:
         if not p.exists():
             raise NativeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7, and whichever
+        # copy is loaded first serves every later library with that SONAME.  Loading torch's first
+        # keeps torch.cuda usable next to this library (the reverse order leaves torch without GPUs).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = NativeLib(p)
         if lib.L.pqp_device_count() <= 0:
             raise NativeError("no HIP device visible: proxsuite_amd runs on MI355X only (no CPU fallback)")
