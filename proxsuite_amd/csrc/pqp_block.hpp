@@ -585,6 +585,92 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top, PQP_LDS long long* prof = n
 }
 
 // ---------------------------------------------------------------------------
+// Register-resident LDL^T for m <= 16*MB, NT = 256 threads as a 16 x 16 grid.
+//
+// The HBM-resident ldlt_factor above pays an HBM round trip per 8-column chunk
+// and a barrier per column; at the sizes of the dual Schur block (m ~ 50..110)
+// that is ~100 dependent memory latencies per factorisation.  Here the lower
+// triangle lives in VGPRs for the whole factorisation: thread (ti, tj) owns
+// the element (16*bi + ti, 16*bj + tj) of every 16 x 16 block bi >= bj
+// (block-cyclic, MB*(MB+1)/2 doubles per thread), `load(i, j)` is called once
+// per element up front (all loads in flight together), and each of the m
+// right-looking column steps costs one barrier: the 16 threads that own
+// column k publish it through LDS, everybody applies the rank-1 update
+// a_ij -= a_ik a_jk / d_k to its own registers.  The block-column index kb is
+// unrolled so every register index is static.
+// Output: the upper mirror U[j][i] = l_ij (i > j) and U[j][j] = d_j in global
+// memory, d[] in LDS -- the layout ldlt_solve consumes.
+// `cbuf`: 2 * 16 * MB doubles of LDS (double-buffered column).
+// ---------------------------------------------------------------------------
+template<int NT, int MB, typename LoadFn>
+__device__ PQP_CALL void
+ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf)
+{
+  static_assert(NT == 256, "ldlt_factor_reg lays the workgroup out as 16 x 16 threads");
+  constexpr int NB = 16;
+  const int ti = threadIdx.x & (NB - 1), tj = threadIdx.x / NB;
+  const int mb = (m + NB - 1) / NB;
+  double a[MB * (MB + 1) / 2];
+#pragma unroll
+  for (int bi = 0; bi < MB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = bi * NB + ti, j = bj * NB + tj;
+      a[bi * (bi + 1) / 2 + bj] = (i < m && j <= i) ? load(i, j) : 0.0;
+    }
+  int par = 0;
+#pragma unroll
+  for (int kb = 0; kb < MB; ++kb) {
+    if (kb < mb) {
+      const int nk = (m - kb * NB < NB) ? (m - kb * NB) : NB;
+      for (int kk = 0; kk < nk; ++kk) {
+        const int k = kb * NB + kk;
+        lptr cb = cbuf + par * (MB * NB);
+        if (tj == kk) {
+#pragma unroll
+          for (int bi = kb; bi < MB; ++bi)
+            if (bi < mb)
+              cb[bi * NB + ti] = a[bi * (bi + 1) / 2 + kb];
+        }
+        __syncthreads();
+        const double dk = cb[k];
+        const double inv = 1.0 / dk;
+        double ci[MB], cj[MB];
+#pragma unroll
+        for (int b = kb; b < MB; ++b) {
+          ci[b] = (b < mb) ? cb[b * NB + ti] : 0.0;
+          cj[b] = (b < mb) ? cb[b * NB + tj] * inv : 0.0;
+        }
+#pragma unroll
+        for (int bi = kb; bi < MB; ++bi)
+#pragma unroll
+          for (int bj = kb; bj <= bi; ++bj)
+            if (bj > kb || tj > kk)
+              a[bi * (bi + 1) / 2 + bj] = fma(-ci[bi], cj[bj], a[bi * (bi + 1) / 2 + bj]);
+        if (tj == kk) {
+#pragma unroll
+          for (int bi = kb; bi < MB; ++bi)
+            if (bi * NB + ti > k)
+              a[bi * (bi + 1) / 2 + kb] = ci[bi] * inv;
+          if (ti == kk)
+            d[k] = dk;
+        }
+        par ^= 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int bi = 0; bi < MB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = bi * NB + ti, j = bj * NB + tj;
+      if (i < m && j <= i)
+        U[(long)j * ld + i] = a[bi * (bi + 1) / 2 + bj];
+    }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // Solve (L D L^T) x = v in place for an LDS vector v (length m <= NT) using the
 // upper-mirror factor of ldlt_factor<NT, false>.  Restates reference
 // include/proxsuite/linalg/dense/solve.hpp:15-26 (forward unit-lower sweep,

@@ -29,6 +29,7 @@
 namespace pqp {
 
 constexpr double MACHINE_EPS = 2.220446049250313e-16;
+constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * SCHUR_MB rows
 constexpr int VALIDATE_BATCH = 8; // constraint rows validated per pass over L^{-1} / Z
 
 struct Dims
@@ -1087,6 +1088,28 @@ struct Solver
     const int rr = r;
     cgptr G = P.G();
     gptr LS = P.LS();
+    if constexpr (NT == 256) {
+      if (rr <= 16 * SCHUR_MB) {
+        // register-resident path: gather + factor + write-back with no intermediate HBM traffic.
+        // G is symmetric; element (i, j) is read as G[cid_j][cid_i] so that the 16 lanes of a
+        // row group sweep ascending constraint ids (near-contiguous addresses).
+        const int ne = d.n_eq;
+        const double mu_eq = info.mu_eq, mu_in = info.mu_in;
+        auto load = [&](int i, int j) -> double {
+          const int ci = cid_of_slot(i), cj = cid_of_slot(j);
+          double v = G[(long)cj * nd + ci];
+          if (i == j)
+            v += (i < ne) ? mu_eq : mu_in;
+          return v;
+        };
+        ldlt_factor_reg<NT, SCHUR_MB>(load, LS, nd, rr, L.dS, L.top);
+        toc(ST_CYC_S_GATHER);
+        tic();
+        schur_dirty = false;
+        count(ST_N_SCHUR_FACT);
+        return;
+      }
+    }
     // gathered loads are batched 8 deep ahead of the stores (G and LS are distinct
     // buffers, but the compiler cannot know and would serialise load/store pairs)
     for (int base = 0; base < rr * rr; base += 8 * NT) {
