@@ -585,6 +585,21 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top, PQP_LDS long long* prof = n
 }
 
 // ---------------------------------------------------------------------------
+// FP64 matrix core: D(16x16) += A(16x4) * B(4x16), one wavefront, v_mfma_f64_16x16x4_f64.
+// Operand layout (lane l of 64): a = A[l & 15][l >> 4], b = B[l >> 4][l & 15];
+// result register r (0..3) of lane l = D[(l >> 4) + 4 r][l & 15].
+// The emulator build (tests/emu) supplies the same function from lane shuffles.
+// ---------------------------------------------------------------------------
+#ifndef PQP_EMULATED_MFMA
+typedef double pqp_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pqp_d4
+mfma_f64_16x16x4(double a, double b, pqp_d4 c)
+{
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+#endif
+
+// ---------------------------------------------------------------------------
 // Register-resident LDL^T for m <= 16*MB, NT = 256 threads as a 16 x 16 grid.
 //
 // The HBM-resident ldlt_factor above pays an HBM round trip per 8-column chunk
@@ -604,21 +619,53 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top, PQP_LDS long long* prof = n
 // ---------------------------------------------------------------------------
 template<int NT, int MB, typename LoadFn>
 __device__ PQP_CALL void
-ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf)
+ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf, PQP_LDS long long* prof = nullptr)
 {
+  long long t0 = 0;
+#define PQP_PROF(slot)                                                                            \
+  if (prof && threadIdx.x == 0) {                                                                  \
+    long long t1 = clock64();                                                                      \
+    prof[slot] += t1 - t0;                                                                         \
+    t0 = t1;                                                                                       \
+  }
+  if (prof && threadIdx.x == 0)
+    t0 = clock64();
   static_assert(NT == 256, "ldlt_factor_reg lays the workgroup out as 16 x 16 threads");
   constexpr int NB = 16;
   const int ti = threadIdx.x & (NB - 1), tj = threadIdx.x / NB;
   const int mb = (m + NB - 1) / NB;
   double a[MB * (MB + 1) / 2];
+  // every load is issued unconditionally on clamped indices and masked afterwards: a
+  // conditional load becomes a branch whose join waits for the data, which would turn the
+  // gather into MB*(MB+1)/2 dependent round trips
 #pragma unroll
   for (int bi = 0; bi < MB; ++bi)
 #pragma unroll
     for (int bj = 0; bj <= bi; ++bj) {
       const int i = bi * NB + ti, j = bj * NB + tj;
-      a[bi * (bi + 1) / 2 + bj] = (i < m && j <= i) ? load(i, j) : 0.0;
+      const int ic = (i < m) ? i : m - 1;
+      const int jc = (j < ic) ? j : ic;
+      a[bi * (bi + 1) / 2 + bj] = load(ic, jc);
+    }
+#pragma unroll
+  for (int bi = 0; bi < MB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = bi * NB + ti, j = bj * NB + tj;
+      if (!(i < m && j <= i))
+        a[bi * (bi + 1) / 2 + bj] = 0.0;
     }
   int par = 0;
+  if (prof) {
+    // drain the loads so that the gather is billed to slot 0
+    double sink = 0;
+#pragma unroll
+    for (int q = 0; q < MB * (MB + 1) / 2; ++q)
+      sink += a[q];
+    if (sink == 1.2345e300)
+      d[0] = sink;
+  }
+  PQP_PROF(0)
 #pragma unroll
   for (int kb = 0; kb < MB; ++kb) {
     if (kb < mb) {
@@ -643,10 +690,12 @@ ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf)
         }
 #pragma unroll
         for (int bi = kb; bi < MB; ++bi)
+          if (bi < mb) { // uniform: block rows past the matrix are skipped
 #pragma unroll
-          for (int bj = kb; bj <= bi; ++bj)
-            if (bj > kb || tj > kk)
-              a[bi * (bi + 1) / 2 + bj] = fma(-ci[bi], cj[bj], a[bi * (bi + 1) / 2 + bj]);
+            for (int bj = kb; bj <= bi; ++bj)
+              if (bj > kb || tj > kk)
+                a[bi * (bi + 1) / 2 + bj] = fma(-ci[bi], cj[bj], a[bi * (bi + 1) / 2 + bj]);
+          }
         if (tj == kk) {
 #pragma unroll
           for (int bi = kb; bi < MB; ++bi)
@@ -659,6 +708,7 @@ ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf)
       }
     }
   }
+  PQP_PROF(1)
 #pragma unroll
   for (int bi = 0; bi < MB; ++bi)
 #pragma unroll
@@ -668,6 +718,8 @@ ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf)
         U[(long)j * ld + i] = a[bi * (bi + 1) / 2 + bj];
     }
   __syncthreads();
+  PQP_PROF(3)
+#undef PQP_PROF
 }
 
 // ---------------------------------------------------------------------------

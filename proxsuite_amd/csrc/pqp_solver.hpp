@@ -808,6 +808,7 @@ struct Solver
   int n_c;       // active inequality count
   int r;         // n_eq + n_c : size of the dual block
   bool schur_dirty;
+  bool z_all_valid; // every row of Z and G is current (eager build_ZG): skip the lazy validation scan
   UD ruiz_c;
   UD dual_feasibility_rhs_2;
   bool nonfinite;
@@ -875,7 +876,11 @@ struct Solver
   __device__ __forceinline__ bool flag_low(int i) const { return (L.aflags[i] & 2) != 0; }
   __device__ __forceinline__ int cid_of_slot(int a) const
   {
-    return (a < d.n_eq) ? a : d.n_eq + L.act[a - d.n_eq];
+    // branch-free (the LDS read is unconditional on a clamped index) so that callers can batch
+    // the global loads that depend on it
+    const int k = a - d.n_eq;
+    const int v = L.act[k < 0 ? 0 : k];
+    return (k < 0) ? a : d.n_eq + v;
   }
   // plain mat-vec through the shared routine
   __device__ __forceinline__ void mv(cgptr M, int ld, int K, int J, clptr v, lptr out)
@@ -908,8 +913,166 @@ struct Solver
       __syncthreads();
     }
     vstore(P.dF(), L.dF, n);
-    for (int k = threadIdx.x; k < d.nd; k += NT)
-      L.zvalid[k] = 0;
+    build_ZG();
+  }
+
+  // Z = L^{-1} B^T for EVERY constraint row (B = [A_s; C_s; diag(i_scaled)]) in both
+  // orientations, and the full Gram matrix G = Z^T D^{-1} Z, right after the primal block is
+  // factorised.  Two small GEMMs on the FP64 matrix cores (16x16x4 tiles, one tile per
+  // wavefront at a time, operands loaded straight from L2/HBM in the MFMA lane layout):
+  //   Zc[k][c] = sum_j W[k][j] Bt[j][c]   and, from the SAME two operand registers with the
+  //   roles swapped, Zr[c][k] -- so both orientations are written with coalesced stores;
+  //   G[c][d]  = sum_k Zc[k][c] (1/D_k) Zc[k][d], lower tiles + their mirrors.
+  // This replaces the lazy row-by-row validation (validate_batch): ~5 MFLOP per QP at C2 done
+  // once as dense tiles instead of ~17 latency-bound passes over W and Z per solve.
+  __device__ __forceinline__ void build_ZG()
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in, nd = d.nd, nb = ne + ni;
+    constexpr int NWV = NT / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int lr = lane & 15, lk = lane >> 4;
+    gptr Zc = P.Zc(), Zr = P.Zr();
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.t1[k] = 1.0 / L.dF[k];
+    if (d.hessian == PQP_HESSIAN_DENSE) {
+      cgptr WU = P.WU(), ATs = P.ATs(), CTs = P.CTs();
+      const int KT = (n + 15) / 16, CT = (nb + 15) / 16;
+      for (int t = w; t < KT * CT; t += NWV) {
+        const int kt = t / CT, ct = t - kt * CT;
+        const int k0 = kt * 16, c0 = ct * 16;
+        const int k = k0 + lr, c = c0 + lr;
+        const bool k_ok = k < n, c_ok = c < nb, is_eq = c < ne;
+        const int kc = k_ok ? k : n - 1;
+        cgptr bbase = is_eq ? (ATs + c) : (CTs + (c_ok ? c - ne : 0));
+        const long bld = is_eq ? ne : ni;
+        pqp_d4 acc1 = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+        const int jend = (k0 + 16 < n) ? (k0 + 16) : n; // W[k][j] = 0 for j > k
+        for (int j0 = 0; j0 < jend; j0 += 16) {
+          double a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u + lk;
+            const int jc = (j < n) ? j : n - 1;
+            a[u] = WU[(long)jc * n + kc];
+            b[u] = bbase[(long)jc * bld];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u + lk;
+            const double av = (j < n && k_ok) ? a[u] : 0.0;
+            const double bv = (j < n && c_ok) ? b[u] : 0.0;
+            acc1 = mfma_f64_16x16x4(av, bv, acc1);
+            acc2 = mfma_f64_16x16x4(bv, av, acc2);
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int kr = k0 + lk + 4 * rr;
+          if (kr < n && c_ok)
+            Zc[(long)kr * nd + c] = acc1[rr];
+          const int cr = c0 + lk + 4 * rr;
+          if (cr < nb && k_ok)
+            Zr[(long)cr * n + k] = acc2[rr];
+        }
+      }
+      if (d.box) {
+        cgptr WL = P.WL();
+        for (int o = threadIdx.x; o < n * n; o += NT) {
+          const int a = o / n, bcol = o - a * n;
+          Zc[(long)a * nd + nb + bcol] = WL[o] * L.isc[bcol]; // Z[k=a][box bcol] = W[a][bcol] i_bcol
+          Zr[(long)(nb + a) * n + bcol] = WU[o] * L.isc[a];   // Zr[box a][k=bcol] = W[bcol][a] i_a
+        }
+      }
+    } else {
+      // diagonal / zero Hessian: L = I, Z = B^T
+      cgptr As = P.As(), Cs = P.Cs(), ATs = P.ATs(), CTs = P.CTs();
+      for (int o = threadIdx.x; o < nd * n; o += NT) {
+        const int c = o / n, k = o - c * n;
+        double v;
+        if (c < ne)
+          v = As[(long)c * n + k];
+        else if (c < nb)
+          v = Cs[(long)(c - ne) * n + k];
+        else
+          v = (k == c - nb) ? L.isc[k] : 0.0;
+        Zr[o] = v;
+      }
+      for (int o = threadIdx.x; o < n * nd; o += NT) {
+        const int k = o / nd, c = o - k * nd;
+        double v;
+        if (c < ne)
+          v = ATs[(long)k * ne + c];
+        else if (c < nb)
+          v = CTs[(long)k * ni + (c - ne)];
+        else
+          v = (k == c - nb) ? L.isc[k] : 0.0;
+        Zc[o] = v;
+      }
+    }
+    __syncthreads();
+    {
+      gptr G = P.G();
+      cgptr Zcc = P.Zc();
+      const int DT = (nd + 15) / 16;
+      for (int t = w; t < DT * (DT + 1) / 2; t += NWV) {
+        int ct = 0, rem = t;
+        while (rem > ct) {
+          rem -= ct + 1;
+          ++ct;
+        }
+        const int dt = rem;
+        const int c0 = ct * 16, d0 = dt * 16;
+        const int c = c0 + lr, dc = d0 + lr;
+        const bool c_ok = c < nd, d_ok = dc < nd;
+        const int cc = c_ok ? c : nd - 1, dcc = d_ok ? dc : nd - 1;
+        pqp_d4 acc1 = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+        for (int k0 = 0; k0 < n; k0 += 16) {
+          double za[4], zb[4], sv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + lk;
+            const int kc = (k < n) ? k : n - 1;
+            za[u] = Zcc[(long)kc * nd + cc];
+            zb[u] = Zcc[(long)kc * nd + dcc];
+            sv[u] = L.t1[kc];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + lk;
+            const double av = (k < n && c_ok) ? za[u] * sv[u] : 0.0;
+            const double bv = (k < n && d_ok) ? zb[u] : 0.0;
+            acc1 = mfma_f64_16x16x4(av, bv, acc1);
+            if (ct != dt)
+              acc2 = mfma_f64_16x16x4(bv, av, acc2);
+          }
+        }
+        if (ct != dt) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int cr = c0 + lk + 4 * rr;
+            if (cr < nd && d_ok)
+              G[(long)cr * nd + dc] = acc1[rr];
+            const int dr = d0 + lk + 4 * rr;
+            if (dr < nd && c_ok)
+              G[(long)dr * nd + c] = acc2[rr];
+          }
+        } else {
+          // diagonal tile: keep G exactly symmetric (lower part + its mirror)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int cr = c0 + lk + 4 * rr;
+            if (cr < nd && d_ok && cr >= dc) {
+              G[(long)cr * nd + dc] = acc1[rr];
+              G[(long)dc * nd + cr] = acc1[rr];
+            }
+          }
+        }
+      }
+    }
+    for (int k = threadIdx.x; k < nd; k += NT)
+      L.zvalid[k] = 1;
+    z_all_valid = true;
+    count(ST_N_NEW_ROWS, nd);
     __syncthreads();
   }
 
@@ -1089,7 +1252,7 @@ struct Solver
     cgptr G = P.G();
     gptr LS = P.LS();
     if constexpr (NT == 256) {
-      if (rr <= 16 * SCHUR_MB) {
+      if (rr > 0 && rr <= 16 * SCHUR_MB) {
         // register-resident path: gather + factor + write-back with no intermediate HBM traffic.
         // G is symmetric; element (i, j) is read as G[cid_j][cid_i] so that the 16 lanes of a
         // row group sweep ascending constraint ids (near-contiguous addresses).
@@ -1097,12 +1260,10 @@ struct Solver
         const double mu_eq = info.mu_eq, mu_in = info.mu_in;
         auto load = [&](int i, int j) -> double {
           const int ci = cid_of_slot(i), cj = cid_of_slot(j);
-          double v = G[(long)cj * nd + ci];
-          if (i == j)
-            v += (i < ne) ? mu_eq : mu_in;
-          return v;
+          const double v = G[(long)cj * nd + ci];
+          return v + ((i == j) ? ((i < ne) ? mu_eq : mu_in) : 0.0);
         };
-        ldlt_factor_reg<NT, SCHUR_MB>(load, LS, nd, rr, L.dS, L.top);
+        ldlt_factor_reg<NT, SCHUR_MB>(load, LS, nd, rr, L.dS, L.top, L.stat + ST_CYC_F_LOAD);
         toc(ST_CYC_S_GATHER);
         tic();
         schur_dirty = false;
@@ -1310,7 +1471,7 @@ struct Solver
     r = ne + n_c;
     if (ch != 0.0)
       schur_dirty = true;
-    {
+    if (!z_all_valid) {
       // rows entering the factorisation for the first time, VALIDATE_BATCH at a time
       const int cap = (d.n + d.n_eq + d.nc + 2 * (d.n + d.nd) + d.nd + 4 * d.n + d.n_eq + d.nc) / d.n;
       const int mb = cap < VALIDATE_BATCH ? (cap < 1 ? 1 : cap) : VALIDATE_BATCH;
@@ -2004,6 +2165,7 @@ struct Solver
     }
     for (int k = threadIdx.x; k < d.nd; k += NT)
       L.zvalid[k] = 0;
+    z_all_valid = false;
     __syncthreads();
 
     // --- what this call has to do (solver.hpp:1125-1376), decided once so that the
@@ -2094,8 +2256,13 @@ struct Solver
       vload(L.dS, P.dS(), d.nd);
       {
         const PQP_GLOBAL int* zv = P.zvalid();
-        for (int k = threadIdx.x; k < d.nd; k += NT)
+        double miss = 0.0;
+        for (int k = threadIdx.x; k < d.nd; k += NT) {
           L.zvalid[k] = zv[k];
+          if (!zv[k])
+            miss = 1.0;
+        }
+        z_all_valid = (R.max(miss) == 0.0);
       }
       n_c = W.n_c;
       r = ne + n_c;

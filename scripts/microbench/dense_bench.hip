@@ -20,6 +20,20 @@ __global__ __launch_bounds__(256, 4) void k_factor(double* Ms, const double* src
     ldlt_factor<256, false>(M, ld, m, s, s + 1024);
   }
 }
+__global__ __launch_bounds__(256, 4) void k_factor_reg(double* Ms, const double* src, int ld, int m, int reps, long long* cyc) {
+  HIP_DYNAMIC_SHARED(double, smem)
+  lptr s = (lptr)smem;
+  gptr M = (gptr)(Ms + (long)blockIdx.x * ld * ld);
+  cgptr S = (cgptr)(src + (long)blockIdx.x * ld * ld);
+  PQP_LDS long long* prof = (PQP_LDS long long*)(s + 2048);
+  if (threadIdx.x < 8) prof[threadIdx.x] = 0;
+  __syncthreads();
+  for (int r = 0; r < reps; ++r) {
+    auto load = [&](int i, int j) -> double { return S[(long)j * ld + i]; };
+    ldlt_factor_reg<256, 7>(load, M, ld, m, s, s + 1024, prof);
+  }
+  if (threadIdx.x < 4) cyc[blockIdx.x * 4 + threadIdx.x] = prof[threadIdx.x];
+}
 __global__ __launch_bounds__(256, 4) void k_copy(double* Ms, const double* src, int ld, int m, int reps) {
   gptr M = (gptr)(Ms + (long)blockIdx.x * ld * ld);
   cgptr S = (cgptr)(src + (long)blockIdx.x * ld * ld);
@@ -79,6 +93,16 @@ int main() {
     hipEventRecord(e0); hipLaunchKernelGGL(k_factor, dim3(B), dim3(256), lds, 0, M, src, ld, m, reps); hipEventRecord(e1);
     CHECK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
     printf("factor m=%3d: %.3f ms per pass of %d matrices (copy-in alone %.3f) -> %.1f us per 1024-wide round\n", m, ms / reps, B, copy_ms / reps, 1e3 * (ms - copy_ms) / reps / 2);
+    if (m <= 112) {
+      long long* cyc; CHECK(hipMalloc(&cyc, B * 4 * 8));
+      hipLaunchKernelGGL(k_factor_reg, dim3(B), dim3(256), lds, 0, M, src, ld, m, reps, cyc);
+      hipEventRecord(e0); hipLaunchKernelGGL(k_factor_reg, dim3(B), dim3(256), lds, 0, M, src, ld, m, reps, cyc); hipEventRecord(e1);
+      CHECK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+      std::vector<long long> hc(B * 4); CHECK(hipMemcpy(hc.data(), cyc, B * 4 * 8, hipMemcpyDeviceToHost));
+      double c0 = 0, c1 = 0, c3 = 0; for (int b = 0; b < B; ++b) { c0 += hc[b * 4]; c1 += hc[b * 4 + 1]; c3 += hc[b * 4 + 3]; }
+      printf("factor_reg m=%3d: %.3f ms per pass -> %.1f us per round; cycles per call: load %.0f loop %.0f (%.0f/col) writeback %.0f\n", m, ms / reps, 1e3 * ms / reps / 2, c0 / B / reps, c1 / B / reps, c1 / B / reps / m, c3 / B / reps);
+      hipFree(cyc);
+    }
     hipEventRecord(e0); hipLaunchKernelGGL(k_solve, dim3(B), dim3(256), lds, 0, M, ld, m, reps, out); hipEventRecord(e1);
     CHECK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
     printf("solve  m=%3d: %.3f ms per pass\n", m, ms / reps);
