@@ -615,8 +615,19 @@ mfma_f64_16x16x4(double a, double b, pqp_d4 c)
 // unrolled so every register index is static.
 // Output: the upper mirror U[j][i] = l_ij (i > j) and U[j][j] = d_j in global
 // memory, d[] in LDS -- the layout ldlt_solve consumes.
-// `cbuf`: 2 * 16 * MB doubles of LDS (double-buffered column).
+// `cbuf`: 4 * 16 * MB doubles of LDS (raw + scaled column, double-buffered).
 // ---------------------------------------------------------------------------
+// value of `v` in lane `src` (uniform) of the calling wavefront, through scalar registers
+#ifndef PQP_EMULATED_MFMA
+__device__ __forceinline__ double
+lane_bcast(double v, int src)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+#endif
+
 template<int NT, int MB, typename LoadFn>
 __device__ PQP_CALL void
 ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf, PQP_LDS long long* prof = nullptr)
@@ -672,37 +683,46 @@ ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf, PQP_LDS l
       const int nk = (m - kb * NB < NB) ? (m - kb * NB) : NB;
       for (int kk = 0; kk < nk; ++kk) {
         const int k = kb * NB + kk;
-        lptr cb = cbuf + par * (MB * NB);
+        lptr cb = cbuf + par * (2 * MB * NB);
+        // the pivot d_k sits in lane 16 (kk & 3) + kk of the wave that owns column k: a scalar
+        // read (every wave reads its own lane; only the owner wave uses the value)
+        const double dkw = lane_bcast(a[kb * (kb + 1) / 2 + kb], ((kk & 3) << 4) + kk);
         if (tj == kk) {
+          // owners publish the raw column (a_ik) and the scaled one (l_ik = a_ik / d_k): the
+          // other threads then need neither the division nor a multiply per element
+          const double inv = 1.0 / dkw;
 #pragma unroll
           for (int bi = kb; bi < MB; ++bi)
-            if (bi < mb)
-              cb[bi * NB + ti] = a[bi * (bi + 1) / 2 + kb];
+            if (bi < mb) {
+              const double raw = a[bi * (bi + 1) / 2 + kb];
+              const double scaled = raw * inv;
+              cb[bi * NB + ti] = raw;
+              cb[MB * NB + bi * NB + ti] = scaled;
+              if (bi * NB + ti > k)
+                a[bi * (bi + 1) / 2 + kb] = scaled;
+            }
+          if (ti == kk)
+            d[k] = dkw;
         }
         __syncthreads();
-        const double dk = cb[k];
-        const double inv = 1.0 / dk;
         double ci[MB], cj[MB];
 #pragma unroll
         for (int b = kb; b < MB; ++b) {
           ci[b] = (b < mb) ? cb[b * NB + ti] : 0.0;
-          cj[b] = (b < mb) ? cb[b * NB + tj] * inv : 0.0;
+          cj[b] = (b < mb) ? cb[MB * NB + b * NB + tj] : 0.0;
         }
 #pragma unroll
         for (int bi = kb; bi < MB; ++bi)
           if (bi < mb) { // uniform: block rows past the matrix are skipped
 #pragma unroll
-            for (int bj = kb; bj <= bi; ++bj)
-              if (bj > kb || tj > kk)
-                a[bi * (bi + 1) / 2 + bj] = fma(-ci[bi], cj[bj], a[bi * (bi + 1) / 2 + bj]);
+            for (int bj = kb + 1; bj <= bi; ++bj)
+              a[bi * (bi + 1) / 2 + bj] = fma(-ci[bi], cj[bj], a[bi * (bi + 1) / 2 + bj]);
           }
-        if (tj == kk) {
+        if (tj > kk) { // the rest of block column kb
 #pragma unroll
           for (int bi = kb; bi < MB; ++bi)
-            if (bi * NB + ti > k)
-              a[bi * (bi + 1) / 2 + kb] = ci[bi] * inv;
-          if (ti == kk)
-            d[k] = dk;
+            if (bi < mb)
+              a[bi * (bi + 1) / 2 + kb] = fma(-ci[bi], cj[kb], a[bi * (bi + 1) / 2 + kb]);
         }
         par ^= 1;
       }

@@ -29,6 +29,7 @@
 namespace pqp {
 
 constexpr double MACHINE_EPS = 2.220446049250313e-16;
+constexpr int ZG_DEPTH = 8; // MFMA k-steps (of 4) whose operand loads are in flight together in build_ZG
 constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * SCHUR_MB rows
 constexpr int VALIDATE_BATCH = 8; // constraint rows validated per pass over L^{-1} / Z
 
@@ -947,17 +948,17 @@ struct Solver
         const long bld = is_eq ? ne : ni;
         pqp_d4 acc1 = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
         const int jend = (k0 + 16 < n) ? (k0 + 16) : n; // W[k][j] = 0 for j > k
-        for (int j0 = 0; j0 < jend; j0 += 16) {
-          double a[4], b[4];
+        for (int j0 = 0; j0 < jend; j0 += 4 * ZG_DEPTH) {
+          double a[ZG_DEPTH], b[ZG_DEPTH];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < ZG_DEPTH; ++u) {
             const int j = j0 + 4 * u + lk;
             const int jc = (j < n) ? j : n - 1;
             a[u] = WU[(long)jc * n + kc];
             b[u] = bbase[(long)jc * bld];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < ZG_DEPTH; ++u) {
             const int j = j0 + 4 * u + lk;
             const double av = (j < n && k_ok) ? a[u] : 0.0;
             const double bv = (j < n && c_ok) ? b[u] : 0.0;
@@ -1026,10 +1027,10 @@ struct Solver
         const bool c_ok = c < nd, d_ok = dc < nd;
         const int cc = c_ok ? c : nd - 1, dcc = d_ok ? dc : nd - 1;
         pqp_d4 acc1 = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
-        for (int k0 = 0; k0 < n; k0 += 16) {
-          double za[4], zb[4], sv[4];
+        for (int k0 = 0; k0 < n; k0 += 4 * ZG_DEPTH) {
+          double za[ZG_DEPTH], zb[ZG_DEPTH], sv[ZG_DEPTH];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < ZG_DEPTH; ++u) {
             const int k = k0 + 4 * u + lk;
             const int kc = (k < n) ? k : n - 1;
             za[u] = Zcc[(long)kc * nd + cc];
@@ -1037,7 +1038,7 @@ struct Solver
             sv[u] = L.t1[kc];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < ZG_DEPTH; ++u) {
             const int k = k0 + 4 * u + lk;
             const double av = (k < n && c_ok) ? za[u] * sv[u] : 0.0;
             const double bv = (k < n && d_ok) ? zb[u] : 0.0;

@@ -20,6 +20,11 @@ struct pqp_d4
   double& operator[](int i) { return v[i]; }
   const double& operator[](int i) const { return v[i]; }
 };
+inline double
+lane_bcast(double v, int src)
+{
+  return __shfl(v, src);
+}
 inline pqp_d4
 mfma_f64_16x16x4(double a, double b, pqp_d4 c)
 {
