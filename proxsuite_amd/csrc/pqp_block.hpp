@@ -907,6 +907,111 @@ tri_inverse(cgptr F, int ld, int n, gptr WL, gptr WU)
   }
 }
 
+// ---------------------------------------------------------------------------
+// tri_inverse on the FP64 matrix cores, n <= 16 * MB.  Same input (the FULL layout of
+// ldlt_factor: L in both mirrors, inv(L_bb) / inv(L_bb)^T in the diagonal blocks) and the same
+// output (WL = L^{-1}, WU = WL^T) as tri_inverse above.
+// Block forward substitution, one block COLUMN j of W per wavefront:
+//     W_jj = inv(L_jj),    W_ij = -inv(L_ii) * sum_{k=j}^{i-1} L_ik W_kj     (i > j)
+// Every product is a 16x16x16 tile product = 4 MFMAs.  The W_kj tiles of the column stay in
+// registers in the MFMA result layout, which IS the B-operand layout, so the chain over i has no
+// memory round trip through W; only L_ik and inv(L_ii) are loaded (coalesced, from the upper
+// mirror).  The transposed tile for WU comes from the same operand registers with the roles of
+// A and B swapped, so both outputs are written with coalesced stores.
+// ---------------------------------------------------------------------------
+template<int NT, int MB>
+__device__ PQP_CALL void
+tri_inverse_mfma(cgptr F, int ld, int n, gptr WL, gptr WU)
+{
+  constexpr int NB = 16;
+  constexpr int NWV = NT / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int nbk = (n + NB - 1) / NB;
+  for (int o = threadIdx.x; o < n * n; o += NT) {
+    int r = o / n, c = o - r * n;
+    double v = (r == c) ? 1.0 : 0.0;
+    WL[(long)r * ld + c] = v;
+    WU[(long)r * ld + c] = v;
+  }
+  __syncthreads();
+  for (int j = w; j < nbk; j += NWV) {
+    const int j0 = j * NB;
+    pqp_d4 Wt[MB];
+    {
+      // diagonal tile: strict lower of F's block = inv(L_jj), strict upper = its transpose
+      pqp_d4 tl = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = lk + 4 * q, col = lr;
+        const int gr = j0 + row, gc = j0 + col;
+        const int grc = (gr < n) ? gr : n - 1, gcc = (gc < n) ? gc : n - 1;
+        const double v = F[(long)grc * ld + gcc];
+        const bool in = gr < n && gc < n;
+        tl[q] = (row > col && in) ? v : ((row == col) ? 1.0 : 0.0);
+        if (in && row != col) {
+          if (row > col)
+            WL[(long)gr * ld + gc] = v;
+          else
+            WU[(long)gr * ld + gc] = v;
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < MB; ++kk)
+        if (kk == j)
+          Wt[kk] = tl;
+    }
+#pragma unroll
+    for (int i = 1; i < MB; ++i) {
+      if (i > j && i < nbk) {
+        const int i0 = i * NB;
+        const int ir = i0 + lr;
+        const int irc = (ir < n) ? ir : n - 1;
+        pqp_d4 T = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+          if (k >= j) {
+            double a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              a[q] = F[(long)(k * NB + 4 * q + lk) * ld + irc]; // L[i0+lr][k0+4q+lk] (upper mirror)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              T = mfma_f64_16x16x4((ir < n) ? a[q] : 0.0, Wt[k][q], T);
+          }
+        }
+        double iv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 4 * q + lk, r = lr; // inv(L_ii)[r][c], read from the transposed upper half
+          const int gc = i0 + c, gr = i0 + r;
+          const int gcc = (gc < n) ? gc : n - 1, grc = (gr < n) ? gr : n - 1;
+          const double v = F[(long)gcc * ld + grc];
+          iv[q] = (r > c && gc < n && gr < n) ? v : ((r == c) ? 1.0 : 0.0);
+        }
+        pqp_d4 Wij = { 0.0, 0.0, 0.0, 0.0 }, WijT = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Wij = mfma_f64_16x16x4(iv[q], T[q], Wij);   // inv(L_ii) * T
+          WijT = mfma_f64_16x16x4(T[q], iv[q], WijT); // T^T * inv(L_ii)^T
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Wij[q] = -Wij[q];
+          const int rowl = i0 + lk + 4 * q; // WL[i-block row][j-block col]
+          if (rowl < n)
+            WL[(long)rowl * ld + j0 + lr] = Wij[q];
+          const int rowu = j0 + lk + 4 * q; // WU[j-block row][i-block col]
+          if (ir < n)
+            WU[(long)rowu * ld + ir] = -WijT[q];
+        }
+        Wt[i] = Wij;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // exclusive prefix count of a per-thread flag over the block; returns this
 // thread's rank among the set flags and the total through `total`.
 // `cnt` is LDS scratch of NT/64 + 1 ints.

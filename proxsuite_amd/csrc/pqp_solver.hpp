@@ -905,7 +905,12 @@ struct Solver
       }
       __syncthreads();
       ldlt_factor<NT, true>(F, n, n, L.dF, L.top);
-      tri_inverse<NT>(F, n, n, P.WL(), P.WU());
+      toc(ST_CYC_F_PANEL); // (sub-phases of ST_CYC_FACTOR_H, which the caller bills in full)
+      if (n <= 16 * SCHUR_MB)
+        tri_inverse_mfma<NT, SCHUR_MB>(F, n, n, P.WL(), P.WU());
+      else
+        tri_inverse<NT>(F, n, n, P.WL(), P.WU());
+      toc(ST_CYC_F_TINV);
     } else {
       // diagonal / zero Hessian: L = I
       cgptr Hs = P.Hs();
@@ -2243,9 +2248,12 @@ struct Solver
     if (do_scale_ws)
       scale_warm_start();
     if (do_factor) {
+      long long t_fh = clock64();
       tic();
       factor_primal_block();
-      toc(ST_CYC_FACTOR_H);
+      if (threadIdx.x == 0)
+        L.stat[ST_CYC_FACTOR_H] += clock64() - t_fh;
+      tic();
       n_c = 0;
       r = ne;
       schur_dirty = true;
