@@ -908,6 +908,88 @@ tri_inverse(cgptr F, int ld, int n, gptr WL, gptr WU)
 }
 
 // ---------------------------------------------------------------------------
+// Inverses of the unit-lower diagonal blocks L_bb of an upper-mirror factor (the output of
+// ldlt_factor_reg), written back into the diagonal blocks in the FULL layout that tri_inverse
+// expects: strict lower = inv(L_bb), strict upper = inv(L_bb)^T, diagonal (d_j) untouched.
+// L_bb = I + N with N strictly lower, N^16 = 0, so
+//     inv(L_bb) = (I - N)(I + N^2)(I + N^4)(I + N^8)
+// exactly: six 16x16 products on the matrix cores per block, no substitution chain.  Every
+// matrix is carried as the pair (X, X^T) of tiles in the MFMA result layout, because a tile used
+// as the A operand stands for its transpose and as the B operand for itself.
+// One block per wavefront at a time.
+// ---------------------------------------------------------------------------
+struct TilePair
+{
+  pqp_d4 x, xt;
+};
+__device__ __forceinline__ TilePair
+tile_mul(const TilePair& a, const TilePair& b)
+{
+  // c = a * b : A operand = (tile a.xt), B operand = (tile b.x);  c^T = b^T a^T
+  TilePair c;
+  c.x = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+  c.xt = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    c.x = mfma_f64_16x16x4(a.xt[q], b.x[q], c.x);
+    c.xt = mfma_f64_16x16x4(b.x[q], a.xt[q], c.xt);
+  }
+  return c;
+}
+template<int NT>
+__device__ PQP_CALL void
+diag_block_inverses_mfma(gptr F, int ld, int n)
+{
+  constexpr int NB = 16;
+  constexpr int NWV = NT / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int nbk = (n + NB - 1) / NB;
+  for (int j = w; j < nbk; j += NWV) {
+    const int j0 = j * NB;
+    TilePair N, P;
+    bool diag[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = lk + 4 * q, col = lr;
+      const int gr = j0 + row, gc = j0 + col;
+      const int grc = (gr < n) ? gr : n - 1, gcc = (gc < n) ? gc : n - 1;
+      // upper mirror: U[c][r] = L[r][c] for r > c
+      const double up = F[(long)grc * ld + gcc];  // (row, col), meaningful for row < col: L[col][row]
+      const double lo = F[(long)gcc * ld + grc];  // (col, row): for row > col this is U[col][row] = L[row][col]
+      const bool in = gr < n && gc < n;
+      N.x[q] = (row > col && in) ? lo : 0.0;  // N[row][col]
+      N.xt[q] = (row < col && in) ? up : 0.0; // N^T[row][col] = N[col][row]
+      diag[q] = (row == col);
+      P.x[q] = (diag[q] ? 1.0 : 0.0) - N.x[q]; // I - N
+      P.xt[q] = (diag[q] ? 1.0 : 0.0) - N.xt[q];
+    }
+    TilePair S = tile_mul(N, N); // N^2
+#pragma unroll
+    for (int rep = 0; rep < 3; ++rep) {
+      TilePair T = S; // I + N^(2,4,8)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (diag[q]) {
+          T.x[q] += 1.0;
+          T.xt[q] += 1.0;
+        }
+      P = tile_mul(P, T);
+      if (rep < 2)
+        S = tile_mul(S, S);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = lk + 4 * q, col = lr;
+      const int gr = j0 + row, gc = j0 + col;
+      if (gr < n && gc < n && row != col)
+        F[(long)gr * ld + gc] = (row > col) ? P.x[q] : P.xt[q];
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // tri_inverse on the FP64 matrix cores, n <= 16 * MB.  Same input (the FULL layout of
 // ldlt_factor: L in both mirrors, inv(L_bb) / inv(L_bb)^T in the diagonal blocks) and the same
 // output (WL = L^{-1}, WU = WL^T) as tri_inverse above.

@@ -899,18 +899,34 @@ struct Solver
     if (d.hessian == PQP_HESSIAN_DENSE) {
       gptr F = P.F();
       cgptr Hs = P.Hs();
-      for (int o = threadIdx.x; o < n * n; o += NT) {
-        int rr = o / n, k = o - rr * n;
-        F[o] = Hs[o] + ((rr == k) ? rho : 0.0);
+      bool done = false;
+      if constexpr (NT == 256) {
+        if (n <= 16 * SCHUR_MB) {
+          // register-resident factorisation straight from H_s (upper triangle read), then the
+          // explicit inverse on the matrix cores
+          auto load = [&](int i, int j) -> double { return Hs[(long)j * n + i] + ((i == j) ? rho : 0.0); };
+          ldlt_factor_reg<NT, SCHUR_MB>(load, F, n, n, L.dF, L.top);
+          toc(ST_CYC_F_PANEL); // (sub-phases of ST_CYC_FACTOR_H, which the caller bills in full)
+          diag_block_inverses_mfma<NT>(F, n, n);
+          tri_inverse_mfma<NT, SCHUR_MB>(F, n, n, P.WL(), P.WU());
+          toc(ST_CYC_F_TINV);
+          done = true;
+        }
       }
-      __syncthreads();
-      ldlt_factor<NT, true>(F, n, n, L.dF, L.top);
-      toc(ST_CYC_F_PANEL); // (sub-phases of ST_CYC_FACTOR_H, which the caller bills in full)
-      if (n <= 16 * SCHUR_MB)
-        tri_inverse_mfma<NT, SCHUR_MB>(F, n, n, P.WL(), P.WU());
-      else
-        tri_inverse<NT>(F, n, n, P.WL(), P.WU());
-      toc(ST_CYC_F_TINV);
+      if (!done) {
+        for (int o = threadIdx.x; o < n * n; o += NT) {
+          int rr = o / n, k = o - rr * n;
+          F[o] = Hs[o] + ((rr == k) ? rho : 0.0);
+        }
+        __syncthreads();
+        ldlt_factor<NT, true>(F, n, n, L.dF, L.top);
+        toc(ST_CYC_F_PANEL);
+        if (n <= 16 * SCHUR_MB)
+          tri_inverse_mfma<NT, SCHUR_MB>(F, n, n, P.WL(), P.WU());
+        else
+          tri_inverse<NT>(F, n, n, P.WL(), P.WU());
+        toc(ST_CYC_F_TINV);
+      }
     } else {
       // diagonal / zero Hessian: L = I
       cgptr Hs = P.Hs();
