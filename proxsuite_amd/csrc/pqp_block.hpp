@@ -1094,6 +1094,305 @@ tri_inverse_mfma(cgptr F, int ld, int n, gptr WL, gptr WU)
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------
+// wave-level ordering point for wave-synchronous LDS exchange (one wavefront writes LDS and the
+// same wavefront reads other lanes' values): the hardware executes a wave's LDS operations in
+// order, so only the compiler has to be stopped from reordering; the emulator supplies a real
+// wave barrier.
+// ---------------------------------------------------------------------------
+#ifndef PQP_EMULATED_MFMA
+__device__ __forceinline__ void
+wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
+// ---------------------------------------------------------------------------
+// Blocked LDL^T on the FP64 matrix cores for any m <= NT, matrix in HBM / L2 (full symmetric
+// row-major input, leading dimension ld).  Same outputs as ldlt_factor<NT, FULL>:
+//   upper mirror  M[k][i] = L[i][k] (i > k),   M[j][j] = d_j,   d[] in LDS;
+//   FULL: lower mirror outside the diagonal blocks, diagonal blocks = inv(L_bb) / inv(L_bb)^T.
+// Left-looking over 16-column panels kb, three phases per panel, one barrier after each:
+//   P1  every wavefront: tiles U(kb, x), x >= kb, of the upper triangle get
+//         U(kb,x) -= sum_{p<kb} U(p,kb)^T D_p U(p,x)
+//       (4 MFMAs per (x, p); operands are rows of U, loaded coalesced in the MFMA layouts);
+//   P2  wavefront 0: the 16x16 diagonal tile is factorised with one ROW per lane, pivot rows
+//       travelling through scalar registers (v_readlane), no LDS traffic and no barrier inside;
+//       inv(L_11) from the Neumann product (diag_block_inverses_mfma's identity);
+//   P3  every wavefront: U(kb,x) <- D_1^{-1} inv(L_11) U(kb,x) for x > kb (4 MFMAs per tile),
+//       the transposed tile for the lower mirror from the swapped operands.
+// `top`: 2*256 + 32 doubles of LDS.
+// ---------------------------------------------------------------------------
+template<int NT, bool FULL>
+__device__ PQP_CALL void
+ldlt_factor_mfma(gptr M, int ld, int m, lptr d, lptr top)
+{
+  constexpr int NB = 16;
+  constexpr int NWV = NT / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int nbk = (m + NB - 1) / NB;
+  lptr tile = top;        // 16 x 16 diagonal tile, row-major
+  lptr mop = top + 256;   // TRSM operand in register order [q][lane]
+  lptr dinv = top + 512;  // 16 inverse pivots
+  for (int kb = 0; kb < nbk; ++kb) {
+    const int k0 = kb * NB;
+    // ---- P1: update block row kb of the upper triangle
+    for (int x = kb + w; x < nbk; x += NWV) {
+      const int x0 = x * NB;
+      const int xc = x0 + lr;
+      const int xcc = (xc < m) ? xc : m - 1;
+      const int kcol = k0 + lr;
+      const int kcc = (kcol < m) ? kcol : m - 1;
+      pqp_d4 acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = k0 + lk + 4 * q;
+        const int rowc = (row < m) ? row : m - 1;
+        const double v = M[(long)rowc * ld + xcc];
+        acc[q] = (row < m && xc < m) ? v : 0.0;
+      }
+      for (int p = 0; p < kb; p += 2) {
+        double ap[2][4], bp[2][4], dp[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int pr = ((p + h < kb) ? (p + h) : p) * NB + lk + 4 * q; // a full block: < m
+            ap[h][q] = M[(long)pr * ld + kcc];
+            bp[h][q] = M[(long)pr * ld + xcc];
+            dp[h][q] = d[pr];
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (p + h < kb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double av = (kcol < m) ? -ap[h][q] * dp[h][q] : 0.0;
+              const double bv = (xc < m) ? bp[h][q] : 0.0;
+              acc = mfma_f64_16x16x4(av, bv, acc);
+            }
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = k0 + lk + 4 * q;
+        if (row < m && xc < m)
+          M[(long)row * ld + xc] = acc[q];
+        if (x == kb)
+          tile[(lk + 4 * q) * NB + lr] = acc[q];
+      }
+    }
+    __syncthreads();
+    // ---- P2: wavefront 0 factorises the diagonal tile, one row per lane (lanes 0..15)
+    if (w == 0) {
+      const int nb = (m - k0 < NB) ? (m - k0) : NB;
+      const int r = lane & 15;
+      double a[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        const double v = tile[r * NB + c];
+        a[c] = (r < nb && c < nb) ? v : ((r == c) ? 1.0 : 0.0); // identity padding
+      }
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        const double dc = lane_bcast(a[c], c);
+        const double l = a[c] / dc;
+#pragma unroll
+        for (int cp = c + 1; cp < NB; ++cp) {
+          const double mcp = lane_bcast(a[c], cp); // A[cp][c] before scaling
+          if (r >= cp)
+            a[cp] = fma(-l, mcp, a[cp]);
+        }
+        if (r > c)
+          a[c] = l;
+      }
+      wave_sync();
+      if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          tile[r * NB + c] = (c < r) ? a[c] : 0.0; // strict lower N of L_11
+        double dr = 1.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c == r)
+            dr = a[c];
+        dinv[r] = 1.0 / dr;
+        if (r < nb)
+          d[k0 + r] = dr;
+      }
+      wave_sync();
+      TilePair N, Pm;
+      bool dg[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = lk + 4 * q, col = lr;
+        N.x[q] = (row > col) ? tile[row * NB + col] : 0.0;
+        N.xt[q] = (row < col) ? tile[col * NB + row] : 0.0;
+        dg[q] = (row == col);
+        Pm.x[q] = (dg[q] ? 1.0 : 0.0) - N.x[q];
+        Pm.xt[q] = (dg[q] ? 1.0 : 0.0) - N.xt[q];
+      }
+      TilePair S = tile_mul(N, N);
+#pragma unroll
+      for (int rep = 0; rep < 3; ++rep) {
+        TilePair T = S;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (dg[q]) {
+            T.x[q] += 1.0;
+            T.xt[q] += 1.0;
+          }
+        Pm = tile_mul(Pm, T);
+        if (rep < 2)
+          S = tile_mul(S, S);
+      }
+      const double dcol = dinv[lr];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // A operand of  D_1^{-1} inv(L_11)  =  registers of the tile  inv(L_11)^T D_1^{-1}
+        mop[q * WAVE + lane] = Pm.xt[q] * dcol;
+        const int row = lk + 4 * q, col = lr;
+        const int gr = k0 + row, gc = k0 + col;
+        if (gr < m && gc < m && row != col) {
+          if (FULL)
+            M[(long)gr * ld + gc] = (row > col) ? Pm.x[q] : Pm.xt[q];
+          else if (row < col)
+            M[(long)gr * ld + gc] = N.xt[q]; // L_11^T in the upper mirror
+        }
+        if (gr < m && row == col)
+          M[(long)gr * ld + gc] = d[gr];
+      }
+    }
+    __syncthreads();
+    // ---- P3: the panel to the right of the diagonal tile
+    for (int x = kb + 1 + w; x < nbk; x += NWV) {
+      const int x0 = x * NB;
+      const int xc = x0 + lr;
+      const int xcc = (xc < m) ? xc : m - 1;
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = mop[q * WAVE + lane];
+        b[q] = M[(long)(k0 + lk + 4 * q) * ld + xcc]; // k0 block is full here (x > kb exists)
+      }
+      pqp_d4 res = { 0.0, 0.0, 0.0, 0.0 }, resT = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double bv = (xc < m) ? b[q] : 0.0;
+        res = mfma_f64_16x16x4(a[q], bv, res);
+        if (FULL)
+          resT = mfma_f64_16x16x4(bv, a[q], resT);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (xc < m)
+          M[(long)(k0 + lk + 4 * q) * ld + xc] = res[q];
+        if (FULL) {
+          const int row = x0 + lk + 4 * q;
+          if (row < m)
+            M[(long)row * ld + k0 + lr] = resT[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tri_inverse on the matrix cores for any n (the register-resident variant above needs
+// n <= 16 * MB): block ROW i of W = L^{-1} at a time, its tiles spread over the wavefronts,
+//     W_ij = -inv(L_ii) * sum_{k=j}^{i-1} L_ik W_kj,
+// W_kj read back from WL (rows k < i are complete: one barrier per block row).
+// ---------------------------------------------------------------------------
+template<int NT>
+__device__ PQP_CALL void
+tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
+{
+  constexpr int NB = 16;
+  constexpr int NWV = NT / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int nbk = (n + NB - 1) / NB;
+  for (int o = threadIdx.x; o < n * n; o += NT) {
+    int r = o / n, c = o - r * n;
+    double v = (r == c) ? 1.0 : 0.0;
+    WL[(long)r * ld + c] = v;
+    WU[(long)r * ld + c] = v;
+  }
+  __syncthreads();
+  for (int j = w; j < nbk; j += NWV) {
+    const int j0 = j * NB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = lk + 4 * q, col = lr;
+      const int gr = j0 + row, gc = j0 + col;
+      if (gr < n && gc < n && row != col) {
+        const double v = F[(long)gr * ld + gc];
+        if (row > col)
+          WL[(long)gr * ld + gc] = v;
+        else
+          WU[(long)gr * ld + gc] = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = 1; i < nbk; ++i) {
+    const int i0 = i * NB;
+    const int ir = i0 + lr;
+    const int irc = (ir < n) ? ir : n - 1;
+    for (int j = w; j < i; j += NWV) {
+      const int j0 = j * NB;
+      pqp_d4 T = { 0.0, 0.0, 0.0, 0.0 };
+      for (int k = j; k < i; k += 2) {
+        double a[2][4], b[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kr = ((k + h < i) ? (k + h) : k) * NB + 4 * q + lk; // full block: < n
+            a[h][q] = F[(long)kr * ld + irc];       // L[i0+lr][kr]   (upper mirror)
+            b[h][q] = WL[(long)kr * ld + j0 + lr];  // W[kr][j0+lr]
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (k + h < i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              T = mfma_f64_16x16x4((ir < n) ? a[h][q] : 0.0, b[h][q], T);
+          }
+      }
+      double iv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * q + lk, r = lr;
+        const int gc = i0 + c, gr = i0 + r;
+        const int gcc = (gc < n) ? gc : n - 1, grc = (gr < n) ? gr : n - 1;
+        const double v = F[(long)gcc * ld + grc];
+        iv[q] = (r > c && gc < n && gr < n) ? v : ((r == c) ? 1.0 : 0.0);
+      }
+      pqp_d4 Wij = { 0.0, 0.0, 0.0, 0.0 }, WijT = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Wij = mfma_f64_16x16x4(iv[q], T[q], Wij);
+        WijT = mfma_f64_16x16x4(T[q], iv[q], WijT);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rowl = i0 + lk + 4 * q;
+        if (rowl < n)
+          WL[(long)rowl * ld + j0 + lr] = -Wij[q];
+        if (ir < n)
+          WU[(long)(j0 + lk + 4 * q) * ld + ir] = -WijT[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // exclusive prefix count of a per-thread flag over the block; returns this
 // thread's rank among the set flags and the total through `total`.
 // `cnt` is LDS scratch of NT/64 + 1 ints.

@@ -103,7 +103,7 @@ enum
   ST_CYC_F_TINV,
   ST_CYC_S_GATHER,
   ST_CYC_SOLVE_LDLT,
-  ST_SPARE,
+  ST_N_SCHUR_BLOCKED, // Schur factorisations that took the blocked (HBM-resident) MFMA path
   ST_COUNT
 };
 
@@ -919,12 +919,12 @@ struct Solver
           F[o] = Hs[o] + ((rr == k) ? rho : 0.0);
         }
         __syncthreads();
-        ldlt_factor<NT, true>(F, n, n, L.dF, L.top);
+        ldlt_factor_mfma<NT, true>(F, n, n, L.dF, L.top);
         toc(ST_CYC_F_PANEL);
         if (n <= 16 * SCHUR_MB)
           tri_inverse_mfma<NT, SCHUR_MB>(F, n, n, P.WL(), P.WU());
         else
-          tri_inverse<NT>(F, n, n, P.WL(), P.WU());
+          tri_inverse_mfma_rows<NT>(F, n, n, P.WL(), P.WU());
         toc(ST_CYC_F_TINV);
       }
     } else {
@@ -958,44 +958,68 @@ struct Solver
       L.t1[k] = 1.0 / L.dF[k];
     if (d.hessian == PQP_HESSIAN_DENSE) {
       cgptr WU = P.WU(), ATs = P.ATs(), CTs = P.CTs();
-      const int KT = (n + 15) / 16, CT = (nb + 15) / 16;
-      for (int t = w; t < KT * CT; t += NWV) {
-        const int kt = t / CT, ct = t - kt * CT;
-        const int k0 = kt * 16, c0 = ct * 16;
-        const int k = k0 + lr, c = c0 + lr;
-        const bool k_ok = k < n, c_ok = c < nb, is_eq = c < ne;
+      // work unit = one 16-row block of Z times TWO adjacent 16-column blocks: the W operand is
+      // loaded once for both, and every batch keeps 3 * ZG_DEPTH loads in flight per lane
+      const int KT = (n + 15) / 16, CT = (nb + 15) / 16, CP = (CT + 1) / 2;
+      for (int t = w; t < KT * CP; t += NWV) {
+        const int kt = t / CP, cp = t - kt * CP;
+        const int k0 = kt * 16;
+        const int k = k0 + lr;
+        const bool k_ok = k < n;
         const int kc = k_ok ? k : n - 1;
-        cgptr bbase = is_eq ? (ATs + c) : (CTs + (c_ok ? c - ne : 0));
-        const long bld = is_eq ? ne : ni;
-        pqp_d4 acc1 = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+        int c0[2], c[2];
+        bool c_ok[2];
+        cgptr bbase[2];
+        long bld[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          c0[h] = (2 * cp + h) * 16;
+          c[h] = c0[h] + lr;
+          c_ok[h] = c[h] < nb;
+          const bool is_eq = c[h] < ne;
+          bbase[h] = is_eq ? (ATs + c[h]) : (CTs + (c_ok[h] ? c[h] - ne : 0));
+          bld[h] = is_eq ? ne : ni;
+        }
+        pqp_d4 acc1[2], acc2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          acc1[h] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+          acc2[h] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+        }
         const int jend = (k0 + 16 < n) ? (k0 + 16) : n; // W[k][j] = 0 for j > k
         for (int j0 = 0; j0 < jend; j0 += 4 * ZG_DEPTH) {
-          double a[ZG_DEPTH], b[ZG_DEPTH];
+          double a[ZG_DEPTH], b0[ZG_DEPTH], b1[ZG_DEPTH];
 #pragma unroll
           for (int u = 0; u < ZG_DEPTH; ++u) {
             const int j = j0 + 4 * u + lk;
             const int jc = (j < n) ? j : n - 1;
             a[u] = WU[(long)jc * n + kc];
-            b[u] = bbase[(long)jc * bld];
+            b0[u] = bbase[0][(long)jc * bld[0]];
+            b1[u] = bbase[1][(long)jc * bld[1]];
           }
 #pragma unroll
           for (int u = 0; u < ZG_DEPTH; ++u) {
             const int j = j0 + 4 * u + lk;
             const double av = (j < n && k_ok) ? a[u] : 0.0;
-            const double bv = (j < n && c_ok) ? b[u] : 0.0;
-            acc1 = mfma_f64_16x16x4(av, bv, acc1);
-            acc2 = mfma_f64_16x16x4(bv, av, acc2);
+            const double bv0 = (j < n && c_ok[0]) ? b0[u] : 0.0;
+            const double bv1 = (j < n && c_ok[1]) ? b1[u] : 0.0;
+            acc1[0] = mfma_f64_16x16x4(av, bv0, acc1[0]);
+            acc2[0] = mfma_f64_16x16x4(bv0, av, acc2[0]);
+            acc1[1] = mfma_f64_16x16x4(av, bv1, acc1[1]);
+            acc2[1] = mfma_f64_16x16x4(bv1, av, acc2[1]);
           }
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int kr = k0 + lk + 4 * rr;
-          if (kr < n && c_ok)
-            Zc[(long)kr * nd + c] = acc1[rr];
-          const int cr = c0 + lk + 4 * rr;
-          if (cr < nb && k_ok)
-            Zr[(long)cr * n + k] = acc2[rr];
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int kr = k0 + lk + 4 * rr;
+            if (kr < n && c_ok[h])
+              Zc[(long)kr * nd + c[h]] = acc1[h][rr];
+            const int cr = c0[h] + lk + 4 * rr;
+            if (cr < nb && k_ok)
+              Zr[(long)cr * n + k] = acc2[h][rr];
+          }
       }
       if (d.box) {
         cgptr WL = P.WL();
@@ -1035,57 +1059,85 @@ struct Solver
     {
       gptr G = P.G();
       cgptr Zcc = P.Zc();
+      // work unit = block row ct of G times TWO adjacent block columns dt, dt+1 <= ct (lower
+      // tiles; each off-diagonal tile also yields its mirror from the swapped operands)
       const int DT = (nd + 15) / 16;
-      for (int t = w; t < DT * (DT + 1) / 2; t += NWV) {
+      int units = 0;
+      for (int ct = 0; ct < DT; ++ct)
+        units += ct / 2 + 1;
+      for (int t = w; t < units; t += NWV) {
         int ct = 0, rem = t;
-        while (rem > ct) {
-          rem -= ct + 1;
+        while (rem >= ct / 2 + 1) {
+          rem -= ct / 2 + 1;
           ++ct;
         }
-        const int dt = rem;
-        const int c0 = ct * 16, d0 = dt * 16;
-        const int c = c0 + lr, dc = d0 + lr;
-        const bool c_ok = c < nd, d_ok = dc < nd;
-        const int cc = c_ok ? c : nd - 1, dcc = d_ok ? dc : nd - 1;
-        pqp_d4 acc1 = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+        const int c0 = ct * 16;
+        const int c = c0 + lr;
+        const bool c_ok = c < nd;
+        const int cc = c_ok ? c : nd - 1;
+        int dts[2], d0[2], dcol[2], dcc[2];
+        bool d_ok[2], live[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          dts[h] = 2 * rem + h;
+          live[h] = dts[h] <= ct; // the second tile of the last pair may not exist
+          d0[h] = dts[h] * 16;
+          dcol[h] = d0[h] + lr;
+          d_ok[h] = live[h] && dcol[h] < nd;
+          dcc[h] = d_ok[h] ? dcol[h] : nd - 1;
+        }
+        pqp_d4 acc1[2], acc2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          acc1[h] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+          acc2[h] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+        }
         for (int k0 = 0; k0 < n; k0 += 4 * ZG_DEPTH) {
-          double za[ZG_DEPTH], zb[ZG_DEPTH], sv[ZG_DEPTH];
+          double za[ZG_DEPTH], zb0[ZG_DEPTH], zb1[ZG_DEPTH], sv[ZG_DEPTH];
 #pragma unroll
           for (int u = 0; u < ZG_DEPTH; ++u) {
             const int k = k0 + 4 * u + lk;
             const int kc = (k < n) ? k : n - 1;
             za[u] = Zcc[(long)kc * nd + cc];
-            zb[u] = Zcc[(long)kc * nd + dcc];
+            zb0[u] = Zcc[(long)kc * nd + dcc[0]];
+            zb1[u] = Zcc[(long)kc * nd + dcc[1]];
             sv[u] = L.t1[kc];
           }
 #pragma unroll
           for (int u = 0; u < ZG_DEPTH; ++u) {
             const int k = k0 + 4 * u + lk;
             const double av = (k < n && c_ok) ? za[u] * sv[u] : 0.0;
-            const double bv = (k < n && d_ok) ? zb[u] : 0.0;
-            acc1 = mfma_f64_16x16x4(av, bv, acc1);
-            if (ct != dt)
-              acc2 = mfma_f64_16x16x4(bv, av, acc2);
+            const double bv0 = (k < n && d_ok[0]) ? zb0[u] : 0.0;
+            const double bv1 = (k < n && d_ok[1]) ? zb1[u] : 0.0;
+            acc1[0] = mfma_f64_16x16x4(av, bv0, acc1[0]);
+            acc2[0] = mfma_f64_16x16x4(bv0, av, acc2[0]);
+            acc1[1] = mfma_f64_16x16x4(av, bv1, acc1[1]);
+            acc2[1] = mfma_f64_16x16x4(bv1, av, acc2[1]);
           }
         }
-        if (ct != dt) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int cr = c0 + lk + 4 * rr;
-            if (cr < nd && d_ok)
-              G[(long)cr * nd + dc] = acc1[rr];
-            const int dr = d0 + lk + 4 * rr;
-            if (dr < nd && c_ok)
-              G[(long)dr * nd + c] = acc2[rr];
-          }
-        } else {
-          // diagonal tile: keep G exactly symmetric (lower part + its mirror)
+        for (int h = 0; h < 2; ++h) {
+          if (!live[h])
+            continue;
+          if (dts[h] != ct) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int cr = c0 + lk + 4 * rr;
-            if (cr < nd && d_ok && cr >= dc) {
-              G[(long)cr * nd + dc] = acc1[rr];
-              G[(long)dc * nd + cr] = acc1[rr];
+            for (int rr = 0; rr < 4; ++rr) {
+              const int cr = c0 + lk + 4 * rr;
+              if (cr < nd && d_ok[h])
+                G[(long)cr * nd + dcol[h]] = acc1[h][rr];
+              const int dr = d0[h] + lk + 4 * rr;
+              if (dr < nd && c_ok)
+                G[(long)dr * nd + c] = acc2[h][rr];
+            }
+          } else {
+            // diagonal tile: keep G exactly symmetric (lower part + its mirror)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int cr = c0 + lk + 4 * rr;
+              if (cr < nd && d_ok[h] && cr >= dcol[h]) {
+                G[(long)cr * nd + dcol[h]] = acc1[h][rr];
+                G[(long)dcol[h] * nd + cr] = acc1[h][rr];
+              }
             }
           }
         }
@@ -1319,7 +1371,12 @@ struct Solver
     }
     __syncthreads();
     toc(ST_CYC_S_GATHER);
-    ldlt_factor<NT, false>(LS, nd, rr, L.dS, L.top, L.stat + ST_CYC_F_LOAD);
+    if constexpr (NT == 256)
+      ldlt_factor<NT, false>(LS, nd, rr, L.dS, L.top);
+    else
+      ldlt_factor_mfma<NT, false>(LS, nd, rr, L.dS, L.top);
+    toc(ST_CYC_F_UPDATE);
+    count(ST_N_SCHUR_BLOCKED);
     tic();
     schur_dirty = false;
     count(ST_N_SCHUR_FACT);

@@ -20,6 +20,11 @@ struct pqp_d4
   double& operator[](int i) { return v[i]; }
   const double& operator[](int i) const { return v[i]; }
 };
+inline void
+wave_sync()
+{
+  hipemu::wave_barrier();
+}
 inline double
 lane_bcast(double v, int src)
 {

@@ -39,6 +39,16 @@ def test_random_batch(lib, oracle, randqp, shape):
     pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=8 if n < 100 else 4)
 
 
+@pytest.mark.parametrize("shape", [(120, 100, 100), (40, 5, 300), (130, 10, 20)])
+def test_matrix_core_fallback_paths(lib, oracle, randqp, shape):
+    """shapes that leave the register-resident factorisations: a dual Schur block above 112 rows
+    (256 threads), a 512-thread workgroup, and a primal block above 112 columns -- the blocked
+    LDL^T and the row-wise triangular inverse on the matrix cores (ldlt_factor_mfma,
+    tri_inverse_mfma_rows)."""
+    n, ne, ni = shape
+    pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=2)
+
+
 @pytest.mark.parametrize("guess", list(InitialGuess))
 def test_state_machine(lib, oracle, randqp, guess):
     pc.case_state_machine(lib, oracle, randqp, guess)

@@ -41,6 +41,14 @@ def test_random_batch(lib, oracle, randqp, shape):
     pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=B)
 
 
+@pytest.mark.parametrize("shape", [(120, 100, 100, 8), (40, 5, 300, 8), (130, 10, 20, 8), (300, 40, 120, 4)])
+def test_matrix_core_fallback_paths(lib, oracle, randqp, shape):
+    """shapes beyond the register-resident factorisations (ldlt_factor_mfma, tri_inverse_mfma_rows):
+    Schur block > 112 rows, 512- and 1024-thread workgroups, primal block > 112 columns."""
+    n, ne, ni, B = shape
+    pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=B)
+
+
 def test_equality_constrained_initial_guess_batch(lib, oracle, randqp):
     pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=32,
                          guess=InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS)
