@@ -590,6 +590,11 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top, PQP_LDS long long* prof = n
 // result register r (0..3) of lane l = D[(l >> 4) + 4 r][l & 15].
 // The emulator build (tests/emu) supplies the same function from lane shuffles.
 // ---------------------------------------------------------------------------
+// an optimisation barrier on a wave-uniform integer held in scalar registers
+#ifndef PQP_OPAQUE_SCALAR
+#define PQP_OPAQUE_SCALAR(v) asm volatile("" : "+s"(v))
+#endif
+
 #ifndef PQP_EMULATED_MFMA
 typedef double pqp_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ pqp_d4

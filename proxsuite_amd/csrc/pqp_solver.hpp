@@ -264,8 +264,18 @@ struct QpRef
   __device__ __forceinline__ long ni() const { return b.d.n_in; }
   __device__ __forceinline__ long nc() const { return b.d.nc; }
   __device__ __forceinline__ long nd() const { return b.d.nd; }
+  // Every pointer is rebuilt from (base, q) where it is used: `lq()` hands out q through an
+  // opaque scalar move so that the compiler neither hoists the ~35 per-QP pointers out of the
+  // solver's loops nor keeps them alive across them (they would occupy ~70 SGPRs for the whole
+  // kernel and push the rest into spills).
+  __device__ __forceinline__ long lq() const
+  {
+    long v = q;
+    PQP_OPAQUE_SCALAR(v);
+    return v;
+  }
 #define PQP_PTR(name, stride) \
-  __device__ __forceinline__ gptr name() const { return (gptr)(b.name + q * (stride)); }
+  __device__ __forceinline__ gptr name() const { return (gptr)(b.name + lq() * (stride)); }
   PQP_PTR(H, n() * n())
   PQP_PTR(g, n())
   PQP_PTR(A, ne() * n())
