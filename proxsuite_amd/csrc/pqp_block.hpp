@@ -593,6 +593,7 @@ ldlt_factor(gptr M, int ld, int m, lptr d, lptr top, PQP_LDS long long* prof = n
 // an optimisation barrier on a wave-uniform integer held in scalar registers
 #ifndef PQP_OPAQUE_SCALAR
 #define PQP_OPAQUE_SCALAR(v) asm volatile("" : "+s"(v))
+#define PQP_OPAQUE_VECTOR(v) asm volatile("" : "+v"(v))
 #endif
 
 #ifndef PQP_EMULATED_MFMA

@@ -80,7 +80,7 @@ struct pqp_batch
   pqp::Batch dev{};
   int device = 0;
   int nt = 256;
-  int wps = 4; // register budget of the solve kernel: 512 / wps VGPRs (env PQP_WAVES_PER_SIMD)
+  int wps = 3; // register budget of the solve kernel: 512 / wps VGPRs (env PQP_WAVES_PER_SIMD); 3 = 168 VGPRs measured best at C2
   int backend = PQP_BACKEND_PRIMAL_DUAL_LDLT;
   size_t lds_solve = 0, lds_setup = 0;
   std::vector<pqp_settings> settings;

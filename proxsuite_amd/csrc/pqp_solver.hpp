@@ -137,22 +137,83 @@ struct Batch
   long long* stats; // ST_COUNT per QP
 };
 
-// LDS carve-up: typed 32-bit LDS pointers ---------------------------------------
+// LDS carve-up -------------------------------------------------------------------------
+// The ~45 per-QP vectors are grouped by length class (n, n_eq, n_c, n_in, n_d) so that every
+// LDS address is  base + (slot * class_length + class_offset)  : twelve scalars describe the
+// whole layout and each pointer is rebuilt where it is used (two scalar instructions behind an
+// optimisation barrier).  Holding 45 hoisted pointers instead overflowed the scalar register
+// file: a fifth of the kernel's instructions were v_readlane reloads of spilled scalars.
 struct Lds
 {
-  lptr x, y, z, xp, yp, zp;
-  lptr gs, bs, us, ls, ubs, lbs, isc;
-  lptr dx, dy, dz;
-  lptr rx, rd;
-  lptr ex, ed;
-  lptr sd;
-  lptr Hdx, Adx, Cdx, ATdy, CTdz, CTzin;
-  lptr dres, se, si, rup;
-  lptr dF, dS;
-  lptr t1, t2, zfull;
-  lptr part, red, top;
-  liptr slot_of, act, zvalid, aflags, icnt, vlist;
-  PQP_LDS long long* stat;
+  lptr base;
+  int n, ne, nc, ni, nd, tmax, nt;
+  int o_ne, o_nc, o_ni, o_nd, o_t2; // class offsets in doubles (class n starts at 0)
+  __device__ __forceinline__ lptr at(int off) const
+  {
+    // the barrier is on a VECTOR register: LDS addresses are vector operands anyway, and a
+    // vector constraint is legal whatever the compiler thinks of the value's uniformity
+    PQP_OPAQUE_VECTOR(off);
+    return base + off;
+  }
+#define PQP_LVEC(name, cls_off, len, slot) \
+  __device__ __forceinline__ lptr name() const { return at((cls_off) + (slot) * (len)); }
+  PQP_LVEC(x, 0, n, 0)
+  PQP_LVEC(xp, 0, n, 1)
+  PQP_LVEC(gs, 0, n, 2)
+  PQP_LVEC(ubs, 0, n, 3)
+  PQP_LVEC(lbs, 0, n, 4)
+  PQP_LVEC(isc, 0, n, 5)
+  PQP_LVEC(dx, 0, n, 6)
+  PQP_LVEC(rx, 0, n, 7)
+  PQP_LVEC(ex, 0, n, 8)
+  PQP_LVEC(Hdx, 0, n, 9)
+  PQP_LVEC(ATdy, 0, n, 10)
+  PQP_LVEC(CTdz, 0, n, 11)
+  PQP_LVEC(CTzin, 0, n, 12)
+  PQP_LVEC(dres, 0, n, 13)
+  PQP_LVEC(dF, 0, n, 14)
+  PQP_LVEC(t1, 0, n, 15)
+  PQP_LVEC(y, o_ne, ne, 0)
+  PQP_LVEC(yp, o_ne, ne, 1)
+  PQP_LVEC(bs, o_ne, ne, 2)
+  PQP_LVEC(dy, o_ne, ne, 3)
+  PQP_LVEC(Adx, o_ne, ne, 4)
+  PQP_LVEC(se, o_ne, ne, 5)
+  PQP_LVEC(z, o_nc, nc, 0)
+  PQP_LVEC(zp, o_nc, nc, 1)
+  PQP_LVEC(dz, o_nc, nc, 2)
+  PQP_LVEC(Cdx, o_nc, nc, 3)
+  PQP_LVEC(si, o_nc, nc, 4)
+  PQP_LVEC(rup, o_nc, nc, 5)
+  PQP_LVEC(zfull, o_nc, nc, 6)
+  PQP_LVEC(us, o_ni, ni, 0)
+  PQP_LVEC(ls, o_ni, ni, 1)
+  PQP_LVEC(rd, o_nd, nd, 0)
+  PQP_LVEC(ed, o_nd, nd, 1)
+  PQP_LVEC(sd, o_nd, nd, 2)
+  PQP_LVEC(dS, o_nd, nd, 3)
+#undef PQP_LVEC
+  __device__ __forceinline__ int part_len() const { return gemv_part_len(nt, tmax); }
+  __device__ __forceinline__ int red_len() const { return 2 * 4 * (nt / WAVE) + 8; }
+  __device__ __forceinline__ lptr t2() const { return at(o_t2); }
+  __device__ __forceinline__ lptr part() const { return at(o_t2 + tmax); }
+  __device__ __forceinline__ lptr red() const { return at(o_t2 + tmax + part_len()); }
+  __device__ __forceinline__ lptr top() const { return at(o_t2 + tmax + part_len() + red_len()); }
+  __device__ __forceinline__ PQP_LDS long long* stat() const
+  {
+    return (PQP_LDS long long*)at(o_t2 + tmax + part_len() + red_len() + 2 * PQP_NB * PQP_NB + 2 * PQP_NB);
+  }
+  __device__ __forceinline__ liptr ints(int off) const
+  {
+    liptr q = (liptr)(base + (o_t2 + tmax + part_len() + red_len() + 2 * PQP_NB * PQP_NB + 2 * PQP_NB + ST_COUNT));
+    PQP_OPAQUE_VECTOR(off);
+    return q + off;
+  }
+  __device__ __forceinline__ liptr slot_of() const { return ints(0); }
+  __device__ __forceinline__ liptr act() const { return ints(nc); }
+  __device__ __forceinline__ liptr zvalid() const { return ints(2 * nc); }
+  __device__ __forceinline__ liptr aflags() const { return ints(2 * nc + nd); }
+  __device__ __forceinline__ liptr icnt() const { return ints(3 * nc + nd); }
 };
 
 __host__ __device__ inline size_t
@@ -186,66 +247,21 @@ lds_bytes(const Dims& d, int nt)
 __device__ __forceinline__ void
 lds_carve(Lds& L, lptr base, const Dims& d, int nt)
 {
-  const int n = d.n, ne = d.n_eq, nc = d.nc, nd = d.nd, ni = d.n_in;
-  const int tmax = nd > n ? nd : n;
-  lptr p = base;
-  auto take = [&](int k) {
-    lptr r = p;
-    p += k;
-    return r;
-  };
-  L.x = take(n);
-  L.y = take(ne);
-  L.z = take(nc);
-  L.xp = take(n);
-  L.yp = take(ne);
-  L.zp = take(nc);
-  L.gs = take(n);
-  L.bs = take(ne);
-  L.us = take(ni);
-  L.ls = take(ni);
-  L.ubs = take(n);
-  L.lbs = take(n);
-  L.isc = take(n);
-  L.dx = take(n);
-  L.dy = take(ne);
-  L.dz = take(nc);
-  L.rx = take(n);
-  L.rd = take(nd);
-  L.ex = take(n);
-  L.ed = take(nd);
-  L.sd = take(nd);
-  L.Hdx = take(n);
-  L.Adx = take(ne);
-  L.Cdx = take(nc);
-  L.ATdy = take(n);
-  L.CTdz = take(n);
-  L.CTzin = take(n);
-  L.dres = take(n);
-  L.se = take(ne);
-  L.si = take(nc);
-  L.rup = take(nc);
-  L.dF = take(n);
-  L.dS = take(nd);
-  L.t1 = take(n);
-  L.t2 = take(tmax);
-  L.zfull = take(nc);
-  L.part = take(gemv_part_len(nt, tmax));
-  L.red = take(2 * 4 * (nt / WAVE) + 8);
-  L.top = take(2 * PQP_NB * PQP_NB + 2 * PQP_NB);
-  L.stat = (PQP_LDS long long*)take(ST_COUNT);
-  liptr q = (liptr)p;
-  L.slot_of = q;
-  q += nc;
-  L.act = q;
-  q += nc;
-  L.zvalid = q;
-  q += nd;
-  L.aflags = q;
-  q += nc;
-  L.icnt = q;
-  q += nt / WAVE + 2;
-  L.vlist = q;
+  // every member goes through v_readfirstlane HERE, with all lanes active, so that the offsets
+  // built from them later are scalar registers whatever the divergence at the point of use
+  L.base = base;
+  L.n = uni(d.n);
+  L.ne = uni(d.n_eq);
+  L.nc = uni(d.nc);
+  L.ni = uni(d.n_in);
+  L.nd = uni(d.nd);
+  L.tmax = uni(d.nd > d.n ? d.nd : d.n);
+  L.nt = nt;
+  L.o_ne = uni(16 * L.n);
+  L.o_nc = uni(L.o_ne + 6 * L.ne);
+  L.o_ni = uni(L.o_nc + 7 * L.nc);
+  L.o_nd = uni(L.o_ni + 2 * L.ni);
+  L.o_t2 = uni(L.o_nd + 4 * L.nd);
 }
 
 // Per-QP HBM pointers, recomputed from the kernel argument on demand (a few
@@ -834,7 +850,7 @@ struct Solver
     , st(b.settings[q_])
   {
     lds_carve(L, lds_base, d, NT);
-    R = Reducer<NT>(L.red);
+    R = Reducer<NT>(L.red());
     t_mark = 0;
     nonfinite = false;
     n_c = 0;
@@ -852,14 +868,14 @@ struct Solver
   {
     if (threadIdx.x == 0) {
       long long t = clock64();
-      L.stat[which] += t - t_mark;
+      L.stat()[which] += t - t_mark;
       t_mark = t;
     }
   }
   __device__ __forceinline__ void count(int which, long long v = 1)
   {
     if (threadIdx.x == 0)
-      L.stat[which] += v;
+      L.stat()[which] += v;
   }
 
   // ---- small helpers --------------------------------------------------------
@@ -883,20 +899,20 @@ struct Solver
     for (int k = threadIdx.x; k < len; k += NT)
       dst[k] = src[k];
   }
-  __device__ __forceinline__ bool flag_up(int i) const { return (L.aflags[i] & 1) != 0; }
-  __device__ __forceinline__ bool flag_low(int i) const { return (L.aflags[i] & 2) != 0; }
+  __device__ __forceinline__ bool flag_up(int i) const { return (L.aflags()[i] & 1) != 0; }
+  __device__ __forceinline__ bool flag_low(int i) const { return (L.aflags()[i] & 2) != 0; }
   __device__ __forceinline__ int cid_of_slot(int a) const
   {
     // branch-free (the LDS read is unconditional on a clamped index) so that callers can batch
     // the global loads that depend on it
     const int k = a - d.n_eq;
-    const int v = L.act[k < 0 ? 0 : k];
+    const int v = L.act()[k < 0 ? 0 : k];
     return (k < 0) ? a : d.n_eq + v;
   }
   // plain mat-vec through the shared routine
   __device__ __forceinline__ void mv(cgptr M, int ld, int K, int J, clptr v, lptr out)
   {
-    gemv<NT>(M, ld, K, J, v, out, L.part, nullptr, 0, nullptr, 0);
+    gemv<NT>(M, ld, K, J, v, out, L.part(), nullptr, 0, nullptr, 0);
   }
 
   // ---- primal block ---------------------------------------------------------
@@ -915,7 +931,7 @@ struct Solver
           // register-resident factorisation straight from H_s (upper triangle read), then the
           // explicit inverse on the matrix cores
           auto load = [&](int i, int j) -> double { return Hs[(long)j * n + i] + ((i == j) ? rho : 0.0); };
-          ldlt_factor_reg<NT, SCHUR_MB>(load, F, n, n, L.dF, L.top);
+          ldlt_factor_reg<NT, SCHUR_MB>(load, F, n, n, L.dF(), L.top());
           toc(ST_CYC_F_PANEL); // (sub-phases of ST_CYC_FACTOR_H, which the caller bills in full)
           diag_block_inverses_mfma<NT>(F, n, n);
           tri_inverse_mfma<NT, SCHUR_MB>(F, n, n, P.WL(), P.WU());
@@ -929,7 +945,7 @@ struct Solver
           F[o] = Hs[o] + ((rr == k) ? rho : 0.0);
         }
         __syncthreads();
-        ldlt_factor_mfma<NT, true>(F, n, n, L.dF, L.top);
+        ldlt_factor_mfma<NT, true>(F, n, n, L.dF(), L.top());
         toc(ST_CYC_F_PANEL);
         if (n <= 16 * SCHUR_MB)
           tri_inverse_mfma<NT, SCHUR_MB>(F, n, n, P.WL(), P.WU());
@@ -941,10 +957,10 @@ struct Solver
       // diagonal / zero Hessian: L = I
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.dF[k] = ((d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] : 0.0) + rho;
+        L.dF()[k] = ((d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] : 0.0) + rho;
       __syncthreads();
     }
-    vstore(P.dF(), L.dF, n);
+    vstore(P.dF(), L.dF(), n);
     build_ZG();
   }
 
@@ -965,7 +981,7 @@ struct Solver
     const int lr = lane & 15, lk = lane >> 4;
     gptr Zc = P.Zc(), Zr = P.Zr();
     for (int k = threadIdx.x; k < n; k += NT)
-      L.t1[k] = 1.0 / L.dF[k];
+      L.t1()[k] = 1.0 / L.dF()[k];
     if (d.hessian == PQP_HESSIAN_DENSE) {
       cgptr WU = P.WU(), ATs = P.ATs(), CTs = P.CTs();
       // work unit = one 16-row block of Z times TWO adjacent 16-column blocks: the W operand is
@@ -1035,8 +1051,8 @@ struct Solver
         cgptr WL = P.WL();
         for (int o = threadIdx.x; o < n * n; o += NT) {
           const int a = o / n, bcol = o - a * n;
-          Zc[(long)a * nd + nb + bcol] = WL[o] * L.isc[bcol]; // Z[k=a][box bcol] = W[a][bcol] i_bcol
-          Zr[(long)(nb + a) * n + bcol] = WU[o] * L.isc[a];   // Zr[box a][k=bcol] = W[bcol][a] i_a
+          Zc[(long)a * nd + nb + bcol] = WL[o] * L.isc()[bcol]; // Z[k=a][box bcol] = W[a][bcol] i_bcol
+          Zr[(long)(nb + a) * n + bcol] = WU[o] * L.isc()[a];   // Zr[box a][k=bcol] = W[bcol][a] i_a
         }
       }
     } else {
@@ -1050,7 +1066,7 @@ struct Solver
         else if (c < nb)
           v = Cs[(long)(c - ne) * n + k];
         else
-          v = (k == c - nb) ? L.isc[k] : 0.0;
+          v = (k == c - nb) ? L.isc()[k] : 0.0;
         Zr[o] = v;
       }
       for (int o = threadIdx.x; o < n * nd; o += NT) {
@@ -1061,7 +1077,7 @@ struct Solver
         else if (c < nb)
           v = CTs[(long)k * ni + (c - ne)];
         else
-          v = (k == c - nb) ? L.isc[k] : 0.0;
+          v = (k == c - nb) ? L.isc()[k] : 0.0;
         Zc[o] = v;
       }
     }
@@ -1111,7 +1127,7 @@ struct Solver
             za[u] = Zcc[(long)kc * nd + cc];
             zb0[u] = Zcc[(long)kc * nd + dcc[0]];
             zb1[u] = Zcc[(long)kc * nd + dcc[1]];
-            sv[u] = L.t1[kc];
+            sv[u] = L.t1()[kc];
           }
 #pragma unroll
           for (int u = 0; u < ZG_DEPTH; ++u) {
@@ -1154,7 +1170,7 @@ struct Solver
       }
     }
     for (int k = threadIdx.x; k < nd; k += NT)
-      L.zvalid[k] = 1;
+      L.zvalid()[k] = 1;
     z_all_valid = true;
     count(ST_N_NEW_ROWS, nd);
     __syncthreads();
@@ -1169,163 +1185,6 @@ struct Solver
       vcopy(out, v, d.n);
       __syncthreads();
     }
-  }
-
-  // Validate m <= VALIDATE_BATCH constraints (ids in L.vlist) in ONE pass over L^{-1}
-  // and ONE pass over Z:  z_cid = L^{-1} b_cid  (rows of Zr / columns of Zc) and the
-  // Gram rows G[cid][*] = z_cid^T D^{-1} z_* against every validated constraint.
-  // Scratch: the m x n tile T lives in the LDS vectors dx..CTzin, which are dead while
-  // the active set is being installed.
-  __device__ __forceinline__ void validate_batch(int m)
-  {
-    const int n = d.n, nd = d.nd, ne = d.n_eq, ni = d.n_in;
-    lptr T = L.dx;
-    {
-      cgptr As = P.As(), Cs = P.Cs();
-      for (int o = threadIdx.x; o < m * n; o += NT) {
-        int j = o / n, k = o - j * n;
-        int cid = L.vlist[j];
-        double v;
-        if (cid < ne)
-          v = As[(long)cid * n + k];
-        else if (cid < ne + ni)
-          v = Cs[(long)(cid - ne) * n + k];
-        else
-          v = (k == cid - ne - ni) ? L.isc[k] : 0.0;
-        T[o] = v;
-      }
-    }
-    __syncthreads();
-    double acc[VALIDATE_BATCH];
-#pragma unroll
-    for (int j = 0; j < VALIDATE_BATCH; ++j)
-      acc[j] = 0.0;
-    const int k = threadIdx.x;
-    if (k < n) {
-      if (d.hessian == PQP_HESSIAN_DENSE) {
-        cgptr WU = P.WU() + k;
-        int i = 0;
-        for (; i + 7 < n; i += 8) {
-          double w[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            w[u] = WU[(long)(i + u) * n];
-#pragma unroll
-          for (int j = 0; j < VALIDATE_BATCH; ++j)
-            if (j < m) {
-              clptr t = T + j * n + i;
-#pragma unroll
-              for (int u = 0; u < 8; ++u)
-                acc[j] = fma(w[u], t[u], acc[j]);
-            }
-        }
-        for (; i + 3 < n; i += 4) {
-          double w0 = WU[(long)i * n], w1 = WU[(long)(i + 1) * n];
-          double w2 = WU[(long)(i + 2) * n], w3 = WU[(long)(i + 3) * n];
-#pragma unroll
-          for (int j = 0; j < VALIDATE_BATCH; ++j)
-            if (j < m) {
-              clptr t = T + j * n + i;
-              acc[j] = fma(w0, t[0], acc[j]);
-              acc[j] = fma(w1, t[1], acc[j]);
-              acc[j] = fma(w2, t[2], acc[j]);
-              acc[j] = fma(w3, t[3], acc[j]);
-            }
-        }
-        for (; i < n; ++i) {
-          double w0 = WU[(long)i * n];
-#pragma unroll
-          for (int j = 0; j < VALIDATE_BATCH; ++j)
-            if (j < m)
-              acc[j] = fma(w0, T[j * n + i], acc[j]);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < VALIDATE_BATCH; ++j)
-          if (j < m)
-            acc[j] = T[j * n + k];
-      }
-    }
-    __syncthreads();
-    if (k < n) {
-      gptr Zr = P.Zr(), Zc = P.Zc();
-      const double dinv = 1.0 / L.dF[k];
-#pragma unroll
-      for (int j = 0; j < VALIDATE_BATCH; ++j)
-        if (j < m) {
-          int cid = L.vlist[j];
-          Zr[(long)cid * n + k] = acc[j];
-          Zc[(long)k * nd + cid] = acc[j];
-          T[j * n + k] = acc[j] * dinv;
-        }
-    }
-    if (threadIdx.x < m)
-      L.zvalid[L.vlist[threadIdx.x]] = 1;
-    __syncthreads();
-    // Gram rows: thread c owns column c of Z
-    for (int c = threadIdx.x; c < nd; c += NT) {
-#pragma unroll
-      for (int j = 0; j < VALIDATE_BATCH; ++j)
-        acc[j] = 0.0;
-      cgptr Zc = P.Zc() + c;
-      int kk = 0;
-      for (; kk + 7 < n; kk += 8) {
-        double zz[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          zz[u] = Zc[(long)(kk + u) * nd];
-#pragma unroll
-        for (int j = 0; j < VALIDATE_BATCH; ++j)
-          if (j < m) {
-            clptr t = T + j * n + kk;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-              acc[j] = fma(zz[u], t[u], acc[j]);
-          }
-      }
-      for (; kk + 3 < n; kk += 4) {
-        double z0 = Zc[(long)kk * nd], z1 = Zc[(long)(kk + 1) * nd];
-        double z2 = Zc[(long)(kk + 2) * nd], z3 = Zc[(long)(kk + 3) * nd];
-#pragma unroll
-        for (int j = 0; j < VALIDATE_BATCH; ++j)
-          if (j < m) {
-            clptr t = T + j * n + kk;
-            acc[j] = fma(z0, t[0], acc[j]);
-            acc[j] = fma(z1, t[1], acc[j]);
-            acc[j] = fma(z2, t[2], acc[j]);
-            acc[j] = fma(z3, t[3], acc[j]);
-          }
-      }
-      for (; kk < n; ++kk) {
-        double z0 = Zc[(long)kk * nd];
-#pragma unroll
-        for (int j = 0; j < VALIDATE_BATCH; ++j)
-          if (j < m)
-            acc[j] = fma(z0, T[j * n + kk], acc[j]);
-      }
-      if (L.zvalid[c]) {
-        gptr G = P.G();
-        // a pair of rows validated in the same pass is produced by two threads (c = cid_a
-        // for row b and c = cid_b for row a) with different rounding: one writer per pair
-        // keeps G exactly symmetric and the run bit-reproducible
-        bool c_in_batch = false;
-#pragma unroll
-        for (int j = 0; j < VALIDATE_BATCH; ++j)
-          if (j < m && L.vlist[j] == c)
-            c_in_batch = true;
-#pragma unroll
-        for (int j = 0; j < VALIDATE_BATCH; ++j)
-          if (j < m) {
-            int cid = L.vlist[j];
-            if (c_in_batch && c < cid)
-              continue;
-            G[(long)cid * nd + c] = acc[j];
-            G[(long)c * nd + cid] = acc[j];
-          }
-      }
-    }
-    __syncthreads();
-    count(ST_N_NEW_ROWS, m);
   }
 
   // ---- dual Schur block: gather M_J + G_JJ in slot order and factorise it -----
@@ -1347,7 +1206,7 @@ struct Solver
           const double v = G[(long)cj * nd + ci];
           return v + ((i == j) ? ((i < ne) ? mu_eq : mu_in) : 0.0);
         };
-        ldlt_factor_reg<NT, SCHUR_MB>(load, LS, nd, rr, L.dS, L.top, L.stat + ST_CYC_F_LOAD);
+        ldlt_factor_reg<NT, SCHUR_MB>(load, LS, nd, rr, L.dS(), L.top(), L.stat() + ST_CYC_F_LOAD);
         toc(ST_CYC_S_GATHER);
         tic();
         schur_dirty = false;
@@ -1382,9 +1241,9 @@ struct Solver
     __syncthreads();
     toc(ST_CYC_S_GATHER);
     if constexpr (NT == 256)
-      ldlt_factor<NT, false>(LS, nd, rr, L.dS, L.top);
+      ldlt_factor<NT, false>(LS, nd, rr, L.dS(), L.top());
     else
-      ldlt_factor_mfma<NT, false>(LS, nd, rr, L.dS, L.top);
+      ldlt_factor_mfma<NT, false>(LS, nd, rr, L.dS(), L.top());
     toc(ST_CYC_F_UPDATE);
     count(ST_N_SCHUR_BLOCKED);
     tic();
@@ -1398,79 +1257,79 @@ struct Solver
   {
     const int n = d.n, nd = d.nd;
     const int rr = r;
-    apply_Linv(bx, L.t1, false); // t = L^{-1} bx
+    apply_Linv(bx, L.t1(), false); // t = L^{-1} bx
     for (int k = threadIdx.x; k < n; k += NT)
-      L.t2[k] = L.t1[k] / L.dF[k];
+      L.t2()[k] = L.t1()[k] / L.dF()[k];
     __syncthreads();
     if (rr > 0) {
       // s_a = z_a . (t / D) - bd_a     (gather of the active columns of Zc)
-      gemv<NT>(P.Zc(), nd, n, rr, L.t2, L.t2, L.part, nullptr, 0, L.act, d.n_eq);
+      gemv<NT>(P.Zc(), nd, n, rr, L.t2(), L.t2(), L.part(), nullptr, 0, L.act(), d.n_eq);
       for (int a = threadIdx.x; a < rr; a += NT)
-        bd[a] = L.t2[a] - bd[a];
+        bd[a] = L.t2()[a] - bd[a];
       __syncthreads();
       // (M + G) dvec = s
       toc(ST_CYC_KKT_SOLVE);
-      ldlt_solve<NT>(P.LS(), nd, rr, L.dS, bd, L.top);
+      ldlt_solve<NT>(P.LS(), nd, rr, L.dS(), bd, L.top());
       toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
-      gemv<NT>(P.Zr(), n, rr, n, bd, L.t2, L.part, L.act, d.n_eq, nullptr, 0);
+      gemv<NT>(P.Zr(), n, rr, n, bd, L.t2(), L.part(), L.act(), d.n_eq, nullptr, 0);
       for (int k = threadIdx.x; k < n; k += NT)
-        L.t1[k] = (L.t1[k] - L.t2[k]) / L.dF[k];
+        L.t1()[k] = (L.t1()[k] - L.t2()[k]) / L.dF()[k];
       __syncthreads();
     } else {
-      vcopy(L.t1, L.t2, n);
+      vcopy(L.t1(), L.t2(), n);
       __syncthreads();
     }
-    apply_Linv(L.t1, bx, true); // x = L^{-T} (.)
+    apply_Linv(L.t1(), bx, true); // x = L^{-T} (.)
     count(ST_N_KKT_SOLVES);
   }
 
-  // err = rhs - K * sol for sol = (L.dx, L.sd); by-products Hdx, Adx, ATdy, the
+  // err = rhs - K * sol for sol = (L.dx(), L.sd()); by-products Hdx, Adx, ATdy, the
   // ACTIVE part of C^T dz in CTdz and C dx for all rows in Cdx (solver.hpp:243-318)
   __device__ __forceinline__ void kkt_residual()
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
     const double rho = info.rho;
     for (int i = threadIdx.x; i < nc; i += NT) {
-      int s = L.slot_of[i];
-      L.zfull[i] = (s >= 0) ? L.sd[ne + s] : 0.0;
+      int s = L.slot_of()[i];
+      L.zfull()[i] = (s >= 0) ? L.sd()[ne + s] : 0.0;
     }
     __syncthreads();
     if (d.hessian == PQP_HESSIAN_DENSE) {
-      mv(P.Hs(), n, n, n, L.dx, L.Hdx);
+      mv(P.Hs(), n, n, n, L.dx(), L.Hdx());
     } else {
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.Hdx[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.dx[k] : 0.0;
+        L.Hdx()[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.dx()[k] : 0.0;
     }
     if (ne > 0) {
-      mv(P.As(), n, ne, n, L.sd, L.ATdy);
-      mv(P.ATs(), ne, n, ne, L.dx, L.Adx);
+      mv(P.As(), n, ne, n, L.sd(), L.ATdy());
+      mv(P.ATs(), ne, n, ne, L.dx(), L.Adx());
     } else {
-      vzero(L.ATdy, n);
+      vzero(L.ATdy(), n);
     }
     if (ni > 0) {
-      mv(P.Cs(), n, ni, n, L.zfull, L.CTdz);
-      mv(P.CTs(), ni, n, ni, L.dx, L.Cdx);
+      mv(P.Cs(), n, ni, n, L.zfull(), L.CTdz());
+      mv(P.CTs(), ni, n, ni, L.dx(), L.Cdx());
     } else {
-      vzero(L.CTdz, n);
+      vzero(L.CTdz(), n);
     }
     __syncthreads();
     if (d.box) {
       for (int k = threadIdx.x; k < n; k += NT) {
-        L.CTdz[k] += L.zfull[ni + k] * L.isc[k];
-        L.Cdx[ni + k] = L.dx[k] * L.isc[k];
+        L.CTdz()[k] += L.zfull()[ni + k] * L.isc()[k];
+        L.Cdx()[ni + k] = L.dx()[k] * L.isc()[k];
       }
       __syncthreads();
     }
     for (int k = threadIdx.x; k < n; k += NT)
-      L.ex[k] = L.rx[k] - rho * L.dx[k] - L.Hdx[k] - L.ATdy[k] - L.CTdz[k];
+      L.ex()[k] = L.rx()[k] - rho * L.dx()[k] - L.Hdx()[k] - L.ATdy()[k] - L.CTdz()[k];
     for (int k = threadIdx.x; k < ne; k += NT)
-      L.ed[k] = L.rd[k] - L.Adx[k] + L.sd[k] * info.mu_eq;
+      L.ed()[k] = L.rd()[k] - L.Adx()[k] + L.sd()[k] * info.mu_eq;
     for (int i = threadIdx.x; i < nc; i += NT) {
-      int s = L.slot_of[i];
+      int s = L.slot_of()[i];
       if (s >= 0)
-        L.ed[ne + s] = L.rd[ne + s] - (L.Cdx[i] - L.sd[ne + s] * info.mu_in);
+        L.ed()[ne + s] = L.rd()[ne + s] - (L.Cdx()[i] - L.sd()[ne + s] * info.mu_in);
     }
     __syncthreads();
   }
@@ -1479,33 +1338,33 @@ struct Solver
   {
     double m = 0;
     for (int k = threadIdx.x; k < d.n; k += NT)
-      m = fmax(m, fabs(L.ex[k]));
+      m = fmax(m, fabs(L.ex()[k]));
     for (int k = threadIdx.x; k < r; k += NT)
-      m = fmax(m, fabs(L.ed[k]));
+      m = fmax(m, fabs(L.ed()[k]));
     return R.max(m);
   }
 
   // reference solver.hpp:406-541: solve + iterative refinement on the unfactorised
   // operator.  The refactorisation fallback (:474-532) has nothing to rebuild here:
   // the Schur block is re-factorised from G on every change and never drifts.
-  // In: rhs in (L.rx, L.rd).  Out: solution in (L.dx, L.sd).
+  // In: rhs in (L.rx(), L.rd()).  Out: solution in (L.dx(), L.sd()).
   __device__ __forceinline__ void iterative_solve(double eps)
   {
     const int n = d.n;
-    vzero(L.dx, n);
-    vzero(L.sd, r);
-    vcopy(L.ex, L.rx, n);
-    vcopy(L.ed, L.rd, r);
+    vzero(L.dx(), n);
+    vzero(L.sd(), r);
+    vcopy(L.ex(), L.rx(), n);
+    vcopy(L.ed(), L.rd(), r);
     __syncthreads();
     long it = 0, it_stability = 0;
     UD preverr = 0, cur = 0;
     while (true) {
       tic();
-      kkt_solve_in_place(L.ex, L.ed);
+      kkt_solve_in_place(L.ex(), L.ed());
       for (int k = threadIdx.x; k < n; k += NT)
-        L.dx[k] += L.ex[k];
+        L.dx()[k] += L.ex()[k];
       for (int k = threadIdx.x; k < r; k += NT)
-        L.sd[k] += L.ed[k];
+        L.sd()[k] += L.ed()[k];
       __syncthreads();
       toc(ST_CYC_KKT_SOLVE);
       kkt_residual();
@@ -1541,17 +1400,17 @@ struct Solver
     int total = 0;
     for (int base = 0; base < nc; base += NT) {
       int i = base + threadIdx.x;
-      bool want = (i < nc) && ((L.aflags[i] & 4) != 0);
-      bool had = (i < nc) && (L.slot_of[i] >= 0);
+      bool want = (i < nc) && ((L.aflags()[i] & 4) != 0);
+      bool had = (i < nc) && (L.slot_of()[i] >= 0);
       if (want != had)
         changed_local = true;
       int tot;
-      int rank = block_rank<NT>(want, L.icnt, tot);
+      int rank = block_rank<NT>(want, L.icnt(), tot);
       if (want) {
-        L.slot_of[i] = total + rank;
-        L.act[total + rank] = i;
+        L.slot_of()[i] = total + rank;
+        L.act()[total + rank] = i;
       } else if (i < nc) {
-        L.slot_of[i] = -1;
+        L.slot_of()[i] = -1;
       }
       total += tot;
     }
@@ -1560,29 +1419,6 @@ struct Solver
     r = ne + n_c;
     if (ch != 0.0)
       schur_dirty = true;
-    if (!z_all_valid) {
-      // rows entering the factorisation for the first time, VALIDATE_BATCH at a time
-      const int cap = (d.n + d.n_eq + d.nc + 2 * (d.n + d.nd) + d.nd + 4 * d.n + d.n_eq + d.nc) / d.n;
-      const int mb = cap < VALIDATE_BATCH ? (cap < 1 ? 1 : cap) : VALIDATE_BATCH;
-      int m = 0;
-      for (int a = 0; a < r; ++a) {
-        int cid = cid_of_slot(a);
-        if (!L.zvalid[cid]) {
-          if (threadIdx.x == 0)
-            L.vlist[m] = cid;
-          ++m;
-          if (m == mb) {
-            __syncthreads();
-            validate_batch(m);
-            m = 0;
-          }
-        }
-      }
-      if (m > 0) {
-        __syncthreads();
-        validate_batch(m);
-      }
-    }
     toc(ST_CYC_ZG);
     if (schur_dirty && r > 0)
       factor_schur();
@@ -1596,28 +1432,28 @@ struct Solver
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     double m_eq0 = 0, m_in0 = 0, m_eql = 0, m_inl = 0;
     if (ne > 0)
-      mv(P.ATs(), ne, n, ne, L.x, L.se);
+      mv(P.ATs(), ne, n, ne, L.x(), L.se());
     if (ni > 0)
-      mv(P.CTs(), ni, n, ni, L.x, L.rup);
+      mv(P.CTs(), ni, n, ni, L.x(), L.rup());
     {
       cgptr de = P.dlt_eq();
       cgptr bb = P.bvec();
       for (int j = threadIdx.x; j < ne; j += NT) {
-        double v = L.se[j] / de[j]; // unscaled A x
+        double v = L.se()[j] / de[j]; // unscaled A x
         m_eq0 = fmax(m_eq0, fabs(v));
         v -= bb[j];
         m_eql = fmax(m_eql, fabs(v));
-        L.se[j] = v;
+        L.se()[j] = v;
       }
       cgptr di = P.dlt_in();
       cgptr uu = P.u(), ll = P.l();
       for (int j = threadIdx.x; j < ni; j += NT) {
-        double v = L.rup[j] / di[j]; // unscaled C x
-        L.rup[j] = v;
+        double v = L.rup()[j] / di[j]; // unscaled C x
+        L.rup()[j] = v;
         m_in0 = fmax(m_in0, fabs(v));
         double pu = v - uu[j], pl = v - ll[j];
         double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
-        L.si[j] = sv;
+        L.si()[j] = sv;
         m_inl = fmax(m_inl, fabs(sv));
       }
     }
@@ -1625,14 +1461,14 @@ struct Solver
       cgptr dx = P.dlt_x();
       cgptr ub = P.u_box(), lb = P.l_box();
       for (int k = threadIdx.x; k < n; k += NT) {
-        double v = L.x[k] * dx[k]; // unscaled x
-        L.rup[ni + k] = v;
+        double v = L.x()[k] * dx[k]; // unscaled x
+        L.rup()[ni + k] = v;
         double pu = v - ub[k], pl = v - lb[k];
         double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
-        L.si[ni + k] = sv;
+        L.si()[ni + k] = sv;
         m_inl = fmax(m_inl, fabs(sv));
-        m_in0 = fmax(m_in0, fabs(L.x[k] - sv)); // utils.hpp:225-229 (as written)
-        m_in0 = fmax(m_in0, fabs(L.x[k]));      // utils.hpp:230-231
+        m_in0 = fmax(m_in0, fabs(L.x()[k] - sv)); // utils.hpp:225-229 (as written)
+        m_in0 = fmax(m_in0, fabs(L.x()[k]));      // utils.hpp:230-231
       }
     }
     R.max3(m_eq0, m_in0, m_eql);
@@ -1644,22 +1480,22 @@ struct Solver
     if (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE) {
       // utils.hpp:241-248 : || A^T se + C^T si ||_inf on the unscaled model
       __syncthreads();
-      vzero(L.t1, n);
-      vzero(L.t2, n);
+      vzero(L.t1(), n);
+      vzero(L.t2(), n);
       __syncthreads();
       if (ne > 0)
-        mv(P.A(), n, ne, n, L.se, L.t1);
+        mv(P.A(), n, ne, n, L.se(), L.t1());
       if (ni > 0)
-        mv(P.C(), n, ni, n, L.si, L.t2);
+        mv(P.C(), n, ni, n, L.si(), L.t2());
       double m = 0;
       for (int k = threadIdx.x; k < n; k += NT)
-        m = fmax(m, fabs(L.t1[k] + L.t2[k]));
+        m = fmax(m, fabs(L.t1()[k] + L.t2()[k]));
       lhs = R.max(m);
     }
     {
       cgptr de = P.dlt_eq();
       for (int k = threadIdx.x; k < ne; k += NT)
-        L.se[k] *= de[k];
+        L.se()[k] *= de[k];
     }
     __syncthreads();
   }
@@ -1676,41 +1512,41 @@ struct Solver
     // H x -> t1, A^T y -> ATdy-free scratch (t2), C^T z -> CTzin-free... use t1/t2/zfull? keep
     // three distinct n-vectors: t1, t2 and ex (free outside the Newton loop)
     if (d.hessian == PQP_HESSIAN_DENSE) {
-      mv(P.Hs(), n, n, n, L.x, L.t1);
+      mv(P.Hs(), n, n, n, L.x(), L.t1());
     } else {
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.t1[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x[k] : 0.0;
+        L.t1()[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x()[k] : 0.0;
     }
     if (ne > 0)
-      mv(P.As(), n, ne, n, L.y, L.t2);
+      mv(P.As(), n, ne, n, L.y(), L.t2());
     else
-      vzero(L.t2, n);
+      vzero(L.t2(), n);
     if (ni > 0)
-      mv(P.Cs(), n, ni, n, L.z, L.ex);
+      mv(P.Cs(), n, ni, n, L.z(), L.ex());
     else
-      vzero(L.ex, n);
+      vzero(L.ex(), n);
     __syncthreads();
     {
       cgptr g = P.g();
       for (int k = threadIdx.x; k < n; k += NT) {
         const double sc = dx[k] * c;
-        double hx = L.t1[k], aty = L.t2[k], ctz = L.ex[k];
+        double hx = L.t1()[k], aty = L.t2()[k], ctz = L.ex()[k];
         double v = hx / sc; // unscaled H x (utils.hpp:469-471)
         m0 = fmax(m0, fabs(v));
-        double xu = L.x[k] * dx[k];
+        double xu = L.x()[k] * dx[k];
         xHx += v * xu;
         gx += g[k] * xu;
         m1 = fmax(m1, fabs(aty / sc));
         double m3k = fabs(ctz / sc);
         if (d.box) {
-          double zb = L.z[ni + k] * L.isc[k];
+          double zb = L.z()[ni + k] * L.isc()[k];
           ctz += zb;
           m3k = fmax(m3k, fabs(zb / sc));
         }
         m3 = fmax(m3, m3k);
-        double dr = L.gs[k] + hx + aty + ctz;
-        L.dres[k] = dr;
+        double dr = L.gs()[k] + hx + aty + ctz;
+        L.dres()[k] = dr;
         ml = fmax(ml, fabs(dr / sc));
       }
     }
@@ -1726,11 +1562,11 @@ struct Solver
       cgptr de = P.dlt_eq();
       cgptr bb = P.bvec();
       for (int k = threadIdx.x; k < ne; k += NT)
-        by += bb[k] * (L.y[k] * de[k] / c);
+        by += bb[k] * (L.y()[k] * de[k] / c);
       cgptr di = P.dlt_in();
       cgptr uu = P.u(), ll = P.l();
       for (int k = threadIdx.x; k < ni; k += NT) {
-        double zi = L.z[k] * di[k] / c;
+        double zi = L.z()[k] * di[k] / c;
         double uk = uu[k] < ib ? uu[k] : ib;
         double lk = ll[k] > -ib ? ll[k] : -ib;
         if (flag_up(k))
@@ -1742,7 +1578,7 @@ struct Solver
         cgptr db = P.dlt_box();
         cgptr ub = P.u_box(), lb = P.l_box();
         for (int k = threadIdx.x; k < n; k += NT) {
-          double zi = db[k] * L.z[ni + k] / c;
+          double zi = db[k] * L.z()[ni + k] / c;
           double uk = ub[k] < ib ? ub[k] : ib;
           double lk = lb[k] > -ib ? lb[k] : -ib;
           if (flag_up(ni + k))
@@ -1783,9 +1619,10 @@ struct Solver
     const int nc = d.nc;
     const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
     double sa = 0, sb = 0, sa2 = 0, sb2 = 0;
+    clptr vCdx = L.Cdx(), vrup = L.rup(), vsi = L.si(), vdz = L.dz(), vz = L.z();
     for (int i = 0; i < nc; ++i) {
-      double cdx = L.Cdx[i];
-      double up0 = L.rup[i], lo0 = L.si[i];
+      double cdx = vCdx[i];
+      double up0 = vrup[i], lo0 = vsi[i];
       bool up = (up0 + cdx * alpha) > 0.;
       bool lo = (lo0 + cdx * alpha) < 0.;
       double e = (up || lo) ? cdx : 0.0;
@@ -1793,8 +1630,8 @@ struct Solver
       sa = fma(e, e, sa);
       sb = fma(apz, e, sb);
       if (!gpdal) {
-        double e2 = e - L.dz[i] * info.mu_in;
-        double apz2 = apz - L.z[i] * info.mu_in;
+        double e2 = e - vdz[i] * info.mu_in;
+        double apz2 = apz - vz[i] * info.mu_in;
         sa2 = fma(e2, e2, sa2);
         sb2 = fma(e2, apz2, sb2);
       }
@@ -1817,23 +1654,23 @@ struct Solver
     double s_xHdx = 0, s_errdx = 0, s_adxres = 0, s_eres = 0;
     double s_dz2 = 0, s_dzz = 0;
     for (int k = threadIdx.x; k < n; k += NT) {
-      double dxk = L.dx[k];
-      s_dxHdx += dxk * L.Hdx[k];
+      double dxk = L.dx()[k];
+      s_dxHdx += dxk * L.Hdx()[k];
       s_dx2 += dxk * dxk;
-      s_xHdx += L.x[k] * L.Hdx[k];
-      s_errdx += (info.rho * (L.x[k] - L.xp[k]) + L.gs[k]) * dxk;
+      s_xHdx += L.x()[k] * L.Hdx()[k];
+      s_errdx += (info.rho * (L.x()[k] - L.xp()[k]) + L.gs()[k]) * dxk;
     }
     for (int k = threadIdx.x; k < ne; k += NT) {
-      double adx = L.Adx[k];
-      double e = adx - L.dy[k] * info.mu_eq;
+      double adx = L.Adx()[k];
+      double e = adx - L.dy()[k] * info.mu_eq;
       s_adx2 += adx * adx;
       s_e2 += e * e;
-      s_adxres += adx * (L.se[k] + L.y[k] * info.mu_eq);
-      s_eres += e * L.se[k];
+      s_adxres += adx * (L.se()[k] + L.y()[k] * info.mu_eq);
+      s_eres += e * L.se()[k];
     }
     for (int k = threadIdx.x; k < nc; k += NT) {
-      s_dz2 += L.dz[k] * L.dz[k];
-      s_dzz += L.dz[k] * L.z[k];
+      s_dz2 += L.dz()[k] * L.dz()[k];
+      s_dzz += L.dz()[k] * L.z()[k];
     }
     R.sum4(s_dxHdx, s_adx2, s_dx2, s_e2);
     R.sum4(s_xHdx, s_errdx, s_adxres, s_eres);
@@ -1857,10 +1694,10 @@ struct Solver
       int t = threadIdx.x + rep * NT;
       if (t < 2 * nc) {
         int i = t >> 1;
-        double cdx = L.Cdx[i];
+        double cdx = L.Cdx()[i];
         double al = -1.0;
         if (cdx != 0.) {
-          double num = (t & 1) ? L.si[i] : L.rup[i];
+          double num = (t & 1) ? L.si()[i] : L.rup()[i];
           al = -num / (cdx + MACHINE_EPS);
         }
         if (al > MACHINE_EPS) {
@@ -1922,9 +1759,9 @@ struct Solver
     const double c = ruiz_c;
     double ndy = 0, ndz = 0, zero = 0;
     for (int k = threadIdx.x; k < ne; k += NT)
-      ndy = fmax(ndy, fabs(L.dy[k]));
+      ndy = fmax(ndy, fabs(L.dy()[k]));
     for (int k = threadIdx.x; k < nc; k += NT)
-      ndz = fmax(ndz, fabs(L.dz[k]));
+      ndz = fmax(ndz, fabs(L.dz()[k]));
     R.max3(ndy, ndz, zero);
     if (!(ndy != 0 || ndz != 0))
       return false;
@@ -1932,32 +1769,32 @@ struct Solver
     {
       cgptr dx = P.dlt_x();
       for (int k = threadIdx.x; k < n; k += NT) {
-        L.ATdy[k] /= dx[k] * c;
-        L.CTdz[k] /= dx[k] * c;
-        lb2 = fmax(lb2, fabs(L.ATdy[k] + L.CTdz[k]));
+        L.ATdy()[k] /= dx[k] * c;
+        L.CTdz()[k] /= dx[k] * c;
+        lb2 = fmax(lb2, fabs(L.ATdy()[k] + L.CTdz()[k]));
       }
       cgptr de = P.dlt_eq();
       for (int k = threadIdx.x; k < ne; k += NT) {
-        lb1 += L.dy[k] * L.bs[k];
-        L.dy[k] = L.dy[k] * de[k] / c;
-        nrm_dy = fmax(nrm_dy, fabs(L.dy[k]));
+        lb1 += L.dy()[k] * L.bs()[k];
+        L.dy()[k] = L.dy()[k] * de[k] / c;
+        nrm_dy = fmax(nrm_dy, fabs(L.dy()[k]));
       }
       cgptr di = P.dlt_in();
       for (int k = threadIdx.x; k < ni; k += NT) {
-        double v = L.dz[k];
-        lb1 += (v > 0 ? v : 0.0) * L.us[k];
-        lb1 -= (v < 0 ? v : 0.0) * L.ls[k];
-        L.dz[k] = v * di[k] / c;
-        nrm_dz = fmax(nrm_dz, fabs(L.dz[k]));
+        double v = L.dz()[k];
+        lb1 += (v > 0 ? v : 0.0) * L.us()[k];
+        lb1 -= (v < 0 ? v : 0.0) * L.ls()[k];
+        L.dz()[k] = v * di[k] / c;
+        nrm_dz = fmax(nrm_dz, fabs(L.dz()[k]));
       }
       if (d.box) {
         cgptr db = P.dlt_box();
         for (int k = threadIdx.x; k < n; k += NT) {
-          double v = L.dz[ni + k];
-          lb1 += (v > 0 ? v : 0.0) * L.ubs[k];
-          lb1 -= (v < 0 ? v : 0.0) * L.lbs[k];
-          L.dz[ni + k] = db[k] * v / c;
-          nrm_dz = fmax(nrm_dz, fabs(L.dz[ni + k]));
+          double v = L.dz()[ni + k];
+          lb1 += (v > 0 ? v : 0.0) * L.ubs()[k];
+          lb1 -= (v < 0 ? v : 0.0) * L.lbs()[k];
+          L.dz()[ni + k] = db[k] * v / c;
+          nrm_dz = fmax(nrm_dz, fabs(L.dz()[ni + k]));
         }
       }
     }
@@ -1976,24 +1813,24 @@ struct Solver
     {
       cgptr dx = P.dlt_x();
       for (int k = threadIdx.x; k < n; k += NT) {
-        L.Hdx[k] /= dx[k] * c;
-        nhdx = fmax(nhdx, fabs(L.Hdx[k]));
-        gdx += L.dx[k] * L.gs[k];
-        L.dx[k] *= dx[k];
-        ndx = fmax(ndx, fabs(L.dx[k]));
+        L.Hdx()[k] /= dx[k] * c;
+        nhdx = fmax(nhdx, fabs(L.Hdx()[k]));
+        gdx += L.dx()[k] * L.gs()[k];
+        L.dx()[k] *= dx[k];
+        ndx = fmax(ndx, fabs(L.dx()[k]));
       }
       cgptr de = P.dlt_eq();
       for (int k = threadIdx.x; k < ne; k += NT) {
-        L.Adx[k] /= de[k];
-        nadx = fmax(nadx, fabs(L.Adx[k]));
+        L.Adx()[k] /= de[k];
+        nadx = fmax(nadx, fabs(L.Adx()[k]));
       }
       cgptr di = P.dlt_in();
       for (int k = threadIdx.x; k < ni; k += NT)
-        L.Cdx[k] /= di[k];
+        L.Cdx()[k] /= di[k];
       if (d.box) {
         cgptr db = P.dlt_box();
         for (int k = threadIdx.x; k < n; k += NT)
-          L.Cdx[ni + k] /= db[k];
+          L.Cdx()[ni + k] /= db[k];
       }
     }
     gdx = R.sum(gdx);
@@ -2002,26 +1839,26 @@ struct Solver
     double bound_neg = -bound;
     double viol = 0; // 1 when some constraint breaks first_cond
     for (int k = threadIdx.x; k < ni; k += NT) {
-      double v = L.Cdx[k];
+      double v = L.Cdx()[k];
       bool ok = true;
-      if (L.us[k] <= 1.E20 && L.ls[k] >= -1.E20)
+      if (L.us()[k] <= 1.E20 && L.ls()[k] >= -1.E20)
         ok = v <= bound && v >= bound_neg;
-      else if (L.us[k] > 1.E20)
+      else if (L.us()[k] > 1.E20)
         ok = v >= bound_neg;
-      else if (L.ls[k] < -1.E20)
+      else if (L.ls()[k] < -1.E20)
         ok = v <= bound;
       if (!ok)
         viol = 1;
     }
     if (d.box)
       for (int k = threadIdx.x; k < n; k += NT) {
-        double v = L.dx[k];
+        double v = L.dx()[k];
         bool ok = true;
-        if (L.ubs[k] <= 1.E20 && L.lbs[k] >= -1.E20)
+        if (L.ubs()[k] <= 1.E20 && L.lbs()[k] >= -1.E20)
           ok = v <= bound && v >= bound_neg;
-        else if (L.ubs[k] > 1.E20)
+        else if (L.ubs()[k] > 1.E20)
           ok = v >= bound_neg;
-        else if (L.lbs[k] < -1.E20)
+        else if (L.lbs()[k] < -1.E20)
           ok = v <= bound;
         if (!ok)
           viol = 1;
@@ -2041,14 +1878,14 @@ struct Solver
     const double zf = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
     double e1 = 0, e2 = 0, e3 = 0;
     for (int i = threadIdx.x; i < nc; i += NT) {
-      double up = L.rup[i], lo = L.si[i];
-      double v = (up > 0 ? up : 0.0) + (lo < 0 ? lo : 0.0) - zf * L.z[i] * info.mu_in;
+      double up = L.rup()[i], lo = L.si()[i];
+      double v = (up > 0 ? up : 0.0) + (lo < 0 ? lo : 0.0) - zf * L.z()[i] * info.mu_in;
       e1 = fmax(e1, fabs(v));
     }
     for (int k = threadIdx.x; k < ne; k += NT)
-      e2 = fmax(e2, fabs(L.se[k]));
+      e2 = fmax(e2, fabs(L.se()[k]));
     for (int k = threadIdx.x; k < n; k += NT)
-      e3 = fmax(e3, fabs(L.dres[k]));
+      e3 = fmax(e3, fabs(L.dres()[k]));
     R.max3(e1, e2, e3);
     return fmax(e1, fmax(e2, e3));
   }
@@ -2062,9 +1899,9 @@ struct Solver
     const double zfac = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
     if (mode == 0) {
       for (int i = threadIdx.x; i < nc; i += NT) {
-        int up = L.rup[i] >= 0 ? 1 : 0;
-        int lo = L.si[i] <= 0 ? 2 : 0;
-        L.aflags[i] = up | lo | ((up | lo) ? 4 : 0);
+        int up = L.rup()[i] >= 0 ? 1 : 0;
+        int lo = L.si()[i] <= 0 ? 2 : 0;
+        L.aflags()[i] = up | lo | ((up | lo) ? 4 : 0);
       }
     }
     __syncthreads();
@@ -2075,58 +1912,58 @@ struct Solver
     if (mode == 0) {
       // right-hand side (solver.hpp:787-847)
       for (int i = threadIdx.x; i < nc; i += NT)
-        L.zfull[i] = (L.slot_of[i] >= 0) ? 0.0 : L.z[i]; // inactive multipliers
+        L.zfull()[i] = (L.slot_of()[i] >= 0) ? 0.0 : L.z()[i]; // inactive multipliers
       __syncthreads();
       if (ni > 0)
-        mv(P.Cs(), n, ni, n, L.zfull, L.CTzin);
+        mv(P.Cs(), n, ni, n, L.zfull(), L.CTzin());
       else
-        vzero(L.CTzin, n);
+        vzero(L.CTzin(), n);
       __syncthreads();
       for (int k = threadIdx.x; k < n; k += NT) {
-        double s = L.CTzin[k];
+        double s = L.CTzin()[k];
         if (d.box) {
-          s += L.zfull[ni + k] * L.isc[k];
-          L.CTzin[k] = s;
+          s += L.zfull()[ni + k] * L.isc()[k];
+          L.CTzin()[k] = s;
         }
-        L.rx[k] = -L.dres[k] + s;
+        L.rx()[k] = -L.dres()[k] + s;
       }
       for (int k = threadIdx.x; k < ne; k += NT)
-        L.rd[k] = -L.se[k];
+        L.rd()[k] = -L.se()[k];
       for (int i = threadIdx.x; i < nc; i += NT) {
-        int s = L.slot_of[i];
+        int s = L.slot_of()[i];
         if (s >= 0) {
           double v = 0;
           if (flag_up(i))
-            v = -L.rup[i] + L.z[i] * info.mu_in * zfac;
+            v = -L.rup()[i] + L.z()[i] * info.mu_in * zfac;
           else if (flag_low(i))
-            v = -L.si[i] + L.z[i] * info.mu_in * zfac;
-          L.rd[ne + s] = v;
+            v = -L.si()[i] + L.z()[i] * info.mu_in * zfac;
+          L.rd()[ne + s] = v;
         }
       }
     } else {
       for (int k = threadIdx.x; k < n; k += NT)
-        L.rx[k] = -L.gs[k];
+        L.rx()[k] = -L.gs()[k];
       for (int k = threadIdx.x; k < ne; k += NT)
-        L.rd[k] = L.bs[k];
+        L.rd()[k] = L.bs()[k];
     }
     __syncthreads();
     toc(ST_CYC_NEWTON_MISC);
     iterative_solve(eps);
     if (mode == 1) {
-      vcopy(L.x, L.dx, n);
-      vcopy(L.y, L.sd, ne);
+      vcopy(L.x(), L.dx(), n);
+      vcopy(L.y(), L.sd(), ne);
       __syncthreads();
       return;
     }
     // un-permute: dz_i = solution of its slot, or -z_i when inactive (:860-868);
     // C^T dz = (active part, from the last residual) - (inactive multipliers' part)
-    vcopy(L.dy, L.sd, ne);
+    vcopy(L.dy(), L.sd(), ne);
     for (int i = threadIdx.x; i < nc; i += NT) {
-      int s = L.slot_of[i];
-      L.dz[i] = (s >= 0) ? L.sd[ne + s] : -L.z[i];
+      int s = L.slot_of()[i];
+      L.dz()[i] = (s >= 0) ? L.sd()[ne + s] : -L.z()[i];
     }
     for (int k = threadIdx.x; k < n; k += NT)
-      L.CTdz[k] -= L.CTzin[k];
+      L.CTdz()[k] -= L.CTzin()[k];
     __syncthreads();
   }
 
@@ -2144,7 +1981,7 @@ struct Solver
       tic();
       if (st.merit_function_type == PQP_MERIT_GPDAL) {
         for (int i = threadIdx.x; i < nc; i += NT)
-          L.Cdx[i] += (st.alpha_gpdal - 1.) * info.mu_in * L.dz[i];
+          L.Cdx()[i] += (st.alpha_gpdal - 1.) * info.mu_in * L.dz()[i];
         __syncthreads();
       }
       UD alpha = 1.0;
@@ -2154,11 +1991,11 @@ struct Solver
       {
         double m = 0;
         for (int k = threadIdx.x; k < n; k += NT)
-          m = fmax(m, fabs(alpha * L.dx[k]));
+          m = fmax(m, fabs(alpha * L.dx()[k]));
         for (int k = threadIdx.x; k < ne; k += NT)
-          m = fmax(m, fabs(alpha * L.dy[k]));
+          m = fmax(m, fabs(alpha * L.dy()[k]));
         for (int k = threadIdx.x; k < nc; k += NT)
-          m = fmax(m, fabs(alpha * L.dz[k]));
+          m = fmax(m, fabs(alpha * L.dz()[k]));
         m = R.max(m);
         if (m < 1.E-11 && iter > 0) {
           info.iter += iter + 1;
@@ -2166,17 +2003,17 @@ struct Solver
         }
       }
       for (int k = threadIdx.x; k < n; k += NT) {
-        L.x[k] += alpha * L.dx[k];
-        L.dres[k] += alpha * (info.rho * L.dx[k] + L.Hdx[k] + L.ATdy[k] + L.CTdz[k]);
+        L.x()[k] += alpha * L.dx()[k];
+        L.dres()[k] += alpha * (info.rho * L.dx()[k] + L.Hdx()[k] + L.ATdy()[k] + L.CTdz()[k]);
       }
       for (int i = threadIdx.x; i < nc; i += NT) {
-        L.rup[i] += alpha * L.Cdx[i];
-        L.si[i] += alpha * L.Cdx[i];
-        L.z[i] += alpha * L.dz[i];
+        L.rup()[i] += alpha * L.Cdx()[i];
+        L.si()[i] += alpha * L.Cdx()[i];
+        L.z()[i] += alpha * L.dz()[i];
       }
       for (int k = threadIdx.x; k < ne; k += NT) {
-        L.se[k] += alpha * (L.Adx[k] - info.mu_eq * L.dy[k]);
-        L.y[k] += alpha * L.dy[k];
+        L.se()[k] += alpha * (L.Adx()[k] - info.mu_eq * L.dy()[k]);
+        L.y()[k] += alpha * L.dy()[k];
       }
       __syncthreads();
       const UD err_in = inner_loop_saddle_point();
@@ -2220,15 +2057,15 @@ struct Solver
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     cgptr dx = P.dlt_x(), de = P.dlt_eq(), di = P.dlt_in();
     for (int k = threadIdx.x; k < n; k += NT)
-      L.x[k] /= dx[k];
+      L.x()[k] /= dx[k];
     for (int k = threadIdx.x; k < ne; k += NT)
-      L.y[k] = L.y[k] / de[k] * ruiz_c;
+      L.y()[k] = L.y()[k] / de[k] * ruiz_c;
     for (int k = threadIdx.x; k < ni; k += NT)
-      L.z[k] = L.z[k] / di[k] * ruiz_c;
+      L.z()[k] = L.z()[k] / di[k] * ruiz_c;
     if (d.box) {
       cgptr db = P.dlt_box();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.z[ni + k] = L.z[ni + k] / db[k] * ruiz_c;
+        L.z()[ni + k] = L.z()[ni + k] / db[k] * ruiz_c;
     }
     __syncthreads();
   }
@@ -2242,18 +2079,18 @@ struct Solver
     ruiz_c = W.ruiz_c;
     dual_feasibility_rhs_2 = W.dual_feasibility_rhs_2;
     for (int k = threadIdx.x; k < ST_COUNT; k += NT)
-      L.stat[k] = 0;
+      L.stat()[k] = 0;
     const long long t_start = (threadIdx.x == 0) ? clock64() : 0;
     // results -> LDS (the warm-start modes read them)
-    vload(L.x, P.x(), n);
-    vload(L.y, P.y(), ne);
-    vload(L.z, P.z(), nc);
+    vload(L.x(), P.x(), n);
+    vload(L.y(), P.y(), ne);
+    vload(L.z(), P.z(), nc);
     for (int i = threadIdx.x; i < nc; i += NT) {
-      L.aflags[i] = 0;
-      L.slot_of[i] = -1;
+      L.aflags()[i] = 0;
+      L.slot_of()[i] = -1;
     }
     for (int k = threadIdx.x; k < d.nd; k += NT)
-      L.zvalid[k] = 0;
+      L.zvalid()[k] = 0;
     z_all_valid = false;
     __syncthreads();
 
@@ -2270,9 +2107,9 @@ struct Solver
     bool do_restore = false;
     if (dirty) {
       if (ig == PQP_EQUALITY_CONSTRAINED_INITIAL_GUESS || ig == PQP_NO_INITIAL_GUESS) {
-        vzero(L.x, n); // results.cleanup
-        vzero(L.y, ne);
-        vzero(L.z, nc);
+        vzero(L.x(), n); // results.cleanup
+        vzero(L.y(), ne);
+        vzero(L.z(), nc);
         cold_start(info, st);
       } else if (wswpr) {
         cleanup_statistics(info);
@@ -2312,20 +2149,20 @@ struct Solver
     if (do_rescale) {
       // re-apply the stored equilibration (solver.hpp:1192-1214); u, l unclamped
       tic();
-      lptr S = L.rx; // rx (n) and rd (nd) are contiguous: ntot doubles, free here
+      lptr S = L.rd(); // scratch of ntot doubles: rd, ed, sd, dS, t2 (4 nd + max(n, nd)) are free here
       vload(S, P.delta(), d.ntot);
       __syncthreads();
       write_scaled<NT>(batch, q, S, ruiz_c, false);
       toc(ST_CYC_SCALE);
     }
-    vload(L.gs, P.gs(), n);
-    vload(L.bs, P.bs(), ne);
-    vload(L.us, P.us(), ni);
-    vload(L.ls, P.ls(), ni);
+    vload(L.gs(), P.gs(), n);
+    vload(L.bs(), P.bs(), ne);
+    vload(L.us(), P.us(), ni);
+    vload(L.ls(), P.ls(), ni);
     if (d.box) {
-      vload(L.ubs, P.ubs(), n);
-      vload(L.lbs, P.lbs(), n);
-      vload(L.isc, P.is(), n);
+      vload(L.ubs(), P.ubs(), n);
+      vload(L.lbs(), P.lbs(), n);
+      vload(L.isc(), P.is(), n);
     }
     __syncthreads();
     if (do_scale_ws)
@@ -2335,7 +2172,7 @@ struct Solver
       tic();
       factor_primal_block();
       if (threadIdx.x == 0)
-        L.stat[ST_CYC_FACTOR_H] += clock64() - t_fh;
+        L.stat()[ST_CYC_FACTOR_H] += clock64() - t_fh;
       tic();
       n_c = 0;
       r = ne;
@@ -2344,13 +2181,13 @@ struct Solver
     if (do_restore) {
       // WARM_START_WITH_PREVIOUS_RESULT on an unchanged model: reuse the block
       // factorisation the previous solve left in HBM (solver.hpp:1173-1187, 1343-1375)
-      vload(L.dF, P.dF(), n);
-      vload(L.dS, P.dS(), d.nd);
+      vload(L.dF(), P.dF(), n);
+      vload(L.dS(), P.dS(), d.nd);
       {
         const PQP_GLOBAL int* zv = P.zvalid();
         double miss = 0.0;
         for (int k = threadIdx.x; k < d.nd; k += NT) {
-          L.zvalid[k] = zv[k];
+          L.zvalid()[k] = zv[k];
           if (!zv[k])
             miss = 1.0;
         }
@@ -2363,8 +2200,8 @@ struct Solver
         const PQP_GLOBAL int* ga = P.act();
         for (int j = threadIdx.x; j < n_c; j += NT) {
           int i = ga[j];
-          L.act[j] = i;
-          L.slot_of[i] = j;
+          L.act()[j] = i;
+          L.slot_of()[i] = j;
         }
       }
       __syncthreads();
@@ -2373,7 +2210,7 @@ struct Solver
     if (do_aset_from_z || do_eq_guess) {
       if (do_aset_from_z) {
         for (int i = threadIdx.x; i < nc; i += NT)
-          L.aflags[i] = (L.z[i] != 0) ? 4 : 0;
+          L.aflags()[i] = (L.z()[i] != 0) ? 4 : 0;
       }
       linear_step(do_eq_guess ? 1 : 2, 1.0);
     }
@@ -2468,22 +2305,22 @@ struct Solver
           }
         }
         info.iter_ext += 1;
-        vcopy(L.xp, L.x, n);
-        vcopy(L.yp, L.y, ne);
-        vcopy(L.zp, L.z, nc);
+        vcopy(L.xp(), L.x(), n);
+        vcopy(L.yp(), L.y(), ne);
+        vcopy(L.zp(), L.z(), nc);
         // shifted inequality residuals (solver.hpp:1523-1559)
         {
           cgptr di = P.dlt_in();
           cgptr db = P.dlt_box();
           for (int i = threadIdx.x; i < nc; i += NT) {
             double sc = (i < ni) ? di[i] : db[i - ni];
-            double v = L.rup[i] * sc + L.z[i] * info.mu_in;
+            double v = L.rup()[i] * sc + L.z()[i] * info.mu_in;
             if (st.merit_function_type == PQP_MERIT_GPDAL)
-              v += (st.alpha_gpdal - 1.) * info.mu_in * L.z[i];
-            double ub = (i < ni) ? L.us[i] : L.ubs[i - ni];
-            double lb = (i < ni) ? L.ls[i] : L.lbs[i - ni];
-            L.rup[i] = v - ub;
-            L.si[i] = v - lb;
+              v += (st.alpha_gpdal - 1.) * info.mu_in * L.z()[i];
+            double ub = (i < ni) ? L.us()[i] : L.ubs()[i - ni];
+            double lb = (i < ni) ? L.ls()[i] : L.lbs()[i - ni];
+            L.rup()[i] = v - ub;
+            L.si()[i] = v - lb;
           }
         }
         __syncthreads();
@@ -2498,30 +2335,30 @@ struct Solver
         }
         if ((info.status == PQP_PRIMAL_INFEASIBLE && !st.primal_infeasibility_solving) ||
             info.status == PQP_DUAL_INFEASIBLE) {
-          vcopy(L.x, L.dx, n); // certificates (solver.hpp:1572-1580)
-          vcopy(L.y, L.dy, ne);
-          vcopy(L.z, L.dz, nc);
+          vcopy(L.x(), L.dx(), n); // certificates (solver.hpp:1572-1580)
+          vcopy(L.y(), L.dy(), ne);
+          vcopy(L.z(), L.dz(), nc);
           __syncthreads();
           break;
         }
         if (scaled_eps == st.eps_abs && st.primal_infeasibility_solving &&
             info.status == PQP_PRIMAL_INFEASIBLE) {
           // solver.hpp:1581-1595 : || A^T 1 + C^T 1 (+ i_scaled) ||_inf * eps_abs
-          lptr ones = L.zfull; // nc >= n_in; n_eq ones taken from L.sd
+          lptr ones = L.zfull(); // nc >= n_in; n_eq ones taken from L.sd()
           for (int k = threadIdx.x; k < ni; k += NT)
             ones[k] = 1.0;
           for (int k = threadIdx.x; k < ne; k += NT)
-            L.sd[k] = 1.0;
-          vzero(L.t1, n);
-          vzero(L.t2, n);
+            L.sd()[k] = 1.0;
+          vzero(L.t1(), n);
+          vzero(L.t2(), n);
           __syncthreads();
           if (ne > 0)
-            mv(P.A(), n, ne, n, L.sd, L.t1);
+            mv(P.A(), n, ne, n, L.sd(), L.t1());
           if (ni > 0)
-            mv(P.C(), n, ni, n, ones, L.t2);
+            mv(P.C(), n, ni, n, ones, L.t2());
           double m = 0;
           for (int k = threadIdx.x; k < n; k += NT)
-            m = fmax(m, fabs(L.t1[k] + L.t2[k] + (d.box ? L.isc[k] : 0.0)));
+            m = fmax(m, fabs(L.t1()[k] + L.t2()[k] + (d.box ? L.isc()[k] : 0.0)));
           scaled_eps = R.max(m) * st.eps_abs;
         }
         stage = 1;
@@ -2549,8 +2386,8 @@ struct Solver
             bcl_eta_ext *= pow(info.mu_in, st.beta_bcl);
             bcl_eta_in = fmax(bcl_eta_in * info.mu_in, eps_in_min);
           } else {
-            vcopy(L.y, L.yp, ne);
-            vcopy(L.z, L.zp, nc);
+            vcopy(L.y(), L.yp(), ne);
+            vcopy(L.z(), L.zp(), nc);
             gdr_fresh = false; // y, z were reset
             __syncthreads();
             new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
@@ -2604,25 +2441,25 @@ struct Solver
     {
       cgptr dx = P.dlt_x(), de = P.dlt_eq(), di = P.dlt_in();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.x[k] *= dx[k];
+        L.x()[k] *= dx[k];
       for (int k = threadIdx.x; k < ne; k += NT)
-        L.y[k] = L.y[k] * de[k] / ruiz_c;
+        L.y()[k] = L.y()[k] * de[k] / ruiz_c;
       for (int k = threadIdx.x; k < ni; k += NT)
-        L.z[k] = L.z[k] * di[k] / ruiz_c;
+        L.z()[k] = L.z()[k] * di[k] / ruiz_c;
       if (d.box) {
         cgptr db = P.dlt_box();
         for (int k = threadIdx.x; k < n; k += NT)
-          L.z[ni + k] = db[k] * L.z[ni + k] / ruiz_c;
+          L.z()[ni + k] = db[k] * L.z()[ni + k] / ruiz_c;
       }
       if (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE) {
         for (int k = threadIdx.x; k < ne; k += NT)
-          L.se[k] /= de[k];
+          L.se()[k] /= de[k];
         for (int k = threadIdx.x; k < ni; k += NT)
-          L.si[k] /= di[k];
+          L.si()[k] /= di[k];
         if (d.box) {
           cgptr db = P.dlt_box();
           for (int k = threadIdx.x; k < n; k += NT)
-            L.si[ni + k] /= db[k];
+            L.si()[ni + k] /= db[k];
         }
       }
     }
@@ -2632,30 +2469,30 @@ struct Solver
       double obj = 0;
       cgptr g = P.g();
       if (d.hessian == PQP_HESSIAN_DENSE) {
-        mv(P.H(), n, n, n, L.x, L.t1);
+        mv(P.H(), n, n, n, L.x(), L.t1());
         for (int k = threadIdx.x; k < n; k += NT)
-          obj += 0.5 * L.t1[k] * L.x[k] + g[k] * L.x[k];
+          obj += 0.5 * L.t1()[k] * L.x()[k] + g[k] * L.x()[k];
       } else {
         cgptr H = P.H();
         for (int k = threadIdx.x; k < n; k += NT)
-          obj += 0.5 * L.x[k] * L.x[k] * H[(long)k * n + k] + g[k] * L.x[k];
+          obj += 0.5 * L.x()[k] * L.x()[k] * H[(long)k * n + k] + g[k] * L.x()[k];
       }
       info.objValue = R.sum(obj);
     }
     // write back
-    vstore(P.x(), L.x, n);
-    vstore(P.y(), L.y, ne);
-    vstore(P.z(), L.z, nc);
-    vstore(P.se(), L.se, ne);
-    vstore(P.si(), L.si, nc);
-    vstore(P.dS(), L.dS, d.nd);
+    vstore(P.x(), L.x(), n);
+    vstore(P.y(), L.y(), ne);
+    vstore(P.z(), L.z(), nc);
+    vstore(P.se(), L.se(), ne);
+    vstore(P.si(), L.si(), nc);
+    vstore(P.dS(), L.dS(), d.nd);
     {
       PQP_GLOBAL int* ga = P.act();
       PQP_GLOBAL int* zv = P.zvalid();
       for (int i = threadIdx.x; i < nc; i += NT)
-        ga[i] = (i < n_c) ? L.act[i] : -1;
+        ga[i] = (i < n_c) ? L.act()[i] : -1;
       for (int k = threadIdx.x; k < d.nd; k += NT)
-        zv[k] = L.zvalid[k];
+        zv[k] = L.zvalid()[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2669,11 +2506,11 @@ struct Solver
       W.mu_in_fact = info.mu_in;
       W.rho_fact = info.rho;
       *P.state() = W;
-      L.stat[ST_N_ACTIVE_FINAL] = n_c;
-      L.stat[ST_CYC_TOTAL] = clock64() - t_start;
+      L.stat()[ST_N_ACTIVE_FINAL] = n_c;
+      L.stat()[ST_CYC_TOTAL] = clock64() - t_start;
       PQP_GLOBAL long long* gs = P.stats();
       for (int k = 0; k < ST_COUNT; ++k)
-        gs[k] = L.stat[k];
+        gs[k] = L.stat()[k];
     }
   }
 };

@@ -10,6 +10,7 @@
 // scalarisation is the identity on the host
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define PQP_OPAQUE_SCALAR(v) ((void)0)
+#define PQP_OPAQUE_VECTOR(v) ((void)0)
 #include "../../hip_emu.hpp"
 // FP64 matrix core (v_mfma_f64_16x16x4_f64) as a wave collective built from lane shuffles,
 // with the hardware's operand layout (see pqp_block.hpp): a = A[l & 15][l >> 4],
