@@ -4,6 +4,7 @@
 // the two kernels (setup = init/update + Ruiz; solve = qp_solve on every QP).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,10 +70,39 @@ pqp_setup_kernel(pqp::Batch batch)
 // lane): the knob that trades spills against resident workgroups per CU.
 template<int NT, int WPS>
 __global__ __launch_bounds__(NT, WPS) void
-pqp_solve_kernel(pqp::Batch batch, long first)
+pqp_solve_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
 {
   HIP_DYNAMIC_SHARED(double, smem)
-  pqp::solve_body<NT>(batch, first + (long)blockIdx.x, (pqp::lptr)smem);
+  // `order` (optional) is the dispatch order of the QPs: workgroups are handed out in blockIdx
+  // order, so listing the expensive QPs first shortens the tail of the launch
+  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
+  pqp::solve_body<NT>(batch, first + slot, (pqp::lptr)smem);
+}
+
+// Dispatch order for the next whole-batch launch: QP i goes to position
+// rank(i) = #{ j : cycles_j > cycles_i  or  (cycles_j == cycles_i and j < i) }  (descending by the
+// device cycles of the solve that just finished; O(B^2) compares, a few microseconds for B ~ 10^3-10^4).
+__global__ __launch_bounds__(256) void
+pqp_order_kernel(const long long* __restrict__ stats, int stride, int B, int* __restrict__ order)
+{
+  constexpr int TILE = 2048;
+  __shared__ long long tile[TILE];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ci = (i < B) ? stats[(long)i * stride] : 0;
+  int rank = 0;
+  for (int j0 = 0; j0 < B; j0 += TILE) {
+    const int cnt = (B - j0 < TILE) ? (B - j0) : TILE;
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x)
+      tile[t] = stats[(long)(j0 + t) * stride];
+    __syncthreads();
+    for (int t = 0; t < cnt; ++t) {
+      const long long cj = tile[t];
+      rank += (cj > ci || (cj == ci && j0 + t < i)) ? 1 : 0;
+    }
+  }
+  if (i < B)
+    order[rank] = i;
 }
 
 struct pqp_batch
@@ -84,6 +114,7 @@ struct pqp_batch
   int backend = PQP_BACKEND_PRIMAL_DUAL_LDLT;
   size_t lds_solve = 0, lds_setup = 0;
   std::vector<pqp_settings> settings;
+  std::vector<pqp_settings> settings_uploaded; // what the device holds
   std::vector<pqp::Cmd> cmd;
   std::vector<char> is_initialized;
   bool settings_dirty = true;
@@ -95,6 +126,14 @@ struct pqp_batch
   float last_ms = 0.f;
   hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
   long range_first = 0, range_count = 0;
+  // Longest-processing-time-first dispatch: after a whole-batch solve the per-QP device cycle
+  // counts (stats[q][0]) order the NEXT whole-batch solve, most expensive QP first.  QPs are
+  // independent, so the order changes nothing but the tail of the launch.  PQP_SCHEDULE=fifo
+  // disables it.
+  bool lpt = true;
+  bool order_valid = false;
+  int* d_order = nullptr;
+
 };
 
 namespace {
@@ -133,8 +172,10 @@ launch_solve(pqp_batch* h)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
+  const int* order = (h->lpt && h->order_valid && whole) ? h->d_order : nullptr;
   hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
-                     h->stream, h->dev, h->range_first);
+                     h->stream, h->dev, h->range_first, order);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
   return PQP_OK;
@@ -145,8 +186,14 @@ upload_settings(pqp_batch* h)
 {
   if (!h->settings_dirty)
     return PQP_OK;
-  HIP_TRY(hipMemcpy(h->d_settings, h->settings.data(), h->settings.size() * sizeof(pqp_settings),
-                    hipMemcpyHostToDevice));
+  // users write into the host records at any time, so every solve has to look at them; the
+  // upload itself is skipped when nothing changed since the last one
+  const size_t bytes = h->settings.size() * sizeof(pqp_settings);
+  if (h->settings_uploaded.size() == h->settings.size() &&
+      std::memcmp(h->settings_uploaded.data(), h->settings.data(), bytes) == 0)
+    return PQP_OK;
+  HIP_TRY(hipMemcpy(h->d_settings, h->settings.data(), bytes, hipMemcpyHostToDevice));
+  h->settings_uploaded = h->settings;
   // the host copy stays "dirty" for ever: users hold raw pointers into it and may
   // write at any time (reference: qp.settings is a public member)
   return PQP_OK;
@@ -371,6 +418,8 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     delete h;
     return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq+n_in(+n)) > 1024 is not supported by this build");
   }
+  if (const char* e = std::getenv("PQP_SCHEDULE"))
+    h->lpt = std::string(e) != "fifo";
   if (const char* e = std::getenv("PQP_WAVES_PER_SIMD")) {
     int v = std::atoi(e);
     if (v >= 1 && v <= 4)
@@ -432,6 +481,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   ALLOC(D.act, B * nc)
   ALLOC(D.zvalid, B * nd)
   ALLOC(D.stats, B * size_t(pqp::ST_COUNT))
+  ALLOC(h->d_order, B)
   ALLOC(h->d_settings, B)
   ALLOC(h->d_cmd, B)
 #undef ALLOC
@@ -641,6 +691,13 @@ pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
     return rc;
   HIP_TRY(hipEventSynchronize(h->ev1));
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  if (h->lpt && first == 0 && count == h->dev.B && count > 1) {
+    // feedback for the next whole-batch launch: order by the device cycles this solve took
+    hipLaunchKernelGGL((pqp_order_kernel), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream,
+                       reinterpret_cast<const long long*>(h->dev.stats), (int)pqp::ST_COUNT, (int)count, h->d_order);
+    HIP_TRY(hipGetLastError());
+    h->order_valid = true;
+  }
   // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
   std::fill(h->is_initialized.begin() + first, h->is_initialized.begin() + first + count, char(1));
   return PQP_OK;

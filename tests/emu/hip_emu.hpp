@@ -255,6 +255,11 @@ hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t wi
   return hipSuccess;
 }
 inline hipError_t
+hipMemcpy2D(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind k)
+{
+  return hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, k);
+}
+inline hipError_t
 hipMemset(void* d, int v, size_t n)
 {
   std::memset(d, v, n);
