@@ -60,6 +60,7 @@ def lib():
         L.pqo_update.argtypes = [vp] + [dp] * 9 + [C.c_int] + [C.c_double] * 4
         L.pqo_solve.argtypes = [vp] + [dp] * 3
         L.pqo_cleanup.argtypes = [vp]
+        L.pqo_compute_backward.argtypes = [vp, dp] + [C.c_double] * 3 + [dp] * 7
         L.pqo_get_results.argtypes = [vp] + [dp] * 5 + [C.POINTER(pqp_info)]
         L.pqo_get_scaled.argtypes = [vp] + [dp] * 9
         L.pqo_get_counters.argtypes = [vp, dp]
@@ -145,6 +146,21 @@ class QP:
         keep = [_arr(x, (self.n,)), _arr(y, (self.n_eq,)), _arr(z, (self.n_c,))]
         self._L.pqo_solve(self._h, *map(_ptr, keep))
         self._sync()
+
+    def compute_backward(self, loss_derivative, eps=1e-4, rho_backward=1e-6, mu_backward=1e-6):
+        """dense::compute_backward (reference dense/compute_ECJ.hpp:29-189).  Returns a dict with
+        dL_dH, dL_dg, dL_dA, dL_db, dL_dC, dL_du, dL_dl (the reference's model.backward_data)."""
+        n, ne, ni = self.n, self.n_eq, self.n_in
+        ld = _arr(loss_derivative, (n + ne + ni,))
+        out = dict(dL_dH=np.zeros((n, n)), dL_dg=np.zeros(n), dL_dA=np.zeros((ne, n)), dL_db=np.zeros(ne),
+                   dL_dC=np.zeros((ni, n)), dL_du=np.zeros(ni), dL_dl=np.zeros(ni))
+        rc = self._L.pqo_compute_backward(self._h, _ptr(ld), float(eps), float(rho_backward), float(mu_backward),
+                                          *[_ptr(out[k]) for k in ("dL_dH", "dL_dg", "dL_dA", "dL_db", "dL_dC",
+                                                                   "dL_du", "dL_dl")])
+        if rc != 0:
+            raise ValueError(self._L.pqo_last_error().decode())
+        self._sync()
+        return out
 
     def cleanup(self):
         self._L.pqo_cleanup(self._h)

@@ -93,6 +93,34 @@ pqo_solve(void* h, const double* x, const double* y, const double* z)
   return 0;
 }
 
+// dense/compute_ECJ.hpp:29-189; outputs may be NULL
+int
+pqo_compute_backward(void* h, const double* loss_derivative, double eps, double rho_new, double mu_new,
+                     double* dL_dH, double* dL_dg, double* dL_dA, double* dL_db, double* dL_dC, double* dL_du,
+                     double* dL_dl)
+{
+  QP* q = static_cast<QP*>(h);
+  try {
+    q->compute_backward(loss_derivative, eps, rho_new, mu_new);
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return -1;
+  }
+  auto cp = [](double* dst, const pqo::Vec& v) {
+    if (dst && !v.empty())
+      std::memcpy(dst, v.data(), v.size() * sizeof(double));
+  };
+  const pqo::BackwardData& b = q->backward_data;
+  cp(dL_dH, b.dL_dH);
+  cp(dL_dg, b.dL_dg);
+  cp(dL_dA, b.dL_dA);
+  cp(dL_db, b.dL_db);
+  cp(dL_dC, b.dL_dC);
+  cp(dL_du, b.dL_du);
+  cp(dL_dl, b.dL_dl);
+  return 0;
+}
+
 void
 pqo_cleanup(void* h)
 {

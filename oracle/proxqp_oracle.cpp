@@ -2037,4 +2037,115 @@ QP::cleanup()
   work_cleanup(work, n_constraints());
 }
 
+// reference dense/compute_ECJ.hpp:29-132 (compute_backward) and :134-189
+// (compute_backward_loss_ESG), restated literally -- including the way the inequality part of
+// the right-hand side is scaled once per loop iteration (:100-112) and the index used for the
+// inactive entries of dz (:139-146).  No box constraints (the reference ignores them here).
+void
+QP::compute_backward(const double* loss_derivative, double eps, double rho_new, double mu_new)
+{
+  if (results.info.status == PQP_DUAL_INFEASIBLE)
+    throw std::invalid_argument("the QP problem is not feasible, so computing the derivatives is not valid "
+                                "in this setting. Try enabling infeasible solving if the problem is only "
+                                "primally infeasible.");
+  const isize n = model.dim, n_eq = model.n_eq, n_in = model.n_in;
+  Workspace& w = work;
+  BackwardData& bd = backward_data;
+  bd.dL_dH.assign(size_t(n * n), 0.0);
+  bd.dL_dg.assign(size_t(n), 0.0);
+  bd.dL_dA.assign(size_t(n_eq * n), 0.0);
+  bd.dL_db.assign(size_t(n_eq), 0.0);
+  bd.dL_dC.assign(size_t(n_in * n), 0.0);
+  bd.dL_du.assign(size_t(n_in), 0.0);
+  bd.dL_dl.assign(size_t(n_in), 0.0);
+  // derive solution: active sets at (x, z) on the unscaled model (:48-57)
+  isize numactive = 0;
+  Vec ctz(size_t(n_in), 0.0); // the reference resizes work.CTz (dim entries) to n_in here
+  for (isize i = 0; i < n_in; ++i) {
+    double cx = 0;
+    for (isize k = 0; k < n; ++k)
+      cx += model.C[size_t(i * n + k)] * results.x[size_t(k)];
+    ctz[size_t(i)] = cx + results.z[size_t(i)];
+    w.active_set_up[size_t(i)] = (ctz[size_t(i)] - model.u[size_t(i)]) >= 0.;
+    w.active_set_low[size_t(i)] = (ctz[size_t(i)] - model.l[size_t(i)]) <= 0.;
+    w.active_inequalities[size_t(i)] = w.active_set_up[size_t(i)] || w.active_set_low[size_t(i)];
+    numactive += w.active_inequalities[size_t(i)] ? 1 : 0;
+  }
+  const isize inner_pb_dim = n + n_eq + numactive;
+  zero(w.rhs);
+  results.info.rho = rho_new;
+  results.info.mu_eq = mu_new;
+  results.info.mu_in = mu_new;
+  // factorisation from scratch with the new proximal parameters, then the active set (:66-86)
+  setup_factorization(*this);
+  w.n_c = 0;
+  for (isize i = 0; i < n_in; ++i) {
+    w.current_bijection_map[size_t(i)] = i;
+    w.new_bijection_map[size_t(i)] = i;
+  }
+  active_set_change(*this);
+  w.constraints_changed = false;
+  // right-hand side (:88-112)
+  for (isize i = 0; i < n + n_eq + n_in; ++i)
+    w.rhs[size_t(i)] = -loss_derivative[i];
+  for (isize k = 0; k < n; ++k)
+    w.rhs[size_t(k)] *= ruiz.delta[size_t(k)] * ruiz.c; // scale_dual_residual_in_place
+  bool eq_zero = true;
+  for (isize k = 0; k < n_eq; ++k)
+    eq_zero = eq_zero && w.rhs[size_t(n + k)] == 0.0;
+  if (!eq_zero)
+    for (isize k = 0; k < n_eq; ++k)
+      w.rhs[size_t(n + k)] = -loss_derivative[n + k] * ruiz.delta[size_t(n + k)]; // ..._eq
+  bool in_zero = true;
+  for (isize k = 0; k < n_in; ++k)
+    in_zero = in_zero && w.rhs[size_t(n + n_eq + k)] == 0.0;
+  if (!in_zero) {
+    for (isize i = 0; i < n_in; ++i) {
+      const isize j = w.current_bijection_map[size_t(i)];
+      if (j < w.n_c)
+        w.rhs[size_t(j + n + n_eq)] = -loss_derivative[i + n + n_eq];
+      for (isize k = 0; k < n_in; ++k) // scale_primal_residual_in_place_in, inside the loop (:107-111)
+        w.rhs[size_t(n + n_eq + k)] *= ruiz.delta[size_t(n + n_eq + k)];
+    }
+  }
+  iterative_solve_with_permut_fact(*this, eps, inner_pb_dim);
+  // compute_backward_loss_ESG (:134-189)
+  zero(w.active_part_z);
+  for (isize j = 0; j < n_in; ++j) {
+    const isize i = w.current_bijection_map[size_t(j)];
+    if (i < w.n_c)
+      w.active_part_z[size_t(j)] = w.dw_aug[size_t(n + n_eq + i)];
+    else
+      w.active_part_z[size_t(j)] = loss_derivative[n + n_eq + i];
+  }
+  for (isize j = 0; j < n_in; ++j)
+    w.dw_aug[size_t(n + n_eq + j)] = w.active_part_z[size_t(j)];
+  for (isize k = 0; k < n; ++k)
+    w.dw_aug[size_t(k)] *= ruiz.delta[size_t(k)]; // unscale_primal_in_place
+  for (isize k = 0; k < n_eq; ++k)
+    w.dw_aug[size_t(n + k)] = w.dw_aug[size_t(n + k)] * ruiz.delta[size_t(n + k)] / ruiz.c;
+  for (isize k = 0; k < n_in; ++k)
+    w.dw_aug[size_t(n + n_eq + k)] =
+      w.dw_aug[size_t(n + n_eq + k)] * ruiz.delta[size_t(n + n_eq + k)] / ruiz.c;
+  const double* dx = w.dw_aug.data();
+  const double* dy = w.dw_aug.data() + n;
+  const double* dz = w.dw_aug.data() + n + n_eq;
+  for (isize i = 0; i < n_in; ++i) {
+    for (isize k = 0; k < n; ++k)
+      bd.dL_dC[size_t(i * n + k)] = dz[i] * results.x[size_t(k)] + results.z[size_t(i)] * dx[k];
+    bd.dL_du[size_t(i)] = w.active_set_up[size_t(i)] ? -dz[i] : 0.0;
+    bd.dL_dl[size_t(i)] = w.active_set_low[size_t(i)] ? -dz[i] : 0.0;
+  }
+  for (isize i = 0; i < n_eq; ++i) {
+    for (isize k = 0; k < n; ++k)
+      bd.dL_dA[size_t(i * n + k)] = dy[i] * results.x[size_t(k)] + results.y[size_t(i)] * dx[k];
+    bd.dL_db[size_t(i)] = -dy[i];
+  }
+  for (isize i = 0; i < n; ++i) {
+    for (isize k = 0; k < n; ++k)
+      bd.dL_dH[size_t(i * n + k)] = 0.5 * (dx[i] * results.x[size_t(k)] + results.x[size_t(i)] * dx[k]);
+    bd.dL_dg[size_t(i)] = dx[i];
+  }
+}
+
 } // namespace pqo

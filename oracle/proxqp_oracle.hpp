@@ -69,6 +69,12 @@ struct Results
   pqp_info info;
 };
 
+// reference dense/backward_data.hpp:27-133: jacobians of the loss wrt the model (row-major)
+struct BackwardData
+{
+  Vec dL_dH, dL_dg, dL_dA, dL_db, dL_dC, dL_du, dL_dl;
+};
+
 // reference preconditioner/ruiz.hpp:316-358
 struct Ruiz
 {
@@ -132,6 +138,10 @@ struct QP
   void solve(const double* x, const double* y, const double* z);
   // wrapper.hpp:958-962
   void cleanup();
+  // dense/compute_ECJ.hpp:29-189 (compute_backward + compute_backward_loss_ESG): derivatives of a
+  // loss wrt (H, g, A, b, C, u, l) given dL/d(x, y, z) at the solution of a solved QP
+  BackwardData backward_data;
+  void compute_backward(const double* loss_derivative, double eps, double rho_new, double mu_new);
 
   isize n_constraints() const { return model.n_in + (box_constraints ? model.dim : 0); }
 };
