@@ -102,6 +102,22 @@ int pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count);
  * NULL (the default) is the null stream.  Calls stay synchronous with respect to the host. */
 int pqp_batch_set_stream(pqp_batch* h, void* stream);
 
+/* dense::compute_backward / solve_backward_in_parallel (reference dense/compute_ECJ.hpp:29-189,
+ * parallel/qp_solve.hpp:83-137): derivatives of a loss wrt (H, g, A, b, C, u, l) of SOLVED QPs.
+ * `loss_derivatives` is [B][dim + n_eq + n_in] = dL/d(x, y, z) per QP (for _range: [count][...],
+ * the QPs first .. first+count-1); eps / rho_backward / mu_backward default to 1e-4 / 1e-6 / 1e-6
+ * in the reference.  One kernel launch, one workgroup per QP.  Returns
+ * PQP_ERR_INVALID_ARGUMENT (the reference throws std::invalid_argument) if a QP of the range is
+ * dual infeasible, PQP_ERR_UNSUPPORTED with box constraints. */
+int pqp_batch_backward(pqp_batch* h, const double* loss_derivatives, double eps, double rho_backward,
+                       double mu_backward);
+int pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const double* loss_derivatives,
+                             double eps, double rho_backward, double mu_backward);
+/* Model::backward_data (reference dense/backward_data.hpp:27-133) of QP idx (-1: the whole
+ * batch, arrays [B][...]); row-major; any pointer may be NULL. */
+int pqp_batch_get_backward(pqp_batch* h, int64_t idx, double* dL_dH, double* dL_dg, double* dL_dA,
+                           double* dL_db, double* dL_dC, double* dL_du, double* dL_dl);
+
 /* QP::results (x, y, z, se, si, info); any output pointer may be NULL. */
 int pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z, double* se,
                           double* si, pqp_info* info);

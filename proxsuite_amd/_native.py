@@ -35,7 +35,8 @@ class NativeLib:
     SYMBOLS = ("pqp_last_error", "pqp_device_count", "pqp_batch_create", "pqp_batch_destroy",
                "pqp_batch_size", "pqp_batch_dense_backend", "pqp_batch_settings", "pqp_batch_init",
                "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_flush",
-               "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_set_stream", "pqp_batch_get_results", "pqp_batch_result_device_ptrs",
+               "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_set_stream", "pqp_batch_backward", "pqp_batch_backward_range",
+               "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs",
                "pqp_batch_get_scaled", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
                "pqp_batch_launch_config")
 
@@ -61,6 +62,9 @@ class NativeLib:
         L.pqp_batch_solve.argtypes = [vp]
         L.pqp_batch_solve_range.argtypes = [vp, C.c_int64, C.c_int64]
         L.pqp_batch_set_stream.argtypes = [vp, vp]
+        L.pqp_batch_backward.argtypes = [vp, _DP] + [C.c_double] * 3
+        L.pqp_batch_backward_range.argtypes = [vp, C.c_int64, C.c_int64, _DP] + [C.c_double] * 3
+        L.pqp_batch_get_backward.argtypes = [vp, C.c_int64] + [_DP] * 7
         L.pqp_batch_get_results.argtypes = [vp, C.c_int64] + [_DP] * 5 + [C.POINTER(pqp_info)]
         L.pqp_batch_result_device_ptrs.argtypes = [vp] + [C.POINTER(_DP)] * 3
         L.pqp_batch_get_scaled.argtypes = [vp, C.c_int64] + [_DP] * 9
@@ -215,6 +219,42 @@ class Batch:
             self.lib.check(self.lib.L.pqp_batch_solve(self._h))
         else:
             self.lib.check(self.lib.L.pqp_batch_solve_range(self._h, int(first), int(1 if count is None else count)))
+
+    def backward(self, loss_derivatives, eps=1e-4, rho_backward=1e-6, mu_backward=1e-6, first=None, count=None):
+        """dense::compute_backward for the whole batch (or the QPs first .. first+count-1).
+        `loss_derivatives`: [B or count, n + n_eq + n_in] (numpy or torch, host or device)."""
+        ntot = self.n + self.n_eq + self.n_in
+        rows = self.B if first is None else int(1 if count is None else count)
+        k, p = _as_array(loss_derivatives, (rows, ntot), "loss_derivatives")
+        if first is None:
+            self.lib.check(self.lib.L.pqp_batch_backward(self._h, p, float(eps), float(rho_backward),
+                                                         float(mu_backward)))
+        else:
+            self.lib.check(self.lib.L.pqp_batch_backward_range(self._h, int(first), rows, p, float(eps),
+                                                               float(rho_backward), float(mu_backward)))
+
+    def backward_results(self, idx=-1, into=None):
+        """Model::backward_data as a dict of numpy arrays (or filled into the given tensors/arrays)."""
+        pre = (self.B,) if idx < 0 else ()
+        n, ne, ni = self.n, self.n_eq, self.n_in
+        shapes = dict(dL_dH=pre + (n, n), dL_dg=pre + (n,), dL_dA=pre + (ne, n), dL_db=pre + (ne,),
+                      dL_dC=pre + (ni, n), dL_du=pre + (ni,), dL_dl=pre + (ni,))
+        out = into if into is not None else {k: np.zeros(v) for k, v in shapes.items()}
+        ptrs = []
+        for name in ("dL_dH", "dL_dg", "dL_dA", "dL_db", "dL_dC", "dL_du", "dL_dl"):
+            buf = out.get(name)
+            if buf is None or (hasattr(buf, "numel") and buf.numel() == 0) or (
+                    not hasattr(buf, "numel") and buf.size == 0):
+                ptrs.append(None)
+            elif hasattr(buf, "data_ptr"):
+                import torch
+                if buf.dtype != torch.float64 or not buf.is_contiguous() or tuple(buf.shape) != shapes[name]:
+                    raise ValueError("backward_results: %s must be contiguous float64 of shape %s" % (name, shapes[name]))
+                ptrs.append(C.cast(buf.data_ptr(), _DP))
+            else:
+                ptrs.append(buf.ctypes.data_as(_DP))
+        self.lib.check(self.lib.L.pqp_batch_get_backward(self._h, int(idx), *ptrs))
+        return out
 
     def set_stream(self, stream):
         """`stream`: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""

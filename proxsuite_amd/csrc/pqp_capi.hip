@@ -79,6 +79,14 @@ pqp_solve_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
   pqp::solve_body<NT>(batch, first + slot, (pqp::lptr)smem);
 }
 
+template<int NT>
+__global__ __launch_bounds__(NT, 2) void
+pqp_backward_kernel(pqp::Batch batch, pqp::BackwardArgs bw)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  pqp::backward_body<NT>(batch, bw, (long)blockIdx.x, (pqp::lptr)smem);
+}
+
 // Dispatch order for the next whole-batch launch: QP i goes to position
 // rank(i) = #{ j : cycles_j > cycles_i  or  (cycles_j == cycles_i and j < i) }  (descending by the
 // device cycles of the solve that just finished; O(B^2) compares, a few microseconds for B ~ 10^3-10^4).
@@ -130,6 +138,9 @@ struct pqp_batch
   // counts (stats[q][0]) order the NEXT whole-batch solve, most expensive QP first.  QPs are
   // independent, so the order changes nothing but the tail of the launch.  PQP_SCHEDULE=fifo
   // disables it.
+  // QPLayer backward outputs ([B][...], allocated at the first pqp_batch_backward)
+  double *bw_dH = nullptr, *bw_dg = nullptr, *bw_dA = nullptr, *bw_db = nullptr, *bw_dC = nullptr,
+         *bw_du = nullptr, *bw_dl = nullptr, *bw_ld = nullptr;
   bool lpt = true;
   bool order_valid = false;
   int* d_order = nullptr;
@@ -359,6 +370,21 @@ enqueue_setup(pqp_batch* h, int64_t idx, bool update_call, const double* H, cons
   return PQP_OK;
 }
 
+} // namespace
+
+namespace {
+template<int NT>
+int
+launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count)
+{
+  if (h->lds_solve > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_backward_kernel<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
+  hipLaunchKernelGGL((pqp_backward_kernel<NT>), dim3((unsigned)count), dim3(NT), h->lds_solve, h->stream,
+                     h->dev, bw);
+  HIP_TRY(hipGetLastError());
+  return PQP_OK;
+}
 } // namespace
 
 extern "C" {
@@ -700,6 +726,110 @@ pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
   }
   // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
   std::fill(h->is_initialized.begin() + first, h->is_initialized.begin() + first + count, char(1));
+  return PQP_OK;
+}
+
+int
+pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const double* loss_derivatives,
+                         double eps, double rho_backward, double mu_backward)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  const pqp::Dims& d = h->dev.d;
+  if (first < 0 || count < 0 || first + count > h->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "backward range outside the batch");
+  if (d.box)
+    return fail(PQP_ERR_UNSUPPORTED, "compute_backward is defined for QPs without box constraints "
+                                     "(reference dense/compute_ECJ.hpp ignores them)");
+  if (!loss_derivatives)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "loss_derivatives is required");
+  if (count == 0)
+    return PQP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->cmd_pending)
+    if (int rc = pqp_batch_flush(h))
+      return rc;
+  const size_t B = size_t(h->dev.B), n = size_t(d.n), ne = size_t(d.n_eq), ni = size_t(d.n_in);
+  const size_t ntot = n + ne + ni;
+  // the reference throws for a dual infeasible QP (compute_ECJ.hpp:37-45)
+  {
+    std::vector<pqp_info> info;
+    info.resize(size_t(count));
+    HIP_TRY(hipMemcpy(info.data(), h->dev.info + first, size_t(count) * sizeof(pqp_info), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < count; ++i)
+      if (info[size_t(i)].status == PQP_DUAL_INFEASIBLE)
+        return fail(PQP_ERR_INVALID_ARGUMENT,
+                    "the QP problem is not feasible, so computing the derivatives is not valid in this setting. "
+                    "Try enabling infeasible solving if the problem is only primally infeasible.");
+  }
+  if (!h->bw_dH) {
+    int rc = 0;
+    if ((rc = dalloc(h, &h->bw_dH, B * n * n)) || (rc = dalloc(h, &h->bw_dg, B * n)) ||
+        (rc = dalloc(h, &h->bw_dA, B * ne * n)) || (rc = dalloc(h, &h->bw_db, B * ne)) ||
+        (rc = dalloc(h, &h->bw_dC, B * ni * n)) || (rc = dalloc(h, &h->bw_du, B * ni)) ||
+        (rc = dalloc(h, &h->bw_dl, B * ni)) || (rc = dalloc(h, &h->bw_ld, B * ntot)))
+      return rc;
+  }
+  HIP_TRY(hipMemcpy(h->bw_ld, loss_derivatives, size_t(count) * ntot * sizeof(double), hipMemcpyDefault));
+  if (int rc = upload_settings(h))
+    return rc;
+  pqp::BackwardArgs bw{};
+  bw.ld = h->bw_ld;
+  bw.eps = eps;
+  bw.rho_new = rho_backward;
+  bw.mu_new = mu_backward;
+  bw.dL_dH = h->bw_dH;
+  bw.dL_dg = h->bw_dg;
+  bw.dL_dA = h->bw_dA;
+  bw.dL_db = h->bw_db;
+  bw.dL_dC = h->bw_dC;
+  bw.dL_du = h->bw_du;
+  bw.dL_dl = h->bw_dl;
+  bw.first = long(first);
+  int rc = 0;
+  switch (h->nt) {
+    case 256:
+      rc = launch_backward<256>(h, bw, long(count));
+      break;
+    case 512:
+      rc = launch_backward<512>(h, bw, long(count));
+      break;
+    default:
+      rc = launch_backward<1024>(h, bw, long(count));
+  }
+  if (rc)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PQP_OK;
+}
+
+int
+pqp_batch_backward(pqp_batch* h, const double* loss_derivatives, double eps, double rho_backward,
+                   double mu_backward)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  return pqp_batch_backward_range(h, 0, h->dev.B, loss_derivatives, eps, rho_backward, mu_backward);
+}
+
+int
+pqp_batch_get_backward(pqp_batch* h, int64_t idx, double* dL_dH, double* dL_dg, double* dL_dA, double* dL_db,
+                       double* dL_dC, double* dL_du, double* dL_dl)
+{
+  if (int rc = check_idx(h, idx))
+    return rc;
+  if (!h->bw_dH)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_backward has not been called on this batch");
+  HIP_TRY(hipSetDevice(h->device));
+  const pqp::Dims& d = h->dev.d;
+  const size_t n = size_t(d.n), ne = size_t(d.n_eq), ni = size_t(d.n_in);
+  const int64_t B = h->dev.B;
+  int rc = 0;
+  if ((rc = copy_out(dL_dH, h->bw_dH, idx, B, n * n)) || (rc = copy_out(dL_dg, h->bw_dg, idx, B, n)) ||
+      (rc = copy_out(dL_dA, h->bw_dA, idx, B, ne * n)) || (rc = copy_out(dL_db, h->bw_db, idx, B, ne)) ||
+      (rc = copy_out(dL_dC, h->bw_dC, idx, B, ni * n)) || (rc = copy_out(dL_du, h->bw_du, idx, B, ni)) ||
+      (rc = copy_out(dL_dl, h->bw_dl, idx, B, ni)))
+    return rc;
   return PQP_OK;
 }
 

@@ -137,6 +137,17 @@ struct Batch
   long long* stats; // ST_COUNT per QP
 };
 
+// QPLayer backward (reference dense/compute_ECJ.hpp): inputs and outputs of one launch.
+// `ld` is [count][n + n_eq + n_in] (dL/dx, dL/dy, dL/dz of the QPs first .. first+count-1);
+// the seven outputs are batch-major arrays over the WHOLE batch ([B][...]).
+struct BackwardArgs
+{
+  const double* ld;
+  double eps, rho_new, mu_new;
+  double *dL_dH, *dL_dg, *dL_dA, *dL_db, *dL_dC, *dL_du, *dL_dl;
+  long first;
+};
+
 // LDS carve-up -------------------------------------------------------------------------
 // The ~45 per-QP vectors are grouped by length class (n, n_eq, n_c, n_in, n_d) so that every
 // LDS address is  base + (slot * class_length + class_offset)  : twelve scalars describe the
@@ -2513,7 +2524,155 @@ struct Solver
         gs[k] = L.stat()[k];
     }
   }
+
+  // ---- QPLayer backward: dense::compute_backward + compute_backward_loss_ESG
+  // (reference dense/compute_ECJ.hpp:29-132, :134-189), on the state a solve left behind.
+  // Same steps as the reference: active sets of the solution on the unscaled model, factorisation
+  // from scratch at (rho, mu) = (rho_new, mu_new), one refined KKT solve with right-hand side
+  // -dL/d(x, y, z_active) in the equilibrated space, then the seven outer products.  The
+  // reference's quirks are kept: the inequality part of the right-hand side is scaled by delta_in
+  // once per loop iteration after the entry is written (:100-112, position-indexed), and the
+  // inactive entries of dz take loss_derivative at their PERMUTED position (:139-146).
+  __device__ __forceinline__ void backward(const BackwardArgs& bw, long slot_in_launch)
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in;
+    const long ntot = (long)n + ne + ni;
+    cgptr ld = (cgptr)(bw.ld + slot_in_launch * ntot);
+    for (int k = threadIdx.x; k < ST_COUNT; k += NT)
+      L.stat()[k] = 0;
+    State W = *P.state();
+    info.load(*P.info());
+    ruiz_c = W.ruiz_c;
+    const double c = ruiz_c;
+    vload(L.x(), P.x(), n);
+    vload(L.y(), P.y(), ne);
+    vload(L.z(), P.z(), ni);
+    cgptr dX = P.dlt_x(), dE = P.dlt_eq(), dI = P.dlt_in();
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.dx()[k] = P.x()[k] / dX[k]; // x in the equilibrated space
+    for (int i = threadIdx.x; i < ni; i += NT) {
+      L.aflags()[i] = 0;
+      L.slot_of()[i] = -1;
+    }
+    for (int k = threadIdx.x; k < d.nd; k += NT)
+      L.zvalid()[k] = 0;
+    z_all_valid = false;
+    __syncthreads();
+    // active sets at the solution (compute_ECJ.hpp:48-57):  C x + z - u >= 0,  C x + z - l <= 0
+    if (ni > 0) {
+      mv(P.CTs(), ni, n, ni, L.dx(), L.Cdx());
+      cgptr gu = P.u(), gl = P.l();
+      for (int i = threadIdx.x; i < ni; i += NT) {
+        const double ctz = L.Cdx()[i] / dI[i] + L.z()[i];
+        const bool up = (ctz - gu[i]) >= 0., lo = (ctz - gl[i]) <= 0.;
+        L.aflags()[i] = (up ? 1 : 0) | (lo ? 2 : 0) | ((up || lo) ? 4 : 0);
+      }
+      __syncthreads();
+    }
+    info.rho = bw.rho_new;
+    info.mu_eq = bw.mu_new;
+    info.mu_in = bw.mu_new;
+    // setup_factorization + active_set_change from the empty set (:66-86)
+    factor_primal_block();
+    n_c = 0;
+    r = ne;
+    schur_dirty = true;
+    apply_active_set();
+    const int na = n_c;
+    // right-hand side (:88-112)
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.rx()[k] = -ld[k] * (dX[k] * c);
+    for (int k = threadIdx.x; k < ne; k += NT)
+      L.rd()[k] = -ld[n + k] * dE[k];
+    double in_any = 0.0;
+    for (int i = threadIdx.x; i < ni; i += NT)
+      in_any = fmax(in_any, fabs(ld[n + ne + i]));
+    in_any = R.max(in_any);
+    for (int i = threadIdx.x; i < ni; i += NT) {
+      const int a = L.slot_of()[i];
+      if (a >= 0) {
+        double v = 0.0;
+        if (in_any != 0.0) {
+          // written at loop iteration i of the reference, then scaled by delta_in[position a]
+          // at iterations i, i+1, ..., n_in-1
+          v = -ld[n + ne + i];
+          const double s = dI[a];
+          for (int t = i; t < ni; ++t)
+            v *= s;
+        }
+        L.rd()[ne + a] = v;
+      }
+    }
+    __syncthreads();
+    iterative_solve(bw.eps);
+    // compute_backward_loss_ESG (:134-189): unpermute dz, unscale, outer products
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.ex()[k] = L.dx()[k] * dX[k];
+    for (int k = threadIdx.x; k < ne; k += NT)
+      L.ed()[k] = L.sd()[k] * dE[k] / c;
+    for (int j = threadIdx.x; j < ni; j += NT) {
+      const int a = L.slot_of()[j];
+      double v;
+      if (a >= 0) {
+        v = L.sd()[ne + a];
+      } else {
+        // permuted position of an inactive constraint after active_set_change from the identity
+        // map: j + #{active i > j}
+        int before = 0;
+        for (int t = 0; t < na; ++t)
+          before += (L.act()[t] < j) ? 1 : 0;
+        v = ld[n + ne + (j + na - before)];
+      }
+      L.zfull()[j] = v * dI[j] / c;
+    }
+    __syncthreads();
+    {
+      const long q0 = q;
+      gptr oH = (gptr)(bw.dL_dH + q0 * n * n), og = (gptr)(bw.dL_dg + q0 * n);
+      gptr oA = (gptr)(bw.dL_dA + q0 * ne * n), ob = (gptr)(bw.dL_db + q0 * ne);
+      gptr oC = (gptr)(bw.dL_dC + q0 * ni * n), ou = (gptr)(bw.dL_du + q0 * ni), ol = (gptr)(bw.dL_dl + q0 * ni);
+      clptr dxu = L.ex(), dyu = L.ed(), dzu = L.zfull(), xs = L.x(), ys = L.y(), zs = L.z();
+      for (int o = threadIdx.x; o < n * n; o += NT) {
+        const int i = o / n, k = o - i * n;
+        oH[o] = 0.5 * (dxu[i] * xs[k] + xs[i] * dxu[k]);
+      }
+      for (int k = threadIdx.x; k < n; k += NT)
+        og[k] = dxu[k];
+      for (int o = threadIdx.x; o < ne * n; o += NT) {
+        const int i = o / n, k = o - i * n;
+        oA[o] = dyu[i] * xs[k] + ys[i] * dxu[k];
+      }
+      for (int k = threadIdx.x; k < ne; k += NT)
+        ob[k] = -dyu[k];
+      for (int o = threadIdx.x; o < ni * n; o += NT) {
+        const int i = o / n, k = o - i * n;
+        oC[o] = dzu[i] * xs[k] + zs[i] * dxu[k];
+      }
+      for (int i = threadIdx.x; i < ni; i += NT) {
+        ou[i] = (L.aflags()[i] & 1) ? -dzu[i] : 0.0;
+        ol[i] = (L.aflags()[i] & 2) ? -dzu[i] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // like the reference, the proximal parameters of `results.info` keep the backward values;
+      // the factorisation in HBM no longer belongs to a forward solve
+      info.store(*P.info());
+      W.factor_valid = 0;
+      W.ls_valid = 0;
+      W.dirty = 1;
+      *P.state() = W;
+    }
+  }
 };
+
+template<int NT>
+__device__ __forceinline__ void
+backward_body(const Batch& batch, const BackwardArgs& bw, long slot, lptr lds_base)
+{
+  Solver<NT> S(batch, bw.first + slot, lds_base);
+  S.backward(bw, slot);
+}
 
 template<int NT>
 __device__ __forceinline__ void

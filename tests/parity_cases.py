@@ -317,3 +317,47 @@ def case_determinism(lib, randqp, n=20, ne=5, ni=8, B=6):
         out.append(b.results()[0].copy())
         b.close()
     assert np.array_equal(out[0], out[1])
+
+
+def case_backward(lib, oracle, randqp, n=10, ne=4, ni=7, B=6, with_dual_terms=True):
+    """QPLayer backward (reference dense/compute_ECJ.hpp:29-189; test/src/dense_backward.cpp): the
+    seven loss jacobians of a solved batch against the oracle's literal restatement, with loss
+    derivatives on x only and on (x, y, z)."""
+    m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.85, 1e-1)
+    b = N.Batch(B, n, ne, ni, lib=lib)
+    settings_all(b, eps_abs=EPS, eps_rel=0)
+    b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
+    b.solve()
+    rng = np.random.default_rng(5)
+    ntot = n + ne + ni
+    for variant in range(2 if with_dual_terms else 1):
+        ld = np.zeros((B, ntot))
+        ld[:, :n] = rng.standard_normal((B, n))
+        if variant == 1:
+            ld[:, n:] = rng.standard_normal((B, ne + ni))
+        b.backward(ld, 1e-5, 1e-7, 1e-7)
+        got = b.backward_results(-1)
+        for i in range(B):
+            q = oracle.QP(n, ne, ni)
+            q.settings.eps_abs = EPS
+            q.settings.eps_rel = 0
+            q.init(m.H[i], m.g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i])
+            q.solve()
+            ref = q.compute_backward(ld[i], 1e-5, 1e-7, 1e-7)
+            for k, v in ref.items():
+                scale = 1 + (np.max(np.abs(v)) if v.size else 0.0)
+                assert np.max(np.abs(got[k][i] - v), initial=0.0) <= 1e-6 * scale, (variant, i, k)
+    # one QP of the batch alone (compute_backward on qps.get(i)) gives the same rows
+    b.solve()
+    ld1 = np.zeros((1, ntot))
+    ld1[0, :n] = 1.0
+    b.backward(ld1, 1e-5, 1e-7, 1e-7, first=2, count=1)
+    one = b.backward_results(2)
+    ldB = np.zeros((B, ntot))
+    ldB[:, :n] = 1.0
+    b.solve()
+    b.backward(ldB, 1e-5, 1e-7, 1e-7)
+    allr = b.backward_results(-1)
+    for k in one:
+        assert np.array_equal(one[k], allr[k][2]), k
+    b.close()

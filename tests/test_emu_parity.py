@@ -49,6 +49,11 @@ def test_matrix_core_fallback_paths(lib, oracle, randqp, shape):
     pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=2)
 
 
+@pytest.mark.parametrize("shape", [(10, 4, 7), (12, 0, 9), (9, 5, 0)])
+def test_backward(lib, oracle, randqp, shape):
+    pc.case_backward(lib, oracle, randqp, *shape, B=4)
+
+
 @pytest.mark.parametrize("guess", list(InitialGuess))
 def test_state_machine(lib, oracle, randqp, guess):
     pc.case_state_machine(lib, oracle, randqp, guess)

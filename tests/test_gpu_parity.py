@@ -49,6 +49,12 @@ def test_matrix_core_fallback_paths(lib, oracle, randqp, shape):
     pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=B)
 
 
+@pytest.mark.parametrize("shape", [(10, 4, 7, 16), (12, 0, 9, 8), (9, 5, 0, 8), (100, 50, 100, 32)])
+def test_backward(lib, oracle, randqp, shape):
+    n, ne, ni, B = shape
+    pc.case_backward(lib, oracle, randqp, n, ne, ni, B=B)
+
+
 def test_equality_constrained_initial_guess_batch(lib, oracle, randqp):
     pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=32,
                          guess=InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS)
