@@ -3,6 +3,7 @@
 #ifndef PROXSUITE_AMD_PROXQP_DENSE_DENSE_HPP
 #define PROXSUITE_AMD_PROXQP_DENSE_DENSE_HPP
 
+#include "proxsuite/proxqp/dense/compute_ECJ.hpp"
 #include "proxsuite/proxqp/dense/wrapper.hpp"
 
 #endif

@@ -13,9 +13,34 @@ namespace proxsuite {
 namespace proxqp {
 namespace dense {
 
+// jacobians of a loss wrt the model, filled by dense::compute_backward
+// (reference include/proxsuite/proxqp/dense/backward_data.hpp:27-133)
+template<typename T>
+struct BackwardData
+{
+  Mat<T> dL_dH;
+  Vec<T> dL_dg;
+  Mat<T> dL_dA;
+  Vec<T> dL_db;
+  Mat<T> dL_dC;
+  Vec<T> dL_du;
+  Vec<T> dL_dl;
+  void initialize(isize dim, isize n_eq, isize n_in)
+  {
+    dL_dH.resize(dim, dim);
+    dL_dg.resize(dim);
+    dL_dA.resize(n_eq, dim);
+    dL_db.resize(n_eq);
+    dL_dC.resize(n_in, dim);
+    dL_du.resize(n_in);
+    dL_dl.resize(n_in);
+  }
+};
+
 template<typename T>
 struct Model
 {
+  BackwardData<T> backward_data;
   Mat<T> H;
   Vec<T> g;
   Mat<T> A;

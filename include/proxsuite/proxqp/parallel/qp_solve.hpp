@@ -10,7 +10,7 @@
 
 #include <cstring>
 
-#include "proxsuite/proxqp/dense/wrapper.hpp"
+#include "proxsuite/proxqp/dense/compute_ECJ.hpp"
 
 namespace proxsuite {
 namespace proxqp {
@@ -58,6 +58,50 @@ solve_in_parallel(std::vector<QP<T>>& qps, const optional<usize> /*num_threads*/
 {
   for (auto& qp : qps)
     qp.solve();
+}
+
+// dense::qp_solve_backward_in_parallel (reference parallel/qp_solve.hpp:83-137): compute_backward
+// for every QP of the batch -- one pqp_batch_backward_range launch per device pool.
+template<typename T>
+void
+qp_solve_backward_in_parallel(optional<const usize> /*num_threads*/, BatchQP<T>& qps,
+                              std::vector<Vec<T>>& loss_derivatives, T eps = 1.E-4, T rho_new = 1.E-6,
+                              T mu_new = 1.E-6)
+{
+  if (isize(loss_derivatives.size()) != qps.size())
+    throw std::invalid_argument("wrong argument size: one loss derivative per QP is expected");
+  for (const auto& e : qps.pools()) {
+    const detail::Pool& p = *e.pool;
+    if (p.used == 0)
+      continue;
+    const usize ntot = usize(p.dim + p.n_eq + p.n_in);
+    std::vector<T> ld(usize(p.used) * ntot);
+    for (usize s = 0; s < e.members.size(); ++s) {
+      const Vec<T>& v = loss_derivatives[usize(e.members[s])];
+      if (usize(v.size()) != ntot)
+        detail::bad_size("the loss derivative has dim + n_eq + n_in entries.", v.size(), isize(ntot));
+      std::memcpy(ld.data() + s * ntot, v.data(), ntot * sizeof(T));
+      qps[e.members[s]].push_settings();
+    }
+    detail::check(pqp_batch_backward_range(p.h, 0, p.used, ld.data(), eps, rho_new, mu_new));
+    for (usize s = 0; s < e.members.size(); ++s) {
+      detail::pull_backward(qps[e.members[s]]);
+      qps[e.members[s]].pull();
+    }
+  }
+}
+
+template<typename T>
+void
+qp_solve_backward_in_parallel(optional<const usize> num_threads, std::vector<QP<T>>& qps,
+                              std::vector<Vec<T>>& loss_derivatives, T eps = 1.E-4, T rho_new = 1.E-6,
+                              T mu_new = 1.E-6)
+{
+  (void)num_threads;
+  if (loss_derivatives.size() != qps.size())
+    throw std::invalid_argument("wrong argument size: one loss derivative per QP is expected");
+  for (usize i = 0; i < qps.size(); ++i)
+    compute_backward<T>(qps[i], loss_derivatives[i], eps, rho_new, mu_new);
 }
 
 } // namespace dense

@@ -27,8 +27,9 @@ from .. import _native
 from .._ctypes_defs import (DenseBackend, HessianType, InitialGuess, MeritFunctionType, QPSolverOutput,
                             pqp_info, pqp_settings)
 
-__all__ = ["QP", "BatchQP", "VectorQP", "solve_in_parallel", "solve", "DenseBackend", "HessianType",
-           "InitialGuess", "QPSolverOutput", "MeritFunctionType", "Settings", "Results", "Info", "Model"]
+__all__ = ["QP", "BatchQP", "VectorQP", "VectorLossDerivatives", "solve_in_parallel", "solve",
+           "compute_backward", "solve_backward_in_parallel", "DenseBackend", "HessianType", "InitialGuess",
+           "QPSolverOutput", "MeritFunctionType", "Settings", "Results", "Info", "Model", "BackwardData"]
 
 _BOOL_SETTINGS = ("verbose", "update_preconditioner", "compute_preconditioner", "compute_timings",
                   "check_duality_gap", "bcl_update", "primal_infeasibility_solving")
@@ -94,11 +95,28 @@ class Results:
         self.x, self.y, self.z, self.se, self.si, self.info = x, y, z, se, si, Info(info)
 
 
+class BackwardData:
+    """`qp.model.backward_data` (reference dense/backward_data.hpp:27-133): the jacobians of the loss
+    wrt the model, filled by compute_backward / solve_backward_in_parallel."""
+
+    __slots__ = ("dL_dH", "dL_dg", "dL_dA", "dL_db", "dL_dC", "dL_du", "dL_dl")
+
+    def __init__(self, dim, n_eq, n_in):
+        self.dL_dH = np.zeros((dim, dim))
+        self.dL_dg = np.zeros(dim)
+        self.dL_dA = np.zeros((n_eq, dim))
+        self.dL_db = np.zeros(n_eq)
+        self.dL_dC = np.zeros((n_in, dim))
+        self.dL_du = np.zeros(n_in)
+        self.dL_dl = np.zeros(n_in)
+
+
 class Model:
     """`qp.model` (reference dense/model.hpp:24-63): the last data handed to init/update."""
 
     def __init__(self, dim, n_eq, n_in, box):
         self.dim, self.n_eq, self.n_in = dim, n_eq, n_in
+        self.backward_data = BackwardData(dim, n_eq, n_in)
         self.n_total = dim + n_eq + n_in
         self.H = np.zeros((dim, dim))
         self.g = np.zeros(dim)
@@ -354,6 +372,56 @@ def solve_in_parallel(qps, num_threads=None):
                 continue
             pool.solve(start, prev - start + 1)
             start = prev = s
+
+
+class VectorLossDerivatives(list):
+    """`std::vector<Vec<T>>` of loss derivatives (reference expose-parallel.hpp:29-31)."""
+
+    def append(self, v):
+        super().append(np.asarray(v, dtype=np.float64))
+
+
+def _store_backward(qp, rows, i):
+    bd = qp.model.backward_data
+    for name in BackwardData.__slots__:
+        setattr(bd, name, np.array(rows[name][i]))
+
+
+def compute_backward(qp, loss_derivative, eps=1e-4, rho_backward=1e-6, mu_backward=1e-6):
+    """dense::compute_backward (reference dense/compute_ECJ.hpp:29-132; python expose-backward.hpp):
+    fills qp.model.backward_data for one solved QP."""
+    ld = np.ascontiguousarray(np.asarray(loss_derivative, dtype=np.float64)).reshape(1, -1)
+    qp._pool.batch.backward(ld, eps, rho_backward, mu_backward, first=qp._slot, count=1)
+    out = qp._pool.batch.backward_results(qp._slot)
+    _store_backward(qp, {k: v[None] for k, v in out.items()}, 0)
+    qp._pool.touch()
+
+
+def solve_backward_in_parallel(num_threads=None, qps=None, loss_derivatives=None, eps=1e-4, rho_backward=1e-6,
+                               mu_backward=1e-6):
+    """dense::solve_backward_in_parallel (reference parallel/qp_solve.hpp:83-137; python
+    expose-parallel.hpp:48-82): compute_backward for every QP, one launch per device pool."""
+    if qps is None or loss_derivatives is None:
+        raise TypeError("qps and loss_derivatives are required")
+    qlist = list(qps) if not isinstance(qps, BatchQP) else [qps.get(i) for i in range(qps.size())]
+    if len(loss_derivatives) != len(qlist):
+        raise ValueError("wrong argument size: one loss derivative per QP is expected")
+    pools = {}
+    for qp, ld in zip(qlist, loss_derivatives):
+        pools.setdefault(id(qp._pool), (qp._pool, []))[1].append((qp._slot, qp, np.asarray(ld, dtype=np.float64)))
+    for pool, items in pools.values():
+        items.sort(key=lambda t: t[0])
+        slots = [t[0] for t in items]
+        if slots == list(range(slots[0], slots[0] + len(slots))):
+            ld = np.ascontiguousarray(np.stack([t[2] for t in items]))
+            pool.batch.backward(ld, eps, rho_backward, mu_backward, first=slots[0], count=len(slots))
+        else:
+            for s, _, v in items:
+                pool.batch.backward(v.reshape(1, -1), eps, rho_backward, mu_backward, first=s, count=1)
+        rows = pool.batch.backward_results(-1)
+        for s, qp, _ in items:
+            _store_backward(qp, rows, s)
+        pool.touch()
 
 
 def solve(H=None, g=None, A=None, b=None, C=None, l=None, u=None, x=None, y=None, z=None, eps_abs=None,

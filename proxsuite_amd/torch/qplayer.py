@@ -9,8 +9,11 @@ batch goes through ONE pqp_batch_init (pointers of the torch tensors, host or RO
 handed to the C-ABI as they are), ONE solve launch with one workgroup per QP, and the
 results are copied device-to-device into the output tensors.
 
-The backward pass (reference qplayer.py:172-253, dense/compute_ECJ.hpp) is the next row of
-the scope table and is not built yet: it raises.
+The backward pass (reference qplayer.py:172-253) is ONE pqp_batch_backward launch (the device
+form of dense/compute_ECJ.hpp's compute_backward for every QP of the batch) whose seven jacobians
+are copied device-to-device into the gradient tensors.  The closest-feasible variant
+(`structural_feasibility=False`) differentiates through the sparse backend in the reference
+(qplayer.py:371-552); that path is outside this repository's scope and raises.
 """
 from __future__ import annotations
 
@@ -88,13 +91,43 @@ def QPFunction(eps=1e-9, maxIter=1000, eps_backward=1.0e-4, rho_backward=1.0e-6,
             A, b = _expand(A_, nbatch, 3), _expand(b_, nbatch, 2)
             batch, x, y, z, _, _ = _solve_batch(Q, p, A, b, G, l, u, eps, maxIter, infeasible=False)
             ctx.batch = batch
+            ctx.dev = Q.device
+            ctx.dtype = Q.dtype
+            ctx.shapes = tuple(tuple(t_.shape) if t_.numel() else () for t_ in (Q_, p_, A_, b_, G_, l_, u_))
+            ctx.batched = (Q_.ndimension() == 3, p_.ndimension() == 2, A_.ndimension() == 3, b_.ndimension() == 2,
+                           G_.ndimension() == 3, l_.ndimension() == 2, u_.ndimension() == 2)
             return x.to(Q.dtype), y.to(Q.dtype), z.to(Q.dtype)
 
         @staticmethod
         def backward(ctx, dl_dzhat, dl_dlams, dl_dnus):
-            raise NotImplementedError(
-                "QPFunction backward (reference dense/compute_ECJ.hpp:29-189) is not part of this "
-                "round's scope (SURVEY.md section 8(f), rank 1)")
+            batch, dev = ctx.batch, ctx.dev
+            B, n, ne, ni = batch.B, batch.n, batch.n_eq, batch.n_in
+            ld = torch.zeros((B, n + ne + ni), dtype=torch.float64, device=dev)
+            ld[:, :n] = dl_dzhat
+            if dl_dlams is not None and ne:
+                ld[:, n:n + ne] = dl_dlams
+            if dl_dnus is not None and ni:
+                ld[:, n + ne:] = dl_dnus
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
+            batch.backward(ld, eps_backward, rho_backward, mu_backward)
+            opts = dict(dtype=torch.float64, device=dev)
+            out = dict(dL_dH=torch.empty((B, n, n), **opts), dL_dg=torch.empty((B, n), **opts),
+                       dL_dA=torch.empty((B, ne, n), **opts), dL_db=torch.empty((B, ne), **opts),
+                       dL_dC=torch.empty((B, ni, n), **opts), dL_du=torch.empty((B, ni), **opts),
+                       dL_dl=torch.empty((B, ni), **opts))
+            batch.backward_results(-1, into=out)
+            t = ctx.dtype
+
+            def shaped(g, like_batched, shape):
+                if g.numel() == 0 or len(shape) == 0:
+                    return None
+                # parameters shared by the batch receive the sum of the per-QP gradients
+                return (g if like_batched else g.sum(dim=0)).to(t).reshape(shape)
+
+            bt, sh = ctx.batched, ctx.shapes
+            names = ("dL_dH", "dL_dg", "dL_dA", "dL_db", "dL_dC", "dL_dl", "dL_du")
+            return tuple(shaped(out[k], bt[i], sh[i]) for i, k in enumerate(names))
 
     class QPFunctionFn_infeas(Function):
         @staticmethod
@@ -118,7 +151,7 @@ def QPFunction(eps=1e-9, maxIter=1000, eps_backward=1.0e-4, rho_backward=1.0e-6,
         @staticmethod
         def backward(ctx, dl_dzhat, dl_dlams, dl_dnus, dl_ds_e, dl_ds_i):
             raise NotImplementedError(
-                "QPFunction backward (reference dense/compute_ECJ.hpp:134-189) is not part of this "
-                "round's scope (SURVEY.md section 8(f), rank 1)")
+                "the backward of the closest-feasible QPFunction differentiates through the sparse backend in "
+                "the reference (qplayer.py:371-552), which is outside this repository's scope")
 
     return QPFunctionFn.apply if structural_feasibility else QPFunctionFn_infeas.apply

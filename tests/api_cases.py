@@ -197,3 +197,89 @@ def case_qpfunction(QPFunction, oracle, randqp, device="cpu", B=5):
     out = QPFunction(eps=1e-9, structural_feasibility=False)(Q, p, A, b, G, l, u)
     assert len(out) == 5 and out[2].shape == (B, ni) and out[4].shape == (B, ni)
     np.testing.assert_allclose(out[0].cpu().numpy(), x.cpu().numpy(), atol=1e-6)
+
+
+def case_backward_api(dense, oracle, randqp):
+    """compute_backward / solve_backward_in_parallel / model.backward_data (reference
+    expose-backward.hpp, expose-parallel.hpp:48-82) against the oracle."""
+    n, ne, ni, B = 9, 3, 5, 4
+    qps = dense.BatchQP(B)
+    datas, lds = [], dense.VectorLossDerivatives()
+    rng = np.random.default_rng(2)
+    for i in range(B):
+        d = _qp_data(randqp, n, ne, ni, 40 + i)
+        qp = qps.init_qp_in_place(n, ne, ni)
+        qp.settings.eps_abs = 1e-9
+        qp.init(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"])
+        datas.append(d)
+        ld = np.zeros(n + ne + ni)
+        ld[:n] = rng.standard_normal(n)
+        lds.append(ld)
+    dense.solve_in_parallel(qps)
+    dense.solve_backward_in_parallel(None, qps, lds, 1e-5, 1e-7, 1e-7)
+    for i, d in enumerate(datas):
+        o = oracle.QP(n, ne, ni)
+        o.settings.eps_abs = 1e-9
+        o.init(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"])
+        o.solve()
+        ref = o.compute_backward(lds[i], 1e-5, 1e-7, 1e-7)
+        bd = qps.get(i).model.backward_data
+        for k, v in ref.items():
+            np.testing.assert_allclose(getattr(bd, k), v, atol=1e-6 * (1 + np.max(np.abs(v), initial=0.0)))
+    # single-QP entry point
+    q1 = qps.get(1)
+    before = np.array(q1.model.backward_data.dL_dg)
+    q1.solve()
+    dense.compute_backward(q1, lds[1], 1e-5, 1e-7, 1e-7)
+    np.testing.assert_allclose(q1.model.backward_data.dL_dg, before, atol=1e-9)
+
+
+def case_qpfunction_backward(QPFunction, device="cpu"):
+    """torch.autograd through QPFunction: gradients of L = sum(w * x*) wrt p, b, u (batched) and Q
+    (shared across the batch) against central finite differences of the forward."""
+    import torch
+    torch.manual_seed(0)
+    B, n, ne, ni = 3, 6, 2, 4
+    M = torch.randn(n, n, dtype=torch.float64)
+    Q = (M @ M.T + torch.eye(n, dtype=torch.float64)).to(device).requires_grad_(True)   # shared
+    p = torch.randn(B, n, dtype=torch.float64, device=device, requires_grad=True)
+    A = torch.randn(B, ne, n, dtype=torch.float64, device=device)
+    xs = torch.randn(B, n, dtype=torch.float64, device=device)
+    b = torch.einsum("bij,bj->bi", A, xs).detach().requires_grad_(True)
+    G = torch.randn(B, ni, n, dtype=torch.float64, device=device)
+    u = (torch.einsum("bij,bj->bi", G, xs) + 0.05).detach().requires_grad_(True)
+    l = torch.full((B, ni), -1.0e20, dtype=torch.float64, device=device)
+    w = torch.randn(B, n, dtype=torch.float64, device=device)
+    f = QPFunction(eps=1e-10, maxIter=1000, eps_backward=1e-9, rho_backward=1e-9, mu_backward=1e-9)
+
+    def loss(Q_, p_, b_, u_):
+        x, _, _ = f(Q_, p_, A, b_, G, l, u_)
+        return (w * x).sum()
+
+    L = loss(Q, p, b, u)
+    L.backward()
+    h = 1e-6
+    with torch.no_grad():
+        for (bi, k) in [(0, 0), (1, 3), (2, 5)]:
+            pp, pm = p.clone(), p.clone()
+            pp[bi, k] += h; pm[bi, k] -= h
+            fd = (loss(Q, pp, b, u) - loss(Q, pm, b, u)) / (2 * h)
+            assert abs(fd.item() - p.grad[bi, k].item()) < 1e-5
+        for (bi, k) in [(0, 1), (2, 0)]:
+            bp, bm = b.clone(), b.clone()
+            bp[bi, k] += h; bm[bi, k] -= h
+            fd = (loss(Q, p, bp, u) - loss(Q, p, bm, u)) / (2 * h)
+            assert abs(fd.item() - b.grad[bi, k].item()) < 1e-5
+        for (bi, k) in [(0, 0), (1, 2), (2, 3)]:
+            up, um = u.clone(), u.clone()
+            up[bi, k] += h; um[bi, k] -= h
+            fd = (loss(Q, p, b, up) - loss(Q, p, b, um)) / (2 * h)
+            assert abs(fd.item() - u.grad[bi, k].item()) < 1e-5
+        for (i, j) in [(0, 0), (1, 4)]:
+            Qp, Qm = Q.clone(), Q.clone()
+            Qp[i, j] += h; Qp[j, i] += h if i != j else 0
+            Qm[i, j] -= h; Qm[j, i] -= h if i != j else 0
+            fd = (loss(Qp, p, b, u) - loss(Qm, p, b, u)) / (2 * h)
+            ref = Q.grad[i, j] + (Q.grad[j, i] if i != j else 0)
+            assert abs(fd.item() - ref.item()) < 1e-5
+    assert Q.grad.shape == Q.shape and p.grad.shape == p.shape

@@ -191,6 +191,58 @@ main(int argc, char** argv)
     CHECK(pri <= eps_abs && dua <= eps_abs);
   }
 
+  // --- dense_backward.cpp:16-80: dx/dg from compute_backward against central finite differences
+  {
+    const isize bd = 10, be = 5, bi = 0;
+    utils::rand::set_seed(1);
+    dense::Model<T> m = utils::dense_strongly_convex_qp(bd, be, bi, 0.85, 1e-1);
+    dense::QP<T> qp{ bd, be, bi };
+    qp.settings.eps_abs = eps_abs;
+    qp.settings.eps_rel = 0;
+    qp.init(m.H, m.g, m.A, m.b, nullopt, nullopt, nullopt);
+    qp.solve();
+    dense::Vec<T> loss_derivative(bd + be + bi);
+    dense::Mat<T> dx_dg(bd, bd);
+    for (isize i = 0; i < bd; ++i) {
+      loss_derivative[i] = 1;
+      dense::compute_backward<T>(qp, loss_derivative, 1e-5, 1e-7, 1e-7);
+      for (isize j = 0; j < bd; ++j)
+        dx_dg(i, j) = qp.model.backward_data.dL_dg[j];
+      loss_derivative[i] = 0;
+    }
+    const T h = 1e-5;
+    for (isize i = 0; i < bd; ++i) {
+      dense::Vec<T> gp = m.g, gm = m.g;
+      gp[i] += h;
+      gm[i] -= h;
+      dense::QP<T> qp2{ bd, be, bi };
+      qp2.settings.eps_abs = eps_abs;
+      qp2.init(m.H, gp, m.A, m.b, nullopt, nullopt, nullopt);
+      qp2.solve();
+      dense::Vec<T> xp = qp2.results.x;
+      qp2.init(m.H, gm, m.A, m.b, nullopt, nullopt, nullopt);
+      qp2.solve();
+      for (isize r = 0; r < bd; ++r)
+        CHECK(std::fabs((xp[r] - qp2.results.x[r]) / (2 * h) - dx_dg(r, i)) < 1e-5);
+    }
+    // batch form
+    dense::BatchQP<T> bq(2);
+    std::vector<dense::Vec<T>> lds;
+    for (int k = 0; k < 2; ++k) {
+      auto& q = bq.init_qp_in_place(bd, be, bi);
+      q.settings.eps_abs = eps_abs;
+      q.init(m.H, m.g, m.A, m.b, nullopt, nullopt, nullopt);
+      dense::Vec<T> ld(bd + be + bi);
+      ld[k] = 1;
+      lds.push_back(ld);
+    }
+    dense::solve_in_parallel(bq);
+    dense::qp_solve_backward_in_parallel<T>(nullopt, bq, lds, 1e-5, 1e-7, 1e-7);
+    for (int k = 0; k < 2; ++k)
+      for (isize j = 0; j < bd; ++j)
+        CHECK(std::fabs(bq[k].model.backward_data.dL_dg[j] - dx_dg(k, j)) < 1e-9);
+  }
+
   std::printf("facade_test: %d failure(s)\n", failures);
   return failures == 0 ? 0 : 1;
 }

@@ -47,6 +47,15 @@ def test_qpfunction_forward(dense, oracle, randqp):
     ac.case_qpfunction(QPFunction, oracle, randqp, device="cpu")
 
 
+def test_backward_api(dense, oracle, randqp):
+    ac.case_backward_api(dense, oracle, randqp)
+
+
+def test_qpfunction_backward(dense):
+    from proxsuite_amd.torch import QPFunction
+    ac.case_qpfunction_backward(QPFunction, device="cpu")
+
+
 def test_product_path_has_no_cpu_fallback():
     """Without a GPU the real library must refuse to load (no oracle, no emulator behind it)."""
     import torch

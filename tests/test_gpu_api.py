@@ -41,6 +41,16 @@ def test_qpfunction_forward(dense, oracle, randqp, device):
     ac.case_qpfunction(QPFunction, oracle, randqp, device=device)
 
 
+def test_backward_api(dense, oracle, randqp):
+    ac.case_backward_api(dense, oracle, randqp)
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_qpfunction_backward(dense, device):
+    from proxsuite_amd.torch import QPFunction
+    ac.case_qpfunction_backward(QPFunction, device=device)
+
+
 def test_omp_get_max_threads(dense):
     from proxsuite_amd import proxqp
     assert proxqp.omp_get_max_threads() >= 256
