@@ -90,24 +90,30 @@ pqp_backward_kernel(pqp::Batch batch, pqp::BackwardArgs bw)
 // Dispatch order for the next whole-batch launch: QP i goes to position
 // rank(i) = #{ j : cycles_j > cycles_i  or  (cycles_j == cycles_i and j < i) }  (descending by the
 // device cycles of the solve that just finished; O(B^2) compares, a few microseconds for B ~ 10^3-10^4).
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(64) void
 pqp_order_kernel(const long long* __restrict__ stats, int stride, int B, int* __restrict__ order)
 {
-  constexpr int TILE = 2048;
-  __shared__ long long tile[TILE];
+  // keys are compared as 32-bit values (cycle counts are clamped to 2^32 - 1: an ordering
+  // heuristic, exactness of huge counts does not matter)
+  constexpr int TILE = 4096;
+  __shared__ unsigned tile[TILE];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const long long ci = (i < B) ? stats[(long)i * stride] : 0;
+  const long long raw = (i < B) ? stats[(long)i * stride] : 0;
+  const unsigned ci = raw > 0xffffffffll ? 0xffffffffu : (raw < 0 ? 0u : (unsigned)raw);
   int rank = 0;
   for (int j0 = 0; j0 < B; j0 += TILE) {
     const int cnt = (B - j0 < TILE) ? (B - j0) : TILE;
     __syncthreads();
-    for (int t = threadIdx.x; t < cnt; t += blockDim.x)
-      tile[t] = stats[(long)(j0 + t) * stride];
-    __syncthreads();
-    for (int t = 0; t < cnt; ++t) {
-      const long long cj = tile[t];
-      rank += (cj > ci || (cj == ci && j0 + t < i)) ? 1 : 0;
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+      const long long r = stats[(long)(j0 + t) * stride];
+      tile[t] = r > 0xffffffffll ? 0xffffffffu : (r < 0 ? 0u : (unsigned)r);
     }
+    __syncthreads();
+    const int split = (i - j0 < 0) ? 0 : ((i - j0 < cnt) ? (i - j0) : cnt); // j < i  <=>  t < split
+    for (int t = 0; t < split; ++t)
+      rank += (tile[t] >= ci) ? 1 : 0;
+    for (int t = split; t < cnt; ++t)
+      rank += (tile[t] > ci) ? 1 : 0;
   }
   if (i < B)
     order[rank] = i;
@@ -719,7 +725,7 @@ pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   if (h->lpt && first == 0 && count == h->dev.B && count > 1) {
     // feedback for the next whole-batch launch: order by the device cycles this solve took
-    hipLaunchKernelGGL((pqp_order_kernel), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL((pqp_order_kernel), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, h->stream,
                        reinterpret_cast<const long long*>(h->dev.stats), (int)pqp::ST_COUNT, (int)count, h->d_order);
     HIP_TRY(hipGetLastError());
     h->order_valid = true;
