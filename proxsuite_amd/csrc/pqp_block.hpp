@@ -851,67 +851,8 @@ ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
   __syncthreads();
 }
 
-// ---------------------------------------------------------------------------
-// Explicit inverse of the unit-lower factor held in the mirrored storage of
-// ldlt_factor:  WL = L^{-1} (row-major, zeros above the diagonal, ones on it)
-// and WU = WL^T, both n x n with leading dimension ld.  With the inverse in both
-// orientations the primal-block solves become two gemv_t passes with no
-// dependent chain at all; it is computed once per factorisation of H + rho I.
-// ---------------------------------------------------------------------------
-template<int NT>
-__device__ PQP_CALL void
-tri_inverse(cgptr F, int ld, int n, gptr WL, gptr WU)
-{
-  constexpr int NB = PQP_NB;
-  for (int o = threadIdx.x; o < n * n; o += NT) {
-    int r = o / n, c = o - r * n;
-    double v = (r == c) ? 1.0 : 0.0;
-    WL[(long)r * ld + c] = v;
-    WU[(long)r * ld + c] = v;
-  }
-  __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += NB) {
-    const int nb = (n - i0 < NB) ? (n - i0) : NB;
-    // diagonal block: inv(L_bb) sits in the strict lower part of F's diagonal block
-    for (int o = threadIdx.x; o < nb * nb; o += NT) {
-      int r = o / nb, c = o - r * nb;
-      if (r > c) {
-        double v = F[(long)(i0 + r) * ld + (i0 + c)];
-        WL[(long)(i0 + r) * ld + (i0 + c)] = v;
-        WU[(long)(i0 + c) * ld + (i0 + r)] = v;
-      }
-    }
-    if (i0 > 0) {
-      const int cnt = nb * i0;
-      // phase A: Y[r][q] = sum_{k=q}^{i0-1} L[i0+r][k] * X[k][q]   -> parked in WU[q][i0+r]
-      for (int o = threadIdx.x; o < cnt; o += NT) {
-        int r = o / i0, q = o - r * i0;
-        cgptr lrow = F + (long)(i0 + r) * ld;
-        double acc = 0;
-        for (int k = q; k < i0; ++k)
-          acc = fma(lrow[k], WL[(long)k * ld + q], acc);
-        WU[(long)q * ld + (i0 + r)] = acc;
-      }
-      __syncthreads();
-      // phase B: X[i0+r][q] = - sum_{r2<=r} inv(L_bb)[r][r2] * Y[r2][q]   -> WL
-      for (int o = threadIdx.x; o < cnt; o += NT) {
-        int r = o / i0, q = o - r * i0;
-        cgptr yq = WU + (long)q * ld + i0;
-        double s = yq[r];
-        for (int r2 = 0; r2 < r; ++r2)
-          s = fma(F[(long)(i0 + r) * ld + (i0 + r2)], yq[r2], s);
-        WL[(long)(i0 + r) * ld + q] = -s;
-      }
-      __syncthreads();
-      // phase C: mirror into WU
-      for (int o = threadIdx.x; o < cnt; o += NT) {
-        int r = o / i0, q = o - r * i0;
-        WU[(long)q * ld + (i0 + r)] = WL[(long)(i0 + r) * ld + q];
-      }
-    }
-    __syncthreads();
-  }
-}
+// (the explicit inverse W = L^{-1} is computed on the matrix cores: tri_inverse_mfma /
+// tri_inverse_mfma_rows below)
 
 // ---------------------------------------------------------------------------
 // Inverses of the unit-lower diagonal blocks L_bb of an upper-mirror factor (the output of
