@@ -303,8 +303,10 @@ gemv_part_len(int nt, int jmax)
 template<int NT>
 __device__ PQP_CALL void
 gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap, int rowsplit,
-     cliptr colmap, int colsplit)
+     cliptr colmap, int colsplit, int tri = 0)
 {
+  // tri = +1: M[k][j] == 0 for k > j (only k <= j is read);  tri = -1: M[k][j] == 0 for k < j.
+  // Honoured on the plain (no row gather) k-split path; the skipped terms are exact zeros.
   constexpr int NW = NT / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
@@ -360,10 +362,15 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
           }
         } else {
           const long step = (long)KS * ld;
+          int Kj = K; // per-lane row range [k, Kj)
+          if (tri > 0)
+            Kj = (cj + 1 < K) ? (cj + 1) : K;
+          if (tri < 0 && cj > k)
+            k += ((cj - k + KS - 1) / KS) * KS;
           cgptr p = col + (long)k * ld;
           // 16, then 8, independent loads issued back to back before their first use: the
           // kernel is bound by HBM round trips, so bytes in flight per lane is the lever
-          for (; k + 15 * KS < K; k += 16 * KS) {
+          for (; k + 15 * KS < Kj; k += 16 * KS) {
             double m[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u)
@@ -377,7 +384,7 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
             }
             p += 16 * step;
           }
-          for (; k + 7 * KS < K; k += 8 * KS) {
+          for (; k + 7 * KS < Kj; k += 8 * KS) {
             double m0 = p[0], m1 = p[step], m2 = p[2 * step], m3 = p[3 * step];
             double m4 = p[4 * step], m5 = p[5 * step], m6 = p[6 * step], m7 = p[7 * step];
             a0 = fma(m0, v[k], a0);
@@ -390,7 +397,7 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
             a3 = fma(m7, v[k + 7 * KS], a3);
             p += 8 * step;
           }
-          for (; k < K; k += KS) {
+          for (; k < Kj; k += KS) {
             a0 = fma(p[0], v[k], a0);
             p += step;
           }
@@ -957,11 +964,11 @@ tri_inverse_mfma(cgptr F, int ld, int n, gptr WL, gptr WU)
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   const int lr = lane & 15, lk = lane >> 4;
   const int nbk = (n + NB - 1) / NB;
-  for (int o = threadIdx.x; o < n * n; o += NT) {
-    int r = o / n, c = o - r * n;
-    double v = (r == c) ? 1.0 : 0.0;
-    WL[(long)r * ld + c] = v;
-    WU[(long)r * ld + c] = v;
+  // WL's strict upper and WU's strict lower triangle are never written by anybody and stay at the
+  // zero they were allocated with: only the unit diagonal is (re)written here
+  for (int k = threadIdx.x; k < n; k += NT) {
+    WL[(long)k * ld + k] = 1.0;
+    WU[(long)k * ld + k] = 1.0;
   }
   __syncthreads();
   for (int j = w; j < nbk; j += NWV) {
@@ -1264,11 +1271,11 @@ tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
   const int lr = lane & 15, lk = lane >> 4;
   const int nbk = (n + NB - 1) / NB;
-  for (int o = threadIdx.x; o < n * n; o += NT) {
-    int r = o / n, c = o - r * n;
-    double v = (r == c) ? 1.0 : 0.0;
-    WL[(long)r * ld + c] = v;
-    WU[(long)r * ld + c] = v;
+  // WL's strict upper and WU's strict lower triangle are never written by anybody and stay at the
+  // zero they were allocated with: only the unit diagonal is (re)written here
+  for (int k = threadIdx.x; k < n; k += NT) {
+    WL[(long)k * ld + k] = 1.0;
+    WU[(long)k * ld + k] = 1.0;
   }
   __syncthreads();
   for (int j = w; j < nbk; j += NWV) {

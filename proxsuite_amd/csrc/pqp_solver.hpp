@@ -1191,7 +1191,9 @@ struct Solver
   __device__ __forceinline__ void apply_Linv(clptr v, lptr out, bool transposed)
   {
     if (d.hessian == PQP_HESSIAN_DENSE) {
-      mv(transposed ? (cgptr)P.WL() : (cgptr)P.WU(), d.n, d.n, d.n, v, out);
+      // W = L^{-1} is lower triangular: WU[k][j] = W[j][k] vanishes for k > j, WL[k][j] for k < j
+      gemv<NT>(transposed ? (cgptr)P.WL() : (cgptr)P.WU(), d.n, d.n, d.n, v, out, L.part(), nullptr, 0, nullptr,
+               0, transposed ? -1 : +1);
     } else if (v != out) {
       vcopy(out, v, d.n);
       __syncthreads();
