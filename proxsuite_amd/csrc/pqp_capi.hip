@@ -68,7 +68,7 @@ pqp_setup_kernel(pqp::Batch batch)
 
 // WPS = waves per SIMD the register allocator must leave room for (512 / WPS VGPRs per
 // lane): the knob that trades spills against resident workgroups per CU.
-template<int NT, int WPS>
+template<int NT, int WPS, int SPEC>
 __global__ __launch_bounds__(NT, WPS) void
 pqp_solve_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
 {
@@ -76,7 +76,7 @@ pqp_solve_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
   // `order` (optional) is the dispatch order of the QPs: workgroups are handed out in blockIdx
   // order, so listing the expensive QPs first shortens the tail of the launch
   const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
-  pqp::solve_body<NT>(batch, first + slot, (pqp::lptr)smem);
+  pqp::solve_body<NT, SPEC>(batch, first + slot, (pqp::lptr)smem);
 }
 
 template<int NT>
@@ -181,17 +181,17 @@ launch_setup(pqp_batch* h)
   return PQP_OK;
 }
 
-template<int NT, int WPS>
+template<int NT, int WPS, int SPEC>
 int
 launch_solve(pqp_batch* h)
 {
   if (h->lds_solve > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS, SPEC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
   const int* order = (h->lpt && h->order_valid && whole) ? h->d_order : nullptr;
-  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
+  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS, SPEC>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
                      h->stream, h->dev, h->range_first, order);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
@@ -268,24 +268,19 @@ dispatch_setup(pqp_batch* h)
 int
 dispatch_solve(pqp_batch* h)
 {
+  // SPEC = 1: no box constraints and a dense Hessian, both known at compile time
+  const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE;
   switch (h->nt) {
     case 256:
-      switch (h->wps) {
-        case 1:
-          return launch_solve<256, 1>(h);
-        case 2:
-          return launch_solve<256, 2>(h);
-        case 3:
-          return launch_solve<256, 3>(h);
-        default:
-          return launch_solve<256, 4>(h);
-      }
+      if (h->wps == 4)
+        return common ? launch_solve<256, 4, 1>(h) : launch_solve<256, 4, 0>(h);
+      return common ? launch_solve<256, 3, 1>(h) : launch_solve<256, 3, 0>(h);
     case 512:
       // (512, 4) -- a 128-VGPR budget for an 8-wave workgroup -- produced NaNs on MI355X with
       // ROCm 7.2 (heavy spilling; parity-checked OK at (512, 2)), so it is not instantiated
-      return launch_solve<512, 2>(h);
+      return common ? launch_solve<512, 2, 1>(h) : launch_solve<512, 2, 0>(h);
     default:
-      return launch_solve<1024, 4>(h);
+      return common ? launch_solve<1024, 4, 1>(h) : launch_solve<1024, 4, 0>(h);
   }
 }
 
@@ -454,7 +449,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     h->lpt = std::string(e) != "fifo";
   if (const char* e = std::getenv("PQP_WAVES_PER_SIMD")) {
     int v = std::atoi(e);
-    if (v >= 1 && v <= 4)
+    if (v == 3 || v == 4)
       h->wps = v;
   }
   h->lds_solve = pqp::lds_bytes(d, h->nt);

@@ -832,9 +832,14 @@ setup_body(const Batch& batch, long q, lptr lds_base)
 // ===========================================================================
 //                               SOLVE
 // ===========================================================================
-template<int NT>
+// SPEC = 1 compiles the solver for the commonest signature -- no box constraints, dense Hessian --
+// with those two switches as compile-time constants (the box / diagonal / zero-Hessian branches and
+// the scalars that feed them disappear from the hot kernel); SPEC = 0 keeps them at run time.
+template<int NT, int SPEC = 0>
 struct Solver
 {
+  __device__ __forceinline__ bool has_box() const { return SPEC == 1 ? false : (d.box != 0); }
+  __device__ __forceinline__ int hess() const { return SPEC == 1 ? (int)PQP_HESSIAN_DENSE : d.hessian; }
   const Batch& batch;
   const long q;
   const Dims d;
@@ -933,7 +938,7 @@ struct Solver
   {
     const int n = d.n;
     const double rho = info.rho;
-    if (d.hessian == PQP_HESSIAN_DENSE) {
+    if (hess() == PQP_HESSIAN_DENSE) {
       gptr F = P.F();
       cgptr Hs = P.Hs();
       bool done = false;
@@ -968,7 +973,7 @@ struct Solver
       // diagonal / zero Hessian: L = I
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.dF()[k] = ((d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] : 0.0) + rho;
+        L.dF()[k] = ((hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] : 0.0) + rho;
       __syncthreads();
     }
     vstore(P.dF(), L.dF(), n);
@@ -993,7 +998,7 @@ struct Solver
     gptr Zc = P.Zc(), Zr = P.Zr();
     for (int k = threadIdx.x; k < n; k += NT)
       L.t1()[k] = 1.0 / L.dF()[k];
-    if (d.hessian == PQP_HESSIAN_DENSE) {
+    if (hess() == PQP_HESSIAN_DENSE) {
       cgptr WU = P.WU(), ATs = P.ATs(), CTs = P.CTs();
       // work unit = one 16-row block of Z times TWO adjacent 16-column blocks: the W operand is
       // loaded once for both, and every batch keeps 3 * ZG_DEPTH loads in flight per lane
@@ -1058,7 +1063,7 @@ struct Solver
               Zr[(long)cr * n + k] = acc2[h][rr];
           }
       }
-      if (d.box) {
+      if (has_box()) {
         cgptr WL = P.WL();
         for (int o = threadIdx.x; o < n * n; o += NT) {
           const int a = o / n, bcol = o - a * n;
@@ -1190,7 +1195,7 @@ struct Solver
   // out = L^{-1} v  /  out = L^{-T} v   (LDS vectors, may alias)
   __device__ __forceinline__ void apply_Linv(clptr v, lptr out, bool transposed)
   {
-    if (d.hessian == PQP_HESSIAN_DENSE) {
+    if (hess() == PQP_HESSIAN_DENSE) {
       // W = L^{-1} is lower triangular: WU[k][j] = W[j][k] vanishes for k > j, WL[k][j] for k < j
       gemv<NT>(transposed ? (cgptr)P.WL() : (cgptr)P.WU(), d.n, d.n, d.n, v, out, L.part(), nullptr, 0, nullptr,
                0, transposed ? -1 : +1);
@@ -1308,12 +1313,12 @@ struct Solver
       L.zfull()[i] = (s >= 0) ? L.sd()[ne + s] : 0.0;
     }
     __syncthreads();
-    if (d.hessian == PQP_HESSIAN_DENSE) {
+    if (hess() == PQP_HESSIAN_DENSE) {
       mv(P.Hs(), n, n, n, L.dx(), L.Hdx());
     } else {
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.Hdx()[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.dx()[k] : 0.0;
+        L.Hdx()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.dx()[k] : 0.0;
     }
     if (ne > 0) {
       mv(P.As(), n, ne, n, L.sd(), L.ATdy());
@@ -1328,7 +1333,7 @@ struct Solver
       vzero(L.CTdz(), n);
     }
     __syncthreads();
-    if (d.box) {
+    if (has_box()) {
       for (int k = threadIdx.x; k < n; k += NT) {
         L.CTdz()[k] += L.zfull()[ni + k] * L.isc()[k];
         L.Cdx()[ni + k] = L.dx()[k] * L.isc()[k];
@@ -1470,7 +1475,7 @@ struct Solver
         m_inl = fmax(m_inl, fabs(sv));
       }
     }
-    if (d.box) {
+    if (has_box()) {
       cgptr dx = P.dlt_x();
       cgptr ub = P.u_box(), lb = P.l_box();
       for (int k = threadIdx.x; k < n; k += NT) {
@@ -1524,12 +1529,12 @@ struct Solver
     double xHx = 0, gx = 0;
     // H x -> t1, A^T y -> ATdy-free scratch (t2), C^T z -> CTzin-free... use t1/t2/zfull? keep
     // three distinct n-vectors: t1, t2 and ex (free outside the Newton loop)
-    if (d.hessian == PQP_HESSIAN_DENSE) {
+    if (hess() == PQP_HESSIAN_DENSE) {
       mv(P.Hs(), n, n, n, L.x(), L.t1());
     } else {
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.t1()[k] = (d.hessian == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x()[k] : 0.0;
+        L.t1()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x()[k] : 0.0;
     }
     if (ne > 0)
       mv(P.As(), n, ne, n, L.y(), L.t2());
@@ -1552,7 +1557,7 @@ struct Solver
         gx += g[k] * xu;
         m1 = fmax(m1, fabs(aty / sc));
         double m3k = fabs(ctz / sc);
-        if (d.box) {
+        if (has_box()) {
           double zb = L.z()[ni + k] * L.isc()[k];
           ctz += zb;
           m3k = fmax(m3k, fabs(zb / sc));
@@ -1564,7 +1569,7 @@ struct Solver
       }
     }
     R.max3(m0, m1, m3);
-    rhs_0 = (d.hessian == PQP_HESSIAN_ZERO) ? 0.0 : m0;
+    rhs_0 = (hess() == PQP_HESSIAN_ZERO) ? 0.0 : m0;
     rhs_1 = m1;
     rhs_3 = m3;
     lhs = R.max(ml);
@@ -1587,7 +1592,7 @@ struct Solver
         if (flag_low(k))
           zl += zi * lk;
       }
-      if (d.box) {
+      if (has_box()) {
         cgptr db = P.dlt_box();
         cgptr ub = P.u_box(), lb = P.l_box();
         for (int k = threadIdx.x; k < n; k += NT) {
@@ -1606,7 +1611,7 @@ struct Solver
     zlb = R.sum(zlb);
     duality_gap = gx;
     rhs_duality_gap = fabs(gx);
-    if (d.hessian != PQP_HESSIAN_ZERO) {
+    if (hess() != PQP_HESSIAN_ZERO) {
       duality_gap += xHx;
       rhs_duality_gap = fmax(rhs_duality_gap, fabs(xHx));
     }
@@ -1616,7 +1621,7 @@ struct Solver
     duality_gap += zu;
     rhs_duality_gap = fmax(rhs_duality_gap, fabs(zl));
     duality_gap += zl;
-    if (d.box) {
+    if (has_box()) {
       rhs_duality_gap = fmax(rhs_duality_gap, fabs(zub));
       duality_gap += zub;
       rhs_duality_gap = fmax(rhs_duality_gap, fabs(zlb));
@@ -1800,7 +1805,7 @@ struct Solver
         L.dz()[k] = v * di[k] / c;
         nrm_dz = fmax(nrm_dz, fabs(L.dz()[k]));
       }
-      if (d.box) {
+      if (has_box()) {
         cgptr db = P.dlt_box();
         for (int k = threadIdx.x; k < n; k += NT) {
           double v = L.dz()[ni + k];
@@ -1840,7 +1845,7 @@ struct Solver
       cgptr di = P.dlt_in();
       for (int k = threadIdx.x; k < ni; k += NT)
         L.Cdx()[k] /= di[k];
-      if (d.box) {
+      if (has_box()) {
         cgptr db = P.dlt_box();
         for (int k = threadIdx.x; k < n; k += NT)
           L.Cdx()[ni + k] /= db[k];
@@ -1863,7 +1868,7 @@ struct Solver
       if (!ok)
         viol = 1;
     }
-    if (d.box)
+    if (has_box())
       for (int k = threadIdx.x; k < n; k += NT) {
         double v = L.dx()[k];
         bool ok = true;
@@ -1934,7 +1939,7 @@ struct Solver
       __syncthreads();
       for (int k = threadIdx.x; k < n; k += NT) {
         double s = L.CTzin()[k];
-        if (d.box) {
+        if (has_box()) {
           s += L.zfull()[ni + k] * L.isc()[k];
           L.CTzin()[k] = s;
         }
@@ -1998,7 +2003,7 @@ struct Solver
         __syncthreads();
       }
       UD alpha = 1.0;
-      if (ni > 0 || d.box)
+      if (ni > 0 || has_box())
         alpha = primal_dual_ls();
       toc(ST_CYC_LINESEARCH);
       {
@@ -2075,7 +2080,7 @@ struct Solver
       L.y()[k] = L.y()[k] / de[k] * ruiz_c;
     for (int k = threadIdx.x; k < ni; k += NT)
       L.z()[k] = L.z()[k] / di[k] * ruiz_c;
-    if (d.box) {
+    if (has_box()) {
       cgptr db = P.dlt_box();
       for (int k = threadIdx.x; k < n; k += NT)
         L.z()[ni + k] = L.z()[ni + k] / db[k] * ruiz_c;
@@ -2172,7 +2177,7 @@ struct Solver
     vload(L.bs(), P.bs(), ne);
     vload(L.us(), P.us(), ni);
     vload(L.ls(), P.ls(), ni);
-    if (d.box) {
+    if (has_box()) {
       vload(L.ubs(), P.ubs(), n);
       vload(L.lbs(), P.lbs(), n);
       vload(L.isc(), P.is(), n);
@@ -2371,7 +2376,7 @@ struct Solver
             mv(P.C(), n, ni, n, ones, L.t2());
           double m = 0;
           for (int k = threadIdx.x; k < n; k += NT)
-            m = fmax(m, fabs(L.t1()[k] + L.t2()[k] + (d.box ? L.isc()[k] : 0.0)));
+            m = fmax(m, fabs(L.t1()[k] + L.t2()[k] + (has_box() ? L.isc()[k] : 0.0)));
           scaled_eps = R.max(m) * st.eps_abs;
         }
         stage = 1;
@@ -2459,7 +2464,7 @@ struct Solver
         L.y()[k] = L.y()[k] * de[k] / ruiz_c;
       for (int k = threadIdx.x; k < ni; k += NT)
         L.z()[k] = L.z()[k] * di[k] / ruiz_c;
-      if (d.box) {
+      if (has_box()) {
         cgptr db = P.dlt_box();
         for (int k = threadIdx.x; k < n; k += NT)
           L.z()[ni + k] = db[k] * L.z()[ni + k] / ruiz_c;
@@ -2469,7 +2474,7 @@ struct Solver
           L.se()[k] /= de[k];
         for (int k = threadIdx.x; k < ni; k += NT)
           L.si()[k] /= di[k];
-        if (d.box) {
+        if (has_box()) {
           cgptr db = P.dlt_box();
           for (int k = threadIdx.x; k < n; k += NT)
             L.si()[ni + k] /= db[k];
@@ -2481,7 +2486,7 @@ struct Solver
     {
       double obj = 0;
       cgptr g = P.g();
-      if (d.hessian == PQP_HESSIAN_DENSE) {
+      if (hess() == PQP_HESSIAN_DENSE) {
         mv(P.H(), n, n, n, L.x(), L.t1());
         for (int k = threadIdx.x; k < n; k += NT)
           obj += 0.5 * L.t1()[k] * L.x()[k] + g[k] * L.x()[k];
@@ -2672,15 +2677,15 @@ template<int NT>
 __device__ __forceinline__ void
 backward_body(const Batch& batch, const BackwardArgs& bw, long slot, lptr lds_base)
 {
-  Solver<NT> S(batch, bw.first + slot, lds_base);
+  Solver<NT, 0> S(batch, bw.first + slot, lds_base);
   S.backward(bw, slot);
 }
 
-template<int NT>
+template<int NT, int SPEC>
 __device__ __forceinline__ void
 solve_body(const Batch& batch, long q, lptr lds_base)
 {
-  Solver<NT> S(batch, q, lds_base);
+  Solver<NT, SPEC> S(batch, q, lds_base);
   S.solve();
 }
 
