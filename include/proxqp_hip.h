@@ -118,6 +118,12 @@ int pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const d
 int pqp_batch_get_backward(pqp_batch* h, int64_t idx, double* dL_dH, double* dL_dg, double* dL_dA,
                            double* dL_db, double* dL_dC, double* dL_du, double* dL_dl);
 
+/* Dispatch order of whole-batch solves: 1 (default) = longest-processing-time first, using the
+ * device cycle counts of the previous whole-batch solve of this handle; 0 = index order.  QPs are
+ * independent: the order changes the tail of the launch, never a result.  (Environment
+ * PQP_SCHEDULE=fifo sets 0 at creation.) */
+int pqp_batch_set_schedule(pqp_batch* h, int longest_first);
+
 /* QP::results (x, y, z, se, si, info); any output pointer may be NULL. */
 int pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z, double* se,
                           double* si, pqp_info* info);

@@ -35,7 +35,7 @@ class NativeLib:
     SYMBOLS = ("pqp_last_error", "pqp_device_count", "pqp_batch_create", "pqp_batch_destroy",
                "pqp_batch_size", "pqp_batch_dense_backend", "pqp_batch_settings", "pqp_batch_init",
                "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_flush",
-               "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_set_stream", "pqp_batch_backward", "pqp_batch_backward_range",
+               "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
                "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs",
                "pqp_batch_get_scaled", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
                "pqp_batch_launch_config")
@@ -62,6 +62,7 @@ class NativeLib:
         L.pqp_batch_solve.argtypes = [vp]
         L.pqp_batch_solve_range.argtypes = [vp, C.c_int64, C.c_int64]
         L.pqp_batch_set_stream.argtypes = [vp, vp]
+        L.pqp_batch_set_schedule.argtypes = [vp, C.c_int]
         L.pqp_batch_backward.argtypes = [vp, _DP] + [C.c_double] * 3
         L.pqp_batch_backward_range.argtypes = [vp, C.c_int64, C.c_int64, _DP] + [C.c_double] * 3
         L.pqp_batch_get_backward.argtypes = [vp, C.c_int64] + [_DP] * 7
@@ -255,6 +256,10 @@ class Batch:
                 ptrs.append(buf.ctypes.data_as(_DP))
         self.lib.check(self.lib.L.pqp_batch_get_backward(self._h, int(idx), *ptrs))
         return out
+
+    def set_schedule(self, longest_first=True):
+        """Dispatch order of whole-batch solves: longest-processing-time first (default) or index order."""
+        self.lib.check(self.lib.L.pqp_batch_set_schedule(self._h, int(bool(longest_first))))
 
     def set_stream(self, stream):
         """`stream`: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""

@@ -689,6 +689,15 @@ pqp_batch_set_stream(pqp_batch* h, void* stream)
 }
 
 int
+pqp_batch_set_schedule(pqp_batch* h, int longest_first)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  h->lpt = longest_first != 0;
+  return PQP_OK;
+}
+
+int
 pqp_batch_solve(pqp_batch* h)
 {
   if (!h)
