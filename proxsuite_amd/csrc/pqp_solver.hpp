@@ -31,7 +31,6 @@ namespace pqp {
 constexpr double MACHINE_EPS = 2.220446049250313e-16;
 constexpr int ZG_DEPTH = 8; // MFMA k-steps (of 4) whose operand loads are in flight together in build_ZG
 constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * SCHUR_MB rows
-constexpr int VALIDATE_BATCH = 8; // constraint rows validated per pass over L^{-1} / Z
 
 struct Dims
 {
@@ -129,7 +128,7 @@ struct Batch
   double *dF;     // n
   double *Zr;     // nd x n  row cid = L^{-1} b_cid
   double *Zc;     // n x nd  transpose of Zr
-  double *G;      // nd x nd Gram matrix  Z^T D^{-1} Z over validated constraints
+  double *G;      // nd x nd Gram matrix  Z^T D^{-1} Z over all constraints (build_ZG)
   double *LS;     // nd x nd mirrored LDL^T of M_J + G_JJ (slot order)
   double *dS;     // nd
   int* act;       // nc      active list kept across solves
@@ -251,7 +250,7 @@ lds_doubles(const Dims& d, int nt)
 __host__ __device__ inline size_t
 lds_bytes(const Dims& d, int nt)
 {
-  size_t ints = (size_t)d.nc * 3 + d.nd + nt / WAVE + 8 + VALIDATE_BATCH;
+  size_t ints = (size_t)d.nc * 3 + d.nd + nt / WAVE + 16;
   return lds_doubles(d, nt) * sizeof(double) + ints * sizeof(int) + 64;
 }
 
@@ -851,7 +850,7 @@ struct Solver
   int n_c;       // active inequality count
   int r;         // n_eq + n_c : size of the dual block
   bool schur_dirty;
-  bool z_all_valid; // every row of Z and G is current (eager build_ZG): skip the lazy validation scan
+  bool z_all_valid; // every row of Z and G is current (set by build_ZG, restored with the factorisation)
   UD ruiz_c;
   UD dual_feasibility_rhs_2;
   bool nonfinite;
@@ -987,8 +986,8 @@ struct Solver
   //   Zc[k][c] = sum_j W[k][j] Bt[j][c]   and, from the SAME two operand registers with the
   //   roles swapped, Zr[c][k] -- so both orientations are written with coalesced stores;
   //   G[c][d]  = sum_k Zc[k][c] (1/D_k) Zc[k][d], lower tiles + their mirrors.
-  // This replaces the lazy row-by-row validation (validate_batch): ~5 MFLOP per QP at C2 done
-  // once as dense tiles instead of ~17 latency-bound passes over W and Z per solve.
+  // ~5 MFLOP per QP at C2, done once per factorisation as dense tiles (an earlier version validated
+  // rows lazily, one latency-bound pass over W and Z per newly active batch of constraints).
   __device__ __forceinline__ void build_ZG()
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nd = d.nd, nb = ne + ni;
@@ -1407,8 +1406,7 @@ struct Solver
   }
 
   // new active set from L.aflags (bit2 = wanted active): rebuilds the slot map in
-  // ascending constraint order, validates rows that enter the factorisation for the
-  // first time and re-factorises the Schur block when anything changed.
+  // ascending constraint order and re-factorises the Schur block when anything changed.
   // (reference linesearch.hpp:549-786 does the same job by editing its LDL^T)
   __device__ __forceinline__ void apply_active_set()
   {
