@@ -38,6 +38,12 @@ class HessianType(enum.IntEnum):
     Diagonal = 2
 
 
+class EigenValueEstimateMethodOption(enum.IntEnum):
+    """reference settings.hpp:49-53"""
+    PowerIteration = 0
+    ExactMethod = 1
+
+
 class MeritFunctionType(enum.IntEnum):
     """reference settings.hpp:36-40"""
     GPDAL = 0

@@ -222,6 +222,16 @@ strongly_convex(Lehmer& rng, long n, long n_eq, long n_in, double p, double sc, 
 
 extern "C" {
 
+// smallest eigenvalue of a symmetric matrix (Householder tridiagonalisation + Sturm bisection):
+// the "ExactMethod" of estimate_minimal_eigen_value_of_symmetric_matrix (reference
+// dense/helpers.hpp:160-163 calls Eigen's SelfAdjointEigenSolver there)
+double
+pqp_min_eigenvalue_symmetric(int64_t n, const double* H)
+{
+  std::vector<double> tmp(H, H + size_t(n) * size_t(n));
+  return min_eigenvalue(tmp, long(n));
+}
+
 void
 pqp_rand_set_seed(uint64_t seed)
 {

@@ -1,8 +1,9 @@
 """`proxsuite.proxqp` namespace of the reference, dense backend only (MI355X build)."""
-from .._ctypes_defs import DenseBackend, HessianType, InitialGuess, MeritFunctionType, QPSolverOutput
+from .._ctypes_defs import (DenseBackend, EigenValueEstimateMethodOption, HessianType, InitialGuess,
+                            MeritFunctionType, QPSolverOutput)
 from . import dense
 
-__all__ = ["dense", "DenseBackend", "HessianType", "InitialGuess", "MeritFunctionType", "QPSolverOutput",
+__all__ = ["dense", "DenseBackend", "EigenValueEstimateMethodOption", "HessianType", "InitialGuess", "MeritFunctionType", "QPSolverOutput",
            "omp_get_max_threads"]
 
 

@@ -24,11 +24,12 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _native
-from .._ctypes_defs import (DenseBackend, HessianType, InitialGuess, MeritFunctionType, QPSolverOutput,
-                            pqp_info, pqp_settings)
+from .._ctypes_defs import (DenseBackend, EigenValueEstimateMethodOption, HessianType, InitialGuess,
+                            MeritFunctionType, QPSolverOutput, pqp_info, pqp_settings)
 
 __all__ = ["QP", "BatchQP", "VectorQP", "VectorLossDerivatives", "solve_in_parallel", "solve",
-           "compute_backward", "solve_backward_in_parallel", "DenseBackend", "HessianType", "InitialGuess",
+           "compute_backward", "solve_backward_in_parallel", "estimate_minimal_eigen_value_of_symmetric_matrix",
+           "EigenValueEstimateMethodOption", "DenseBackend", "HessianType", "InitialGuess",
            "QPSolverOutput", "MeritFunctionType", "Settings", "Results", "Info", "Model", "BackwardData"]
 
 _BOOL_SETTINGS = ("verbose", "update_preconditioner", "compute_preconditioner", "compute_timings",
@@ -372,6 +373,39 @@ def solve_in_parallel(qps, num_threads=None):
                 continue
             pool.solve(start, prev - start + 1)
             start = prev = s
+
+
+def estimate_minimal_eigen_value_of_symmetric_matrix(H, estimate_method_option=EigenValueEstimateMethodOption.ExactMethod,
+                                                     power_iteration_accuracy=1.0e-3, nb_power_iteration=1000):
+    """Host-side helper for non-convex QPs, as in the reference (dense/helpers.hpp:24-165, python
+    expose-helpers.hpp:22-46): the value goes to `init(..., manual_minimal_H_eigenvalue=...)`.
+    ExactMethod = smallest eigenvalue (Householder + Sturm bisection in libpqp_randqp.so);
+    PowerIteration = the reference's two power iterations, restated."""
+    H = np.ascontiguousarray(np.asarray(H, dtype=np.float64))
+    if H.ndim != 2 or H.shape[0] != H.shape[1]:
+        raise ValueError("wrong argument size: H has a number of rows different of the number of columns.")
+    if not np.allclose(H, H.T, rtol=np.finfo(float).eps, atol=0.0):
+        raise ValueError("H is not symmetric.")
+    n = H.shape[0]
+    if EigenValueEstimateMethodOption(estimate_method_option) == EigenValueEstimateMethodOption.ExactMethod:
+        from ..utils import random_qp as _rq
+        return float(_rq.min_eigenvalue_symmetric(H))
+
+    def power(op):
+        rhs = np.full(n, 1.0 / np.sqrt(n))
+        dw = op(rhs)
+        eig = 0.0
+        for _ in range(int(nb_power_iteration)):
+            rhs = dw / np.linalg.norm(dw)
+            dw = op(rhs)
+            eig = float(rhs @ dw)
+            if np.max(np.abs(dw - eig * rhs)) <= power_iteration_accuracy:
+                break
+        return eig
+
+    dominant = power(lambda v: H @ v)
+    min_eig = dominant - power(lambda v: dominant * v - H @ v)
+    return float(min(min_eig, dominant))
 
 
 class VectorLossDerivatives(list):

@@ -63,6 +63,15 @@ class Model:
         return self.C.shape[-2]
 
 
+def min_eigenvalue_symmetric(H) -> float:
+    """Smallest eigenvalue of a symmetric matrix (Householder tridiagonalisation + Sturm bisection)."""
+    H = np.ascontiguousarray(np.asarray(H, dtype=np.float64))
+    L = _load()
+    L.pqp_min_eigenvalue_symmetric.restype = C.c_double
+    L.pqp_min_eigenvalue_symmetric.argtypes = [C.c_int64, C.POINTER(C.c_double)]
+    return float(L.pqp_min_eigenvalue_symmetric(H.shape[0], _p(H)))
+
+
 def set_seed(seed: int) -> None:
     """reference random_qp_problems.hpp:121-127"""
     _load().pqp_rand_set_seed(int(seed))

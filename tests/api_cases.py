@@ -283,3 +283,35 @@ def case_qpfunction_backward(QPFunction, device="cpu"):
             ref = Q.grad[i, j] + (Q.grad[j, i] if i != j else 0)
             assert abs(fd.item() - ref.item()) < 1e-5
     assert Q.grad.shape == Q.shape and p.grad.shape == p.shape
+
+
+def case_nonconvex_helpers(dense):
+    """estimate_minimal_eigen_value_of_symmetric_matrix + manual_minimal_H_eigenvalue (reference
+    test/src/dense_qp_wrapper.cpp:7153-7617 pattern: estimate, pass to init, solve a non-convex QP
+    whose minimum is pinned by box-like constraints)."""
+    rng = np.random.default_rng(4)
+    n = 12
+    M = rng.standard_normal((n, n))
+    H = (M + M.T) / 2  # indefinite
+    lam = np.linalg.eigvalsh(H)[0]
+    assert lam < 0
+    e_exact = dense.estimate_minimal_eigen_value_of_symmetric_matrix(H)
+    e_power = dense.estimate_minimal_eigen_value_of_symmetric_matrix(
+        H, dense.EigenValueEstimateMethodOption.PowerIteration, 1e-10, 100000)
+    assert abs(e_exact - lam) < 1e-10 and abs(e_power - lam) < 1e-6
+    import pytest
+    with pytest.raises(ValueError):
+        dense.estimate_minimal_eigen_value_of_symmetric_matrix(H + np.triu(np.ones((n, n)), 1))
+    # non-convex QP on a box: a KKT point is found once rho covers the negative curvature
+    g = rng.standard_normal(n)
+    C = np.eye(n)
+    l, u = -np.ones(n), np.ones(n)
+    qp = dense.QP(n, 0, n)
+    qp.settings.eps_abs = 1e-9
+    qp.init(H, g, None, None, C, l, u, manual_minimal_H_eigenvalue=e_exact)
+    assert qp.settings.default_H_eigenvalue_estimate == e_exact
+    qp.solve()
+    r = qp.results
+    assert r.info.status == dense.QPSolverOutput.PROXQP_SOLVED
+    assert np.max(np.abs(H @ r.x + g + r.z)) <= 1e-9
+    assert np.all(r.x <= 1 + 1e-9) and np.all(r.x >= -1 - 1e-9)

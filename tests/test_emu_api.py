@@ -47,6 +47,10 @@ def test_qpfunction_forward(dense, oracle, randqp):
     ac.case_qpfunction(QPFunction, oracle, randqp, device="cpu")
 
 
+def test_nonconvex_helpers(dense):
+    ac.case_nonconvex_helpers(dense)
+
+
 def test_backward_api(dense, oracle, randqp):
     ac.case_backward_api(dense, oracle, randqp)
 
