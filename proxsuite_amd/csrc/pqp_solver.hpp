@@ -1257,7 +1257,11 @@ struct Solver
     }
     __syncthreads();
     toc(ST_CYC_S_GATHER);
-    if constexpr (NT == 256)
+    // Schur blocks above the register-resident limit.  The specialised 256-thread kernel (SPEC = 1,
+    // where such blocks are rare: C2) keeps the small HBM-resident routine -- pulling the blocked
+    // matrix-core version into it costs that kernel registers it needs elsewhere; every other
+    // instantiation (box / diagonal-Hessian shapes such as C5 reach 130-200 active rows) uses it.
+    if constexpr (NT == 256 && SPEC == 1)
       ldlt_factor<NT, false>(LS, nd, rr, L.dS(), L.top());
     else
       ldlt_factor_mfma<NT, false>(LS, nd, rr, L.dS(), L.top());
