@@ -10,6 +10,9 @@ expose-parallel.hpp:27-46, expose-solve.hpp) for the dense ProxQP path:
     VectorQP()          .append(qp)
     solve_in_parallel(qps, num_threads=None)
     solve(H, g, A, b, C, l, u, ...)
+    compute_backward(qp, loss_derivative, eps, rho_backward, mu_backward)   -> qp.model.backward_data
+    solve_backward_in_parallel(num_threads, qps, loss_derivatives, ...)
+    estimate_minimal_eigen_value_of_symmetric_matrix(H, ...)               (host-side helper)
 
 What differs is where the work happens.  A `BatchQP` owns device-resident *pools*: one
 C-ABI batch handle per problem signature (n, n_eq, n_in, box, Hessian type, backend), sized
