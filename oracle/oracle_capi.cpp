@@ -7,6 +7,8 @@
 #include <cstring>
 #ifdef _OPENMP
 #include <omp.h>
+#include <sched.h>
+#include <vector>
 #endif
 
 using pqo::isize;
@@ -186,6 +188,12 @@ pqo_get_counters(void* h, double* out)
 // The reference's data-parallel driver, restated:
 // include/proxsuite/proxqp/parallel/qp_solve.hpp:41-59
 // (`#pragma omp parallel for schedule(dynamic)` over independent QPs).
+//
+// The team's threads are bound to distinct CPUs of the caller's affinity mask for the duration of
+// the loop (what OMP_PROC_BIND=spread does, without depending on the environment): freshly created
+// OpenMP workers otherwise start on the caller's CPU and some kernels take about a second to spread
+// them, during which the "parallel" loop time-shares one core (measured: 8 threads no faster than
+// 1 for the first five calls).  As a timed CPU baseline that would flatter the GPU.
 int
 pqo_solve_in_parallel(void** handles, int64_t count, int num_threads)
 {
@@ -193,9 +201,28 @@ pqo_solve_in_parallel(void** handles, int64_t count, int num_threads)
   int nt = num_threads > 0 ? num_threads : std::max(omp_get_max_threads() / 2, 1);
   omp_set_dynamic(0);
   omp_set_num_threads(nt);
-#pragma omp parallel for schedule(dynamic)
-  for (int64_t i = 0; i < count; ++i)
-    static_cast<QP*>(handles[i])->solve(nullptr, nullptr, nullptr);
+  cpu_set_t caller_mask;
+  std::vector<int> cpus;
+  const bool have_mask = sched_getaffinity(0, sizeof(caller_mask), &caller_mask) == 0;
+  if (have_mask)
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &caller_mask))
+        cpus.push_back(c);
+#pragma omp parallel
+  {
+    if (nt > 1 && !cpus.empty()) {
+      cpu_set_t one;
+      CPU_ZERO(&one);
+      CPU_SET(cpus[size_t(omp_get_thread_num()) % cpus.size()], &one);
+      sched_setaffinity(0, sizeof(one), &one);
+    }
+#pragma omp for schedule(dynamic)
+    for (int64_t i = 0; i < count; ++i)
+      static_cast<QP*>(handles[i])->solve(nullptr, nullptr, nullptr);
+    // the caller gets its mask back; the pool's workers stay where they are (as with OMP_PROC_BIND)
+    if (nt > 1 && have_mask && omp_get_thread_num() == 0)
+      sched_setaffinity(0, sizeof(caller_mask), &caller_mask);
+  }
   return nt;
 #else
   (void)num_threads;
