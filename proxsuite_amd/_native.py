@@ -87,6 +87,11 @@ _lib = None
 
 
 def hip_library_path() -> Path:
+    """In-tree build of the HIP library; PQP_HIP_LIBRARY selects another build of the SAME library
+    (kernel experiments) -- it is never a fallback: the file must exist and a GPU must be there."""
+    override = os.environ.get("PQP_HIP_LIBRARY")
+    if override:
+        return Path(override).resolve()
     return Path(__file__).resolve().parent / "csrc" / "libproxqp_hip.so"
 
 

@@ -439,6 +439,109 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
 }
 
 // ---------------------------------------------------------------------------
+// gemv_dual: BOTH products of a row-major matrix M (R rows x n columns) in ONE pass over it:
+//   rowout[r] = sum_j M[r][j] * v[j]      r < R
+//   colout[j] = sum_r w[r] * M[r][j]      j < n          (COLS = false: skipped, w / colout unused)
+// This is what the KKT residual needs of A and C (A dx with A^T dy, C dx with C^T dz,
+// reference solver.hpp:243-318); a pair of gemv calls reads the matrix and a transposed copy.
+// Lane layout: 16 lanes share a row (one 128-byte segment per load), a wavefront covers four
+// rows per step, each lane keeps the 8 column accumulators of its 16-column stripes; columns
+// beyond 128 are handled in further blocks of 128.  Row sums close with four xor-shuffles
+// inside the 16-lane group, column sums with two across the groups and an LDS pass across the
+// wavefronts.  `part`: gemv_dual_part_len() doubles of LDS.  v, w must not alias the outputs.
+// Two barriers with COLS, one otherwise.  (The column pass is a template flag and not a null
+// test of w: LDS offset 0 is a valid address -- the first vector of the carve-up lives there.)
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int
+gemv_dual_part_len(int nt, int n)
+{
+  return (nt / WAVE) * n;
+}
+
+// SYM = true: M is a symmetric n x n matrix (R == n), w == v, and rowout == colout receives M v
+// from the LOWER triangle alone (stripes right of a wavefront's rows are not loaded): row sums
+// over j <= r plus column sums over the strict part.
+template<int NT, bool SYM = false, bool COLS = true>
+__device__ PQP_CALL void
+gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part)
+{
+  constexpr int NW = NT / WAVE;
+  constexpr int CH = 8; // 16-column stripes per lane and column block
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x / WAVE;
+  const int g = lane >> 4, s = lane & 15;
+  for (int c0 = 0; c0 < n; c0 += 16 * CH) {
+    double vv[CH], acc[CH];
+    int off[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = c0 + 16 * c + s;
+      off[c] = (col < n) ? col : (n - 1); // clamped: the load stays unconditional
+      vv[c] = (col < n) ? v[off[c]] : 0.0;
+      acc[c] = 0.0;
+    }
+    for (int base = 0; base < R; base += 4 * NW) {
+      const int r = base + 4 * wid + g;
+      const bool valid = r < R;
+      const int rlast = base + 4 * wid + 3; // last row of this wavefront's step (wave-uniform)
+      cgptr row = M + (long)(valid ? r : (R - 1)) * ld;
+      double m[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int cs = c0 + 16 * c; // stripe tests are wave-uniform
+        m[c] = (cs < n && (!SYM || cs <= rlast)) ? row[off[c]] : 0.0;
+      }
+      double p0 = 0, p1 = 0;
+#pragma unroll
+      for (int c = 0; c < CH; c += 2) {
+        if (SYM) {
+          p0 = fma((c0 + 16 * c + s <= r) ? m[c] : 0.0, vv[c], p0);
+          p1 = fma((c0 + 16 * (c + 1) + s <= r) ? m[c + 1] : 0.0, vv[c + 1], p1);
+        } else {
+          p0 = fma(m[c], vv[c], p0);
+          p1 = fma(m[c + 1], vv[c + 1], p1);
+        }
+      }
+      double pr = p0 + p1;
+      pr += __shfl_xor(pr, 1);
+      pr += __shfl_xor(pr, 2);
+      pr += __shfl_xor(pr, 4);
+      pr += __shfl_xor(pr, 8);
+      if (valid && s == 0)
+        rowout[r] = (c0 == 0) ? pr : rowout[r] + pr;
+      if (COLS) {
+        const double wr = valid ? w[valid ? r : 0] : 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          acc[c] = fma(wr, (!SYM || c0 + 16 * c + s < r) ? m[c] : 0.0, acc[c]);
+      }
+    }
+    if (COLS) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        double a = acc[c];
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        const int col = c0 + 16 * c + s;
+        if (g == 0 && col < n)
+          part[wid * n + col] = a;
+      }
+    }
+  }
+  __syncthreads();
+  if (COLS) {
+    for (int j = threadIdx.x; j < n; j += NT) {
+      double a = part[j];
+#pragma unroll
+      for (int q = 1; q < NW; ++q)
+        a += part[q * n + j];
+      colout[j] = SYM ? rowout[j] + a : a;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Blocked left-looking LDL^T of a symmetric m x m matrix stored FULL row-major
 // in HBM (leading dimension ld, m <= NT: thread i owns row i of the panel in
 // registers).  Only the UPPER triangle of the input is read.  On exit:

@@ -274,6 +274,8 @@ dispatch_solve(pqp_batch* h)
     case 256:
       if (h->wps == 4)
         return common ? launch_solve<256, 4, 1>(h) : launch_solve<256, 4, 0>(h);
+      if (h->wps == 2)
+        return common ? launch_solve<256, 2, 1>(h) : launch_solve<256, 2, 0>(h);
       return common ? launch_solve<256, 3, 1>(h) : launch_solve<256, 3, 0>(h);
     case 512:
       // (512, 4) -- a 128-VGPR budget for an 8-wave workgroup -- produced NaNs on MI355X with
@@ -449,7 +451,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     h->lpt = std::string(e) != "fifo";
   if (const char* e = std::getenv("PQP_WAVES_PER_SIMD")) {
     int v = std::atoi(e);
-    if (v == 3 || v == 4)
+    if (v >= 2 && v <= 4)
       h->wps = v;
   }
   h->lds_solve = pqp::lds_bytes(d, h->nt);

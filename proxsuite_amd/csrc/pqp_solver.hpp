@@ -156,7 +156,7 @@ struct BackwardArgs
 struct Lds
 {
   lptr base;
-  int n, ne, nc, ni, nd, tmax, nt;
+  int n, ne, nc, ni, nd, tmax, nt, plen;
   int o_ne, o_nc, o_ni, o_nd, o_t2; // class offsets in doubles (class n starts at 0)
   __device__ __forceinline__ lptr at(int off) const
   {
@@ -203,7 +203,7 @@ struct Lds
   PQP_LVEC(sd, o_nd, nd, 2)
   PQP_LVEC(dS, o_nd, nd, 3)
 #undef PQP_LVEC
-  __device__ __forceinline__ int part_len() const { return gemv_part_len(nt, tmax); }
+  __device__ __forceinline__ int part_len() const { return plen; }
   __device__ __forceinline__ int red_len() const { return 2 * 4 * (nt / WAVE) + 8; }
   __device__ __forceinline__ lptr t2() const { return at(o_t2); }
   __device__ __forceinline__ lptr part() const { return at(o_t2 + tmax); }
@@ -226,6 +226,15 @@ struct Lds
   __device__ __forceinline__ liptr icnt() const { return ints(3 * nc + nd); }
 };
 
+// `part`: cross-wavefront scratch of gemv, and of gemv_dual where that routine is used (the
+// 256-thread kernels: NW * n doubles; the wider workgroups keep the gemv pair)
+__host__ __device__ inline int
+part_doubles(int nt, int tmax, int n)
+{
+  const int a = gemv_part_len(nt, tmax), b = (nt == 256) ? gemv_dual_part_len(nt, n) : 0;
+  return a > b ? a : b;
+}
+
 __host__ __device__ inline size_t
 lds_doubles(const Dims& d, int nt)
 {
@@ -241,7 +250,7 @@ lds_doubles(const Dims& d, int nt)
   s += n + ne + 2 * nc;                  // dres se si rup
   s += n + nd;                           // dF dS
   s += n + tmax + nc;                    // t1 t2 zfull
-  s += gemv_part_len(nt, (int)tmax);     // part
+  s += part_doubles(nt, (int)tmax, (int)n); // part
   s += 2 * 4 * (nt / WAVE) + 8;          // red
   s += 2 * PQP_NB * PQP_NB + 2 * PQP_NB; // top
   s += ST_COUNT;                         // stat (long long)
@@ -267,6 +276,7 @@ lds_carve(Lds& L, lptr base, const Dims& d, int nt)
   L.nd = uni(d.nd);
   L.tmax = uni(d.nd > d.n ? d.nd : d.n);
   L.nt = nt;
+  L.plen = uni(part_doubles(nt, L.tmax, L.n));
   L.o_ne = uni(16 * L.n);
   L.o_nc = uni(L.o_ne + 6 * L.ne);
   L.o_ni = uni(L.o_nc + 7 * L.nc);
@@ -850,6 +860,7 @@ struct Solver
   int n_c;       // active inequality count
   int r;         // n_eq + n_c : size of the dual block
   bool schur_dirty;
+  bool aty_fresh; // L.ATdy / L.CTdz hold A^T y, C^T z of the current iterate (see global_primal_residual)
   bool z_all_valid; // every row of Z and G is current (set by build_ZG, restored with the factorisation)
   UD ruiz_c;
   UD dual_feasibility_rhs_2;
@@ -924,6 +935,10 @@ struct Solver
     const int v = L.act()[k < 0 ? 0 : k];
     return (k < 0) ? a : d.n_eq + v;
   }
+  // out = H_s v for the dense H_s.  (A lower-triangle-only pass -- gemv_dual<NT, true> -- halves the
+  // bytes but measured SLOWER at C2: 1.00 M vs 0.87 M cycles per QP in the KKT residual; the
+  // triangular rows unbalance the wavefronts and the plain gemv keeps 16 loads per lane in flight.)
+  __device__ __forceinline__ void hess_mv(clptr v, lptr out) { mv(P.Hs(), d.n, d.n, d.n, v, out); }
   // plain mat-vec through the shared routine
   __device__ __forceinline__ void mv(cgptr M, int ld, int K, int J, clptr v, lptr out)
   {
@@ -1317,21 +1332,30 @@ struct Solver
     }
     __syncthreads();
     if (hess() == PQP_HESSIAN_DENSE) {
-      mv(P.Hs(), n, n, n, L.dx(), L.Hdx());
+      hess_mv(L.dx(), L.Hdx());
     } else {
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
         L.Hdx()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.dx()[k] : 0.0;
     }
     if (ne > 0) {
-      mv(P.As(), n, ne, n, L.sd(), L.ATdy());
-      mv(P.ATs(), ne, n, ne, L.dx(), L.Adx());
+      if constexpr (NT == 256) {
+        // A is read ONCE: row sums give A dx, column sums A^T dy
+        gemv_dual<NT>(P.As(), n, ne, n, L.dx(), L.sd(), L.Adx(), L.ATdy(), L.part());
+      } else {
+        mv(P.As(), n, ne, n, L.sd(), L.ATdy());
+        mv(P.ATs(), ne, n, ne, L.dx(), L.Adx());
+      }
     } else {
       vzero(L.ATdy(), n);
     }
     if (ni > 0) {
-      mv(P.Cs(), n, ni, n, L.zfull(), L.CTdz());
-      mv(P.CTs(), ni, n, ni, L.dx(), L.Cdx());
+      if constexpr (NT == 256) {
+        gemv_dual<NT>(P.Cs(), n, ni, n, L.dx(), L.zfull(), L.Cdx(), L.CTdz(), L.part());
+      } else {
+        mv(P.Cs(), n, ni, n, L.zfull(), L.CTdz());
+        mv(P.CTs(), ni, n, ni, L.dx(), L.Cdx());
+      }
     } else {
       vzero(L.CTdz(), n);
     }
@@ -1451,10 +1475,25 @@ struct Solver
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     double m_eq0 = 0, m_in0 = 0, m_eql = 0, m_inl = 0;
-    if (ne > 0)
-      mv(P.ATs(), ne, n, ne, L.x(), L.se());
-    if (ni > 0)
-      mv(P.CTs(), ni, n, ni, L.x(), L.rup());
+    if constexpr (NT == 256) {
+      // one pass over A_s and C_s: the row sums are A x / C x; the column sums A^T y / C^T z are
+      // what global_dual_residual needs at this same iterate, parked in the Newton by-product
+      // vectors (idle between Newton loops) and flagged by `aty_fresh`
+      if (ne > 0)
+        gemv_dual<NT>(P.As(), n, ne, n, L.x(), L.y(), L.se(), L.ATdy(), L.part());
+      else
+        vzero(L.ATdy(), n);
+      if (ni > 0)
+        gemv_dual<NT>(P.Cs(), n, ni, n, L.x(), L.z(), L.rup(), L.CTdz(), L.part());
+      else
+        vzero(L.CTdz(), n);
+      aty_fresh = true;
+    } else {
+      if (ne > 0)
+        mv(P.ATs(), ne, n, ne, L.x(), L.se());
+      if (ni > 0)
+        mv(P.CTs(), ni, n, ni, L.x(), L.rup());
+    }
     {
       cgptr de = P.dlt_eq();
       cgptr bb = P.bvec();
@@ -1532,26 +1571,31 @@ struct Solver
     // H x -> t1, A^T y -> ATdy-free scratch (t2), C^T z -> CTzin-free... use t1/t2/zfull? keep
     // three distinct n-vectors: t1, t2 and ex (free outside the Newton loop)
     if (hess() == PQP_HESSIAN_DENSE) {
-      mv(P.Hs(), n, n, n, L.x(), L.t1());
+      hess_mv(L.x(), L.t1());
     } else {
       cgptr Hs = P.Hs();
       for (int k = threadIdx.x; k < n; k += NT)
         L.t1()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x()[k] : 0.0;
     }
-    if (ne > 0)
-      mv(P.As(), n, ne, n, L.y(), L.t2());
-    else
-      vzero(L.t2(), n);
-    if (ni > 0)
-      mv(P.Cs(), n, ni, n, L.z(), L.ex());
-    else
-      vzero(L.ex(), n);
+    const bool have_products = aty_fresh; // A^T y, C^T z left by global_primal_residual
+    if (!have_products) {
+      if (ne > 0)
+        mv(P.As(), n, ne, n, L.y(), L.t2());
+      else
+        vzero(L.t2(), n);
+      if (ni > 0)
+        mv(P.Cs(), n, ni, n, L.z(), L.ex());
+      else
+        vzero(L.ex(), n);
+    }
     __syncthreads();
     {
       cgptr g = P.g();
+      clptr v_aty = have_products ? (clptr)L.ATdy() : (clptr)L.t2();
+      clptr v_ctz = have_products ? (clptr)L.CTdz() : (clptr)L.ex();
       for (int k = threadIdx.x; k < n; k += NT) {
         const double sc = dx[k] * c;
-        double hx = L.t1()[k], aty = L.t2()[k], ctz = L.ex()[k];
+        double hx = L.t1()[k], aty = v_aty[k], ctz = v_ctz[k];
         double v = hx / sc; // unscaled H x (utils.hpp:469-471)
         m0 = fmax(m0, fabs(v));
         double xu = L.x()[k] * dx[k];
@@ -2262,6 +2306,7 @@ struct Solver
     // `gdr_fresh` say that the cached values (and the LDS vectors se, rup, si / dres
     // they leave behind) still describe the current iterate.
     bool gpr_fresh = false, gdr_fresh = false;
+    aty_fresh = false;
     UD pl_cache = 0, dl_cache = 0;
     while (!done) {
       tic();
@@ -2348,6 +2393,7 @@ struct Solver
         newton_semi_smooth(bcl_eta_in);
         gpr_fresh = false; // x, y, z moved; the shifted rup / si were consumed
         gdr_fresh = false;
+        aty_fresh = false; // (and the Newton loop reused the vectors they were parked in)
 
         if (nonfinite) {
           info.status = PQP_MAX_ITER_REACHED;
@@ -2409,6 +2455,7 @@ struct Solver
             vcopy(L.y(), L.yp(), ne);
             vcopy(L.z(), L.zp(), nc);
             gdr_fresh = false; // y, z were reset
+            aty_fresh = false;
             __syncthreads();
             new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
             new_bcl_mu_eq = fmax(info.mu_eq * st.mu_update_factor, st.mu_min_eq);

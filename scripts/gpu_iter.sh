@@ -1,11 +1,18 @@
 #!/bin/bash
-# quick GPU iteration: parity tests + bench (phase stats) at the register budgets given in $1 (default "4")
+# quick GPU iteration: sanity check (seconds; aborts the rest when the kernel is broken), parity
+# tests, bench with phase stats at the register budgets given in $1 (default "3")
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-WPS_LIST=${1:-4}
-echo "== pytest gpu"; timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu.log
+WPS_LIST=${1:-3}
+echo "== quickcheck"; timeout 90 python scripts/gpu_quickcheck.py 100 2>&1 | grep -v amdgpu | tee gpurun_out/quickcheck.log
+python - <<PY || { echo "quickcheck FAILED: skipping the rest"; exit 1; }
+import re, sys
+m = re.findall(r"solved (\d+)/(\d+)", open("gpurun_out/quickcheck.log").read())
+sys.exit(0 if len(m) == 4 and all(a == b for a, b in m) else 1)
+PY
+echo "== pytest gpu"; timeout 300 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu.log
 for w in $WPS_LIST; do
-  echo "== bench wps=$w"; PQP_WAVES_PER_SIMD=$w timeout 300 python bench.py --steps 5 --warmup 1 --stats --no-cpu-baseline > gpurun_out/bench_wps$w.log 2>&1; echo "rc=$?"
+  echo "== bench wps=$w"; PQP_WAVES_PER_SIMD=$w timeout 120 python bench.py --steps 5 --warmup 1 --stats --no-cpu-baseline > gpurun_out/bench_wps$w.log 2>&1; echo "rc=$?"
   grep -v amdgpu.ids gpurun_out/bench_wps$w.log | head -19
   python - <<PY
 import json
