@@ -111,6 +111,68 @@ struct UD
   __device__ __forceinline__ UD& operator*=(double x) { return *this = v * x; }
 };
 
+// Wavefront reductions.  On the device they are pure VALU: the AMDGPU backend's own scan pattern on
+// DPP moves (row_shr 1/2/4/8 inside the 16-lane rows, row_bcast15 onto rows 1 and 3, row_bcast31
+// onto rows 2 and 3) leaves the result in lane 63, which v_readlane hands to every lane.  The
+// xor-butterfly on __shfl_xor they replace goes through the LDS crossbar (ds_bpermute): six
+// dependent LDS round trips per value, on the pipe the solver's vectors live on.
+#ifndef PQP_EMULATED_MFMA
+template<int CTRL, int ROW_MASK>
+__device__ __forceinline__ double
+dpp_move(double old, double v)
+{
+  // lanes whose source lane does not exist (or whose row is masked out) keep `old`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double
+readlane_f64(double v, int src)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+#define PQP_WAVE_REDUCE(OP, IDENT)                                                                \
+  v = OP(v, dpp_move<0x111, 0xf>(IDENT, v)); /* row_shr:1 */                                       \
+  v = OP(v, dpp_move<0x112, 0xf>(IDENT, v)); /* row_shr:2 */                                       \
+  v = OP(v, dpp_move<0x114, 0xf>(IDENT, v)); /* row_shr:4 */                                       \
+  v = OP(v, dpp_move<0x118, 0xf>(IDENT, v)); /* row_shr:8 */                                       \
+  v = OP(v, dpp_move<0x142, 0xa>(IDENT, v)); /* row_bcast:15 -> rows 1, 3 */                       \
+  v = OP(v, dpp_move<0x143, 0xc>(IDENT, v)); /* row_bcast:31 -> rows 2, 3 */                       \
+  return readlane_f64(v, 63);
+__device__ __forceinline__ double
+pqp_add(double a, double b)
+{
+  return a + b;
+}
+__device__ __forceinline__ double
+wave_sum(double v)
+{
+  PQP_WAVE_REDUCE(pqp_add, 0.0)
+}
+__device__ __forceinline__ double
+wave_max(double v)
+{
+  PQP_WAVE_REDUCE(fmax, -__builtin_inf())
+}
+__device__ __forceinline__ double
+wave_min(double v)
+{
+  PQP_WAVE_REDUCE(fmin, __builtin_inf())
+}
+#undef PQP_WAVE_REDUCE
+// sum over each 16-lane row; the total is valid in the row's LAST lane (lane & 15 == 15)
+__device__ __forceinline__ double
+row16_sum(double v)
+{
+  v += dpp_move<0x111, 0xf>(0.0, v);
+  v += dpp_move<0x112, 0xf>(0.0, v);
+  v += dpp_move<0x114, 0xf>(0.0, v);
+  v += dpp_move<0x118, 0xf>(0.0, v);
+  return v;
+}
+#else
 __device__ __forceinline__ double
 wave_sum(double v)
 {
@@ -135,6 +197,16 @@ wave_min(double v)
     v = fmin(v, __shfl_xor(v, o));
   return v;
 }
+__device__ __forceinline__ double
+row16_sum(double v)
+{
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v; // every lane of the row, its last one included
+}
+#endif
 
 // Block reductions with a parity-toggled LDS scratch: ONE barrier per reduction.
 // `red` points at 2 * 4 * (NT/64) doubles.  Every thread of the block must call
@@ -446,7 +518,7 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
 // reference solver.hpp:243-318); a pair of gemv calls reads the matrix and a transposed copy.
 // Lane layout: 16 lanes share a row (one 128-byte segment per load), a wavefront covers four
 // rows per step, each lane keeps the 8 column accumulators of its 16-column stripes; columns
-// beyond 128 are handled in further blocks of 128.  Row sums close with four xor-shuffles
+// beyond 128 are handled in further blocks of 128.  Row sums close with four DPP row shifts
 // inside the 16-lane group, column sums with two across the groups and an LDS pass across the
 // wavefronts.  `part`: gemv_dual_part_len() doubles of LDS.  v, w must not alias the outputs.
 // Two barriers with COLS, one otherwise.  (The column pass is a template flag and not a null
@@ -502,12 +574,8 @@ gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr col
           p1 = fma(m[c + 1], vv[c + 1], p1);
         }
       }
-      double pr = p0 + p1;
-      pr += __shfl_xor(pr, 1);
-      pr += __shfl_xor(pr, 2);
-      pr += __shfl_xor(pr, 4);
-      pr += __shfl_xor(pr, 8);
-      if (valid && s == 0)
+      const double pr = row16_sum(p0 + p1);
+      if (valid && s == 15)
         rowout[r] = (c0 == 0) ? pr : rowout[r] + pr;
       if (COLS) {
         const double wr = valid ? w[valid ? r : 0] : 0.0;

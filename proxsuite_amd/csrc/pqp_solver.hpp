@@ -1978,10 +1978,33 @@ struct Solver
       for (int i = threadIdx.x; i < nc; i += NT)
         L.zfull()[i] = (L.slot_of()[i] >= 0) ? 0.0 : L.z()[i]; // inactive multipliers
       __syncthreads();
-      if (ni > 0)
-        mv(P.Cs(), n, ni, n, L.zfull(), L.CTzin());
-      else
+      if (ni > 0) {
+        // C^T z over the INACTIVE rows: only rows that have just left the active set carry a
+        // nonzero multiplier (the step drives them to zero), so the rows are compacted first --
+        // indices behind the active list in L.act(), values in t2 -- and only those rows of C_s
+        // are read (typically a handful out of n_in; none at all once the active set settles)
+        int listed = 0;
+        liptr list = L.act() + n_c;
+        for (int base = 0; base < ni; base += NT) {
+          const int i = base + threadIdx.x;
+          const double zi = (i < ni) ? L.zfull()[i] : 0.0;
+          const bool f = zi != 0.0;
+          int tot;
+          const int rank = block_rank<NT>(f, L.icnt(), tot);
+          if (f) {
+            list[listed + rank] = i;
+            L.t2()[listed + rank] = zi;
+          }
+          listed += tot;
+        }
+        __syncthreads();
+        if (listed > 0)
+          gemv<NT>(P.Cs(), n, listed, n, L.t2(), L.CTzin(), L.part(), list, 0, nullptr, 0);
+        else
+          vzero(L.CTzin(), n);
+      } else {
         vzero(L.CTzin(), n);
+      }
       __syncthreads();
       for (int k = threadIdx.x; k < n; k += NT) {
         double s = L.CTzin()[k];
