@@ -533,9 +533,12 @@ gemv_dual_part_len(int nt, int n)
 // SYM = true: M is a symmetric n x n matrix (R == n), w == v, and rowout == colout receives M v
 // from the LOWER triangle alone (stripes right of a wavefront's rows are not loaded): row sums
 // over j <= r plus column sums over the strict part.
-template<int NT, bool SYM = false, bool COLS = true>
+// GATHER = true: row r of the product is row  r < rowsplit ? r : rowsplit + rowmap[r - rowsplit]
+// of M (the gemv convention; rowmap in LDS).
+template<int NT, bool SYM = false, bool COLS = true, bool GATHER = false>
 __device__ PQP_CALL void
-gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part)
+gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
+          cliptr rowmap = nullptr, int rowsplit = 0)
 {
   constexpr int NW = NT / WAVE;
   constexpr int CH = 8; // 16-column stripes per lane and column block
@@ -556,7 +559,10 @@ gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr col
       const int r = base + 4 * wid + g;
       const bool valid = r < R;
       const int rlast = base + 4 * wid + 3; // last row of this wavefront's step (wave-uniform)
-      cgptr row = M + (long)(valid ? r : (R - 1)) * ld;
+      int rsrc = valid ? r : (R - 1);
+      if (GATHER && rsrc >= rowsplit)
+        rsrc = rowsplit + rowmap[rsrc - rowsplit];
+      cgptr row = M + (long)rsrc * ld;
       double m[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
