@@ -970,7 +970,7 @@ ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
       const int base = j0 & (WAVE - 1);
 #pragma unroll
       for (int q = 0; q < NB; ++q) {
-        double yq = __shfl(val, base + q);
+        double yq = lane_bcast(val, base + q); // v_readlane: the source lane is wave-uniform
         if (q < nb && c > q && c < nb)
           val = fma(-u[q], yq, val);
       }
@@ -1012,7 +1012,7 @@ ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
 #pragma unroll
       for (int qq = 0; qq < NB; ++qq) {
         const int q = NB - 1 - qq;
-        double xq = __shfl(val, base + q);
+        double xq = lane_bcast(val, base + q);
         if (q < nb && c >= 0 && c < q)
           val = fma(-u[q], xq, val);
       }
