@@ -111,6 +111,17 @@ struct UD
   __device__ __forceinline__ UD& operator*=(double x) { return *this = v * x; }
 };
 
+// keeps a value (and the loads that produced it) alive without storing it
+__device__ __forceinline__ void
+keep_alive(double v)
+{
+#ifndef PQP_EMULATED_MFMA
+  asm volatile("" ::"v"(v));
+#else
+  (void)v;
+#endif
+}
+
 // Wavefront reductions.  On the device they are pure VALU: the AMDGPU backend's own scan pattern on
 // DPP moves (row_shr 1/2/4/8 inside the 16-lane rows, row_bcast15 onto rows 1 and 3, row_bcast31
 // onto rows 2 and 3) leaves the result in lane 63, which v_readlane hands to every lane.  The

@@ -1293,6 +1293,22 @@ struct Solver
   {
     const int n = d.n, nd = d.nd;
     const int rr = r;
+    // The triangular solves on the Schur factor below are chains of dependent block steps, each
+    // waiting for its panel of LS: touch every cache line of the factor's triangle NOW (one or
+    // two loads per thread, results unused) so that those panels come from L2 instead of HBM by
+    // the time the two mat-vecs in front of them have run.
+    double touched = 0.0;
+    if (rr > 0) {
+      cgptr LSp = P.LS();
+      const int chunks = (rr + 15) / 16 + 1;
+      for (int idx = threadIdx.x; idx < rr * chunks; idx += NT) {
+        const int j = idx / chunks, c = idx - j * chunks;
+        const long first = (long)j * nd + j, last = (long)j * nd + rr - 1; // row j, columns j .. rr-1
+        const long line = (first >> 4) + c;
+        const long e = (line << 4) > first ? (line << 4) : first;
+        touched += LSp[(e <= last) ? e : last];
+      }
+    }
     apply_Linv(bx, L.t1(), false); // t = L^{-1} bx
     for (int k = threadIdx.x; k < n; k += NT)
       L.t2()[k] = L.t1()[k] / L.dF()[k];
@@ -1326,6 +1342,7 @@ struct Solver
       __syncthreads();
     }
     apply_Linv(L.t1(), bx, true); // x = L^{-T} (.)
+    keep_alive(touched);
     count(ST_N_KKT_SOLVES);
   }
 
