@@ -1314,19 +1314,13 @@ struct Solver
       L.t2()[k] = L.t1()[k] / L.dF()[k];
     __syncthreads();
     if (rr > 0) {
-      // s_a = z_a . (t / D) - bd_a
-      if constexpr (NT == 256) {
-        // row sums over the ACTIVE rows of Zr (contiguous rows; the column gather of Zc below
-        // touches every cache line of that matrix): part is free scratch when COLS is off
-        gemv_dual<NT, false, false, true>(P.Zr(), n, rr, n, L.t2(), L.t2(), L.part(), L.part(), L.part(), L.act(),
-                                          d.n_eq);
-        for (int a = threadIdx.x; a < rr; a += NT)
-          bd[a] = L.part()[a] - bd[a];
-      } else {
-        gemv<NT>(P.Zc(), nd, n, rr, L.t2(), L.t2(), L.part(), nullptr, 0, L.act(), d.n_eq);
-        for (int a = threadIdx.x; a < rr; a += NT)
-          bd[a] = L.t2()[a] - bd[a];
-      }
+      // s_a = z_a . (t / D) - bd_a : row sums over the ACTIVE rows of Zr (contiguous rows; a column
+      // gather of Zc would touch every cache line of that matrix).  `part` is free scratch here
+      // (gemv_dual only uses it for column sums) and holds at least n_d doubles.
+      gemv_dual<NT, false, false, true>(P.Zr(), n, rr, n, L.t2(), L.t2(), L.part(), L.part(), L.part(), L.act(),
+                                        d.n_eq);
+      for (int a = threadIdx.x; a < rr; a += NT)
+        bd[a] = L.part()[a] - bd[a];
       __syncthreads();
       // (M + G) dvec = s
       toc(ST_CYC_KKT_SOLVE);
