@@ -527,7 +527,7 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
 //   colout[j] = sum_r w[r] * M[r][j]      j < n          (COLS = false: skipped, w / colout unused)
 // This is what the KKT residual needs of A and C (A dx with A^T dy, C dx with C^T dz,
 // reference solver.hpp:243-318); a pair of gemv calls reads the matrix and a transposed copy.
-// Lane layout: 16 lanes share a row (one 128-byte segment per load), a wavefront covers four
+// Lane layout: 16 lanes share a row (one 128- or 256-byte segment per load), a wavefront covers four
 // rows per step, each lane keeps the 8 column accumulators of its 16-column stripes; columns
 // beyond 128 are handled in further blocks of 128.  Row sums close with four DPP row shifts
 // inside the 16-lane group, column sums with two across the groups and an LDS pass across the
@@ -541,56 +541,84 @@ gemv_dual_part_len(int nt, int n)
   return (nt / WAVE) * n;
 }
 
-// SYM = true: M is a symmetric n x n matrix (R == n), w == v, and rowout == colout receives M v
-// from the LOWER triangle alone (stripes right of a wavefront's rows are not loaded): row sums
-// over j <= r plus column sums over the strict part.
 // GATHER = true: row r of the product is row  r < rowsplit ? r : rowsplit + rowmap[r - rowsplit]
 // of M (the gemv convention; rowmap in LDS).
-template<int NT, bool SYM = false, bool COLS = true, bool GATHER = false>
-__device__ PQP_CALL void
-gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
-          cliptr rowmap = nullptr, int rowsplit = 0)
+// two adjacent doubles in one 16-byte load (address 16-byte aligned)
+struct Pair
+{
+  double x, y;
+};
+__device__ __forceinline__ Pair
+load_pair(cgptr p)
+{
+#ifndef PQP_EMULATED_MFMA
+  typedef double pqp_d2 __attribute__((ext_vector_type(2)));
+  const pqp_d2 t = *reinterpret_cast<const PQP_GLOBAL pqp_d2*>(p);
+  return Pair{ t.x, t.y };
+#else
+  return Pair{ p[0], p[1] };
+#endif
+}
+
+// W = doubles per lane and load: 2 (16-byte loads, 32-column stripes; needs even ld / n and a
+// 16-byte aligned M) or 1.
+template<int NT, bool COLS, bool GATHER, int W>
+__device__ __forceinline__ void
+gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
+               cliptr rowmap, int rowsplit)
 {
   constexpr int NW = NT / WAVE;
-  constexpr int CH = 8; // 16-column stripes per lane and column block
+  constexpr int CH = 8 / W; // stripes of 16 * W columns per lane and column block (128 columns)
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
   const int g = lane >> 4, s = lane & 15;
-  for (int c0 = 0; c0 < n; c0 += 16 * CH) {
-    double vv[CH], acc[CH];
+  for (int c0 = 0; c0 < n; c0 += 128) {
+    double vv[CH][W], acc[CH][W];
     int off[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int col = c0 + 16 * c + s;
-      off[c] = (col < n) ? col : (n - 1); // clamped: the load stays unconditional
-      vv[c] = (col < n) ? v[off[c]] : 0.0;
-      acc[c] = 0.0;
+      const int col = c0 + 16 * W * c + W * s;
+      off[c] = (col < n) ? col : (n - W); // clamped: the load stays unconditional
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        vv[c][e] = (col + e < n) ? v[off[c] + e] : 0.0;
+        acc[c][e] = 0.0;
+      }
     }
     for (int base = 0; base < R; base += 4 * NW) {
       const int r = base + 4 * wid + g;
       const bool valid = r < R;
-      const int rlast = base + 4 * wid + 3; // last row of this wavefront's step (wave-uniform)
       int rsrc = valid ? r : (R - 1);
       if (GATHER && rsrc >= rowsplit)
         rsrc = rowsplit + rowmap[rsrc - rowsplit];
       cgptr row = M + (long)rsrc * ld;
-      double m[CH];
+      double m[CH][W];
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const int cs = c0 + 16 * c; // stripe tests are wave-uniform
-        m[c] = (cs < n && (!SYM || cs <= rlast)) ? row[off[c]] : 0.0;
+        if (c0 + 16 * W * c < n) { // stripe test is wave-uniform
+          if (W == 2) {
+            const Pair t = load_pair(row + off[c]);
+            m[c][0] = t.x;
+            m[c][W - 1] = t.y;
+          } else {
+            m[c][0] = row[off[c]];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < W; ++e)
+            m[c][e] = 0.0;
+        }
       }
       double p0 = 0, p1 = 0;
 #pragma unroll
-      for (int c = 0; c < CH; c += 2) {
-        if (SYM) {
-          p0 = fma((c0 + 16 * c + s <= r) ? m[c] : 0.0, vv[c], p0);
-          p1 = fma((c0 + 16 * (c + 1) + s <= r) ? m[c + 1] : 0.0, vv[c + 1], p1);
-        } else {
-          p0 = fma(m[c], vv[c], p0);
-          p1 = fma(m[c + 1], vv[c + 1], p1);
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          if ((c * W + e) & 1)
+            p1 = fma(m[c][e], vv[c][e], p1);
+          else
+            p0 = fma(m[c][e], vv[c][e], p0);
         }
-      }
       const double pr = row16_sum(p0 + p1);
       if (valid && s == 15)
         rowout[r] = (c0 == 0) ? pr : rowout[r] + pr;
@@ -598,19 +626,23 @@ gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr col
         const double wr = valid ? w[valid ? r : 0] : 0.0;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-          acc[c] = fma(wr, (!SYM || c0 + 16 * c + s < r) ? m[c] : 0.0, acc[c]);
+#pragma unroll
+          for (int e = 0; e < W; ++e)
+            acc[c][e] = fma(wr, m[c][e], acc[c][e]);
       }
     }
     if (COLS) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        double a = acc[c];
-        a += __shfl_xor(a, 16);
-        a += __shfl_xor(a, 32);
-        const int col = c0 + 16 * c + s;
-        if (g == 0 && col < n)
-          part[wid * n + col] = a;
-      }
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          double a = acc[c][e];
+          a += __shfl_xor(a, 16);
+          a += __shfl_xor(a, 32);
+          const int col = c0 + 16 * W * c + W * s + e;
+          if (g == 0 && col < n)
+            part[wid * n + col] = a;
+        }
     }
   }
   __syncthreads();
@@ -620,10 +652,22 @@ gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr col
 #pragma unroll
       for (int q = 1; q < NW; ++q)
         a += part[q * n + j];
-      colout[j] = SYM ? rowout[j] + a : a;
+      colout[j] = a;
     }
     __syncthreads();
   }
+}
+
+template<int NT, bool COLS = true, bool GATHER = false>
+__device__ PQP_CALL void
+gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
+          cliptr rowmap = nullptr, int rowsplit = 0)
+{
+  const bool wide = (((ld | n) & 1) == 0) && ((reinterpret_cast<unsigned long long>(M) & 15ull) == 0);
+  if (wide)
+    gemv_dual_impl<NT, COLS, GATHER, 2>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
+  else
+    gemv_dual_impl<NT, COLS, GATHER, 1>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
 }
 
 // ---------------------------------------------------------------------------

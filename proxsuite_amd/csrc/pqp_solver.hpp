@@ -935,7 +935,7 @@ struct Solver
     const int v = L.act()[k < 0 ? 0 : k];
     return (k < 0) ? a : d.n_eq + v;
   }
-  // out = H_s v for the dense H_s.  (A lower-triangle-only pass -- gemv_dual<NT, true> -- halves the
+  // out = H_s v for the dense H_s.  (A lower-triangle-only variant of gemv_dual halves the
   // bytes but measured SLOWER at C2: 1.00 M vs 0.87 M cycles per QP in the KKT residual; the
   // triangular rows unbalance the wavefronts and the plain gemv keeps 16 loads per lane in flight.)
   __device__ __forceinline__ void hess_mv(clptr v, lptr out) { mv(P.Hs(), d.n, d.n, d.n, v, out); }
@@ -1317,7 +1317,7 @@ struct Solver
       // s_a = z_a . (t / D) - bd_a : row sums over the ACTIVE rows of Zr (contiguous rows; a column
       // gather of Zc would touch every cache line of that matrix).  `part` is free scratch here
       // (gemv_dual only uses it for column sums) and holds at least n_d doubles.
-      gemv_dual<NT, false, false, true>(P.Zr(), n, rr, n, L.t2(), L.t2(), L.part(), L.part(), L.part(), L.act(),
+      gemv_dual<NT, false, true>(P.Zr(), n, rr, n, L.t2(), L.t2(), L.part(), L.part(), L.part(), L.act(),
                                         d.n_eq);
       for (int a = threadIdx.x; a < rr; a += NT)
         bd[a] = L.part()[a] - bd[a];
