@@ -562,7 +562,7 @@ load_pair(cgptr p)
 
 // W = doubles per lane and load: 2 (16-byte loads, 32-column stripes; needs even ld / n and a
 // 16-byte aligned M) or 1.
-template<int NT, bool COLS, bool GATHER, int W>
+template<int NT, bool COLS, bool GATHER, bool ROWS, int W>
 __device__ __forceinline__ void
 gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
                cliptr rowmap, int rowsplit)
@@ -581,7 +581,7 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
       off[c] = (col < n) ? col : (n - W); // clamped: the load stays unconditional
 #pragma unroll
       for (int e = 0; e < W; ++e) {
-        vv[c][e] = (col + e < n) ? v[off[c] + e] : 0.0;
+        vv[c][e] = (ROWS && col + e < n) ? v[off[c] + e] : 0.0;
         acc[c][e] = 0.0;
       }
     }
@@ -609,19 +609,21 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
             m[c][e] = 0.0;
         }
       }
-      double p0 = 0, p1 = 0;
+      if (ROWS) {
+        double p0 = 0, p1 = 0;
 #pragma unroll
-      for (int c = 0; c < CH; ++c)
+        for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int e = 0; e < W; ++e) {
-          if ((c * W + e) & 1)
-            p1 = fma(m[c][e], vv[c][e], p1);
-          else
-            p0 = fma(m[c][e], vv[c][e], p0);
-        }
-      const double pr = row16_sum(p0 + p1);
-      if (valid && s == 15)
-        rowout[r] = (c0 == 0) ? pr : rowout[r] + pr;
+          for (int e = 0; e < W; ++e) {
+            if ((c * W + e) & 1)
+              p1 = fma(m[c][e], vv[c][e], p1);
+            else
+              p0 = fma(m[c][e], vv[c][e], p0);
+          }
+        const double pr = row16_sum(p0 + p1);
+        if (valid && s == 15)
+          rowout[r] = (c0 == 0) ? pr : rowout[r] + pr;
+      }
       if (COLS) {
         const double wr = valid ? w[valid ? r : 0] : 0.0;
 #pragma unroll
@@ -658,16 +660,17 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
   }
 }
 
-template<int NT, bool COLS = true, bool GATHER = false>
+// ROWS = false: column sums only (v / rowout unused).
+template<int NT, bool COLS = true, bool GATHER = false, bool ROWS = true>
 __device__ PQP_CALL void
 gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
           cliptr rowmap = nullptr, int rowsplit = 0)
 {
   const bool wide = (((ld | n) & 1) == 0) && ((reinterpret_cast<unsigned long long>(M) & 15ull) == 0);
   if (wide)
-    gemv_dual_impl<NT, COLS, GATHER, 2>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
+    gemv_dual_impl<NT, COLS, GATHER, ROWS, 2>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
   else
-    gemv_dual_impl<NT, COLS, GATHER, 1>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
+    gemv_dual_impl<NT, COLS, GATHER, ROWS, 1>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
 }
 
 // ---------------------------------------------------------------------------

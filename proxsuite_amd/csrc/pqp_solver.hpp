@@ -1327,7 +1327,10 @@ struct Solver
       ldlt_solve<NT>(P.LS(), nd, rr, L.dS(), bd, L.top());
       toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
-      gemv<NT>(P.Zr(), n, rr, n, bd, L.t2(), L.part(), L.act(), d.n_eq, nullptr, 0);
+      if constexpr (NT == 256)
+        gemv_dual<NT, true, true, false>(P.Zr(), n, rr, n, bd, bd, L.t2(), L.t2(), L.part(), L.act(), d.n_eq);
+      else
+        gemv<NT>(P.Zr(), n, rr, n, bd, L.t2(), L.part(), L.act(), d.n_eq, nullptr, 0);
       for (int k = threadIdx.x; k < n; k += NT)
         L.t1()[k] = (L.t1()[k] - L.t2()[k]) / L.dF()[k];
       __syncthreads();
