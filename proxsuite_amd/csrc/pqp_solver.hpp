@@ -938,7 +938,13 @@ struct Solver
   // out = H_s v for the dense H_s.  (A lower-triangle-only variant of gemv_dual halves the
   // bytes but measured SLOWER at C2: 1.00 M vs 0.87 M cycles per QP in the KKT residual; the
   // triangular rows unbalance the wavefronts and the plain gemv keeps 16 loads per lane in flight.)
-  __device__ __forceinline__ void hess_mv(clptr v, lptr out) { mv(P.Hs(), d.n, d.n, d.n, v, out); }
+  __device__ __forceinline__ void hess_mv(clptr v, lptr out)
+  {
+    if constexpr (NT == 256) // column sums of the symmetric H_s = H_s v, with 16-byte loads
+      gemv_dual<NT, true, false, false>(P.Hs(), d.n, d.n, d.n, v, v, out, out, L.part());
+    else
+      mv(P.Hs(), d.n, d.n, d.n, v, out);
+  }
   // plain mat-vec through the shared routine
   __device__ __forceinline__ void mv(cgptr M, int ld, int K, int J, clptr v, lptr out)
   {
