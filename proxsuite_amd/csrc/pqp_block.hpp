@@ -585,52 +585,62 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
         acc[c][e] = 0.0;
       }
     }
-    for (int base = 0; base < R; base += 4 * NW) {
-      const int r = base + 4 * wid + g;
-      const bool valid = r < R;
-      int rsrc = valid ? r : (R - 1);
-      if (GATHER && rsrc >= rowsplit)
-        rsrc = rowsplit + rowmap[rsrc - rowsplit];
-      cgptr row = M + (long)rsrc * ld;
-      double m[CH][W];
+    // U row steps per trip: the loads of all of them are issued before the first use
+    constexpr int U = 2;
+    for (int base = 0; base < R; base += U * 4 * NW) {
+      int r[U];
+      bool valid[U];
+      double m[U][CH][W];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        if (c0 + 16 * W * c < n) { // stripe test is wave-uniform
-          if (W == 2) {
-            const Pair t = load_pair(row + off[c]);
-            m[c][0] = t.x;
-            m[c][W - 1] = t.y;
+      for (int u = 0; u < U; ++u) {
+        r[u] = base + u * 4 * NW + 4 * wid + g;
+        valid[u] = r[u] < R;
+        int rsrc = valid[u] ? r[u] : (R - 1);
+        if (GATHER && rsrc >= rowsplit)
+          rsrc = rowsplit + rowmap[rsrc - rowsplit];
+        cgptr row = M + (long)rsrc * ld;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          if (c0 + 16 * W * c < n) { // stripe test is wave-uniform
+            if (W == 2) {
+              const Pair t = load_pair(row + off[c]);
+              m[u][c][0] = t.x;
+              m[u][c][W - 1] = t.y;
+            } else {
+              m[u][c][0] = row[off[c]];
+            }
           } else {
-            m[c][0] = row[off[c]];
-          }
-        } else {
 #pragma unroll
-          for (int e = 0; e < W; ++e)
-            m[c][e] = 0.0;
+            for (int e = 0; e < W; ++e)
+              m[u][c][e] = 0.0;
+          }
         }
       }
-      if (ROWS) {
-        double p0 = 0, p1 = 0;
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
+      for (int u = 0; u < U; ++u) {
+        if (ROWS) {
+          double p0 = 0, p1 = 0;
 #pragma unroll
-          for (int e = 0; e < W; ++e) {
-            if ((c * W + e) & 1)
-              p1 = fma(m[c][e], vv[c][e], p1);
-            else
-              p0 = fma(m[c][e], vv[c][e], p0);
-          }
-        const double pr = row16_sum(p0 + p1);
-        if (valid && s == 15)
-          rowout[r] = (c0 == 0) ? pr : rowout[r] + pr;
-      }
-      if (COLS) {
-        const double wr = valid ? w[valid ? r : 0] : 0.0;
+          for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
+            for (int e = 0; e < W; ++e) {
+              if ((c * W + e) & 1)
+                p1 = fma(m[u][c][e], vv[c][e], p1);
+              else
+                p0 = fma(m[u][c][e], vv[c][e], p0);
+            }
+          const double pr = row16_sum(p0 + p1);
+          if (valid[u] && s == 15)
+            rowout[r[u]] = (c0 == 0) ? pr : rowout[r[u]] + pr;
+        }
+        if (COLS) {
+          const double wr = valid[u] ? w[valid[u] ? r[u] : 0] : 0.0;
 #pragma unroll
-          for (int e = 0; e < W; ++e)
-            acc[c][e] = fma(wr, m[c][e], acc[c][e]);
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int e = 0; e < W; ++e)
+              acc[c][e] = fma(wr, m[u][c][e], acc[c][e]);
+        }
       }
     }
     if (COLS) {
