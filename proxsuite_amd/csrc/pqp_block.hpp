@@ -1014,7 +1014,7 @@ template<int NT>
 __device__ PQP_CALL void
 ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
 {
-  constexpr int NB = PQP_NB;
+  constexpr int NB = 32; // rows per block step (one wavefront holds two blocks)
   const int a = threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
