@@ -33,7 +33,7 @@ def test_ruiz(lib, oracle, randqp):
     pc.case_ruiz(lib, oracle, randqp)
 
 
-@pytest.mark.parametrize("shape", [(10, 2, 3), (30, 7, 9), (50, 25, 50), (100, 50, 100)])
+@pytest.mark.parametrize("shape", [(10, 2, 3), (30, 7, 9), (33, 8, 11), (50, 25, 50), (100, 50, 100)])  # odd n: 8-byte-load path of gemv_dual
 def test_random_batch(lib, oracle, randqp, shape):
     n, ne, ni = shape
     pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=8 if n < 100 else 4)

@@ -35,7 +35,8 @@ def test_ruiz(lib, oracle, randqp):
 
 
 @pytest.mark.parametrize("shape", [(10, 2, 3, 32), (30, 7, 9, 32), (50, 25, 50, 128), (100, 50, 100, 64),
-                                   (60, 0, 20, 16), (60, 20, 0, 16), (200, 30, 56, 8)])
+                                   (60, 0, 20, 16), (60, 20, 0, 16), (200, 30, 56, 8),
+                                   (33, 8, 11, 16), (101, 49, 99, 16), (1, 0, 1, 4)])  # odd n: 8-byte-load path of gemv_dual
 def test_random_batch(lib, oracle, randqp, shape):
     n, ne, ni, B = shape
     pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=B)
