@@ -480,9 +480,20 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
             a3 = fma(m7, v[k + 7 * KS], a3);
             p += 8 * step;
           }
-          for (; k < Kj; k += KS) {
-            a0 = fma(p[0], v[k], a0);
-            p += step;
+          if (k < Kj) {
+            // at most 7 rows are left: ONE batch of clamped, masked loads (a row-at-a-time tail
+            // would cost a memory round trip per row)
+            double m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              m[u] = p[((k + u * KS < Kj) ? u : 0) * step];
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+              a0 = fma(m[u], (k + u * KS < Kj) ? v[k + u * KS] : 0.0, a0);
+              a1 = fma(m[u + 1], (k + (u + 1) * KS < Kj) ? v[k + (u + 1) * KS] : 0.0, a1);
+              a2 = fma(m[u + 2], (k + (u + 2) * KS < Kj) ? v[k + (u + 2) * KS] : 0.0, a2);
+              a3 = fma(m[u + 3], (k + (u + 3) * KS < Kj) ? v[k + (u + 3) * KS] : 0.0, a3);
+            }
           }
         }
         part[ks * J + j] = (a0 + a1) + (a2 + a3);

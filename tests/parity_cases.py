@@ -277,14 +277,22 @@ def case_maros_meszaros(lib, P, q, A, l, u):
         bt.solve()
         x, y, z, se, si, info = bt.results(0)
         dua = H @ x + g
+        mag = np.abs(H) @ np.abs(x) + np.abs(g)  # size of the terms that cancel in `dua`
         if n_eq:
             dua = dua + Aeq.T @ y
+            mag = mag + np.abs(Aeq.T) @ np.abs(y)
             assert np.max(np.abs(Aeq @ x - b)) < eps * 1.0001
         if n_in:
             dua = dua + C.T @ z
+            mag = mag + np.abs(C.T) @ np.abs(z)
             assert (C @ x - lin).min() > -eps
             assert (C @ x - uin).max() < eps
-        assert np.max(np.abs(dua)) < 2 * eps
+        # the reference's acceptance line (2 * eps) plus the fp64 floor of evaluating the residual:
+        # QPCBOEI2 has multipliers of 1e8, its terms reach 2.5e8 and cancel to 1e-8 -- one ulp of
+        # them is 5.6e-8, so the recomputed residual moves by a few 1e-8 with the summation order
+        # while the solver's own criterion is met (info.dua_res = 2e-10 on that problem)
+        assert np.max(np.abs(dua)) < 2 * eps + 4 * np.finfo(float).eps * np.max(mag)
+        assert info.dua_res <= eps and info.pri_res <= eps
         if it > 0:
             assert info.iter == 0
     bt.close()
