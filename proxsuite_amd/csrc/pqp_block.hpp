@@ -426,22 +426,22 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
               a3 = fma(m[u + 3], v[k + (u + 3) * KS], a3);
             }
           }
-          for (; k + 3 * KS < K; k += 4 * KS) {
-            int k1 = k + KS, k2 = k + 2 * KS, k3 = k + 3 * KS;
-            int r0 = (k < rowsplit) ? k : rowsplit + rowmap[k - rowsplit];
-            int r1 = (k1 < rowsplit) ? k1 : rowsplit + rowmap[k1 - rowsplit];
-            int r2 = (k2 < rowsplit) ? k2 : rowsplit + rowmap[k2 - rowsplit];
-            int r3 = (k3 < rowsplit) ? k3 : rowsplit + rowmap[k3 - rowsplit];
-            double m0 = col[(long)r0 * ld], m1 = col[(long)r1 * ld];
-            double m2 = col[(long)r2 * ld], m3 = col[(long)r3 * ld];
-            a0 = fma(m0, v[k], a0);
-            a1 = fma(m1, v[k1], a1);
-            a2 = fma(m2, v[k2], a2);
-            a3 = fma(m3, v[k3], a3);
-          }
-          for (; k < K; k += KS) {
-            int rk = (k < rowsplit) ? k : rowsplit + rowmap[k - rowsplit];
-            a0 = fma(col[(long)rk * ld], v[k], a0);
+          if (k < K) {
+            // at most 8 gathered rows are left: one batch of clamped, masked loads
+            double m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int ku = (k + u * KS < K) ? (k + u * KS) : k;
+              const int ru = (ku < rowsplit) ? ku : rowsplit + rowmap[ku - rowsplit];
+              m[u] = col[(long)ru * ld];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+              a0 = fma(m[u], (k + u * KS < K) ? v[k + u * KS] : 0.0, a0);
+              a1 = fma(m[u + 1], (k + (u + 1) * KS < K) ? v[k + (u + 1) * KS] : 0.0, a1);
+              a2 = fma(m[u + 2], (k + (u + 2) * KS < K) ? v[k + (u + 2) * KS] : 0.0, a2);
+              a3 = fma(m[u + 3], (k + (u + 3) * KS < K) ? v[k + (u + 3) * KS] : 0.0, a3);
+            }
           }
         } else {
           const long step = (long)KS * ld;
