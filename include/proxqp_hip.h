@@ -132,6 +132,13 @@ int pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, doubl
  * keep the solution on the GPU (the QPLayer forward). */
 int pqp_batch_result_device_ptrs(pqp_batch* h, double** x, double** y, double** z);
 
+/* (x, y, z, status, iter) of the QPs [first, first + count) packed by a device kernel into one
+ * row-major [count][dim + n_eq + n_c + 2] fp64 buffer `out` (DEVICE memory), launched on `stream`
+ * (hipStream_t; NULL = the null stream) and not synchronised: the payload of the one collective
+ * of the sharded path, the final all_gather over RCCL (reference parallel/qp_solve.hpp:41-59 has
+ * shared memory instead; proxsuite_amd/sharding.py). */
+int pqp_batch_pack_results(pqp_batch* h, int64_t first, int64_t count, double* out, void* stream);
+
 /* scaled model and equilibration of one QP (testing / reference
  * test/src/dense_ruiz_equilibration.cpp) */
 int pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A, double* b,

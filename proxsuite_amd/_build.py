@@ -46,25 +46,50 @@ def build_randqp(force: bool = False) -> Path:
     return RANDQP_LIB
 
 
+# pqp_kernels.hip is compiled once per kernel family (see its header): every solve kernel is
+# ~350 KB of inlined code and takes about a minute of hipcc time, so the objects are built in
+# parallel and linked into one shared library.
+KERNEL_TUS = (1, 2, 3, 4, 5, 6)
+OBJ_DIR = ROOT / "build" / "obj"
+
+
 def hip_sources():
-    return [CSRC / "pqp_capi.hip"]
+    return [CSRC / "pqp_capi.hip", CSRC / "pqp_kernels.hip"]
 
 
 def hip_headers():
     return sorted(CSRC.glob("*.hpp")) + sorted(INCLUDE.glob("*.h"))
 
 
-def build_hip(force: bool = False, extra_flags=()) -> Path:
-    """Cross-compiles for gfx950 (works without a GPU)."""
+def hip_flags(extra_flags=()):
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+            "-I", str(INCLUDE), "-I", str(CSRC), *extra_flags]
+
+
+def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_TUS) -> Path:
+    """Cross-compiles for gfx950 (works without a GPU).  `out` / `extra_flags` build a variant
+    of the library somewhere else (A/B runs: scripts/gpu_ab.sh); `tus` restricts the kernel
+    families that are compiled (development only: the launchers of the others are then missing
+    and the link fails unless the variant is never asked for them... so keep the default)."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    srcs = hip_sources()
-    if not force and _newer(HIP_LIB, list(srcs) + hip_headers()):
-        return HIP_LIB
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=fast", "-I", str(INCLUDE), "-I", str(CSRC), *extra_flags,
-           "-o", str(HIP_LIB), *map(str, srcs)]
-    _run(cmd)
-    return HIP_LIB
+    lib = Path(out) if out else HIP_LIB
+    deps = list(hip_sources()) + hip_headers() + [Path(__file__)]
+    if not force and not extra_flags and _newer(lib, deps):
+        return lib
+    tag = "default" if not extra_flags else "v%08x" % (hash(tuple(extra_flags)) & 0xffffffff)
+    odir = OBJ_DIR / tag
+    odir.mkdir(parents=True, exist_ok=True)
+    flags = hip_flags(extra_flags)
+    jobs = [([hipcc, *flags, "-c", str(CSRC / "pqp_capi.hip"), "-o", str(odir / "capi.o")], odir / "capi.o")]
+    for k in tus:
+        o = odir / ("kernels_%d.o" % k)
+        jobs.append(([hipcc, *flags, "-DPQP_TU=%d" % k, "-c", str(CSRC / "pqp_kernels.hip"), "-o", str(o)], o))
+    todo = [j for j in jobs if force or extra_flags or not _newer(j[1], deps)]
+    with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
+        list(ex.map(lambda j: _run(j[0]), todo))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *[str(j[1]) for j in jobs]])
+    return lib
 
 
 def build_oracle(force: bool = False) -> Path:

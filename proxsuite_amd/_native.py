@@ -36,7 +36,7 @@ class NativeLib:
                "pqp_batch_size", "pqp_batch_dense_backend", "pqp_batch_settings", "pqp_batch_init",
                "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_flush",
                "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
-               "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs",
+               "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs", "pqp_batch_pack_results",
                "pqp_batch_get_scaled", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
                "pqp_batch_launch_config")
 
@@ -68,6 +68,7 @@ class NativeLib:
         L.pqp_batch_get_backward.argtypes = [vp, C.c_int64] + [_DP] * 7
         L.pqp_batch_get_results.argtypes = [vp, C.c_int64] + [_DP] * 5 + [C.POINTER(pqp_info)]
         L.pqp_batch_result_device_ptrs.argtypes = [vp] + [C.POINTER(_DP)] * 3
+        L.pqp_batch_pack_results.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
         L.pqp_batch_get_scaled.argtypes = [vp, C.c_int64] + [_DP] * 9
         L.pqp_batch_get_stats.argtypes = [vp, C.POINTER(C.c_int64)]
         L.pqp_batch_last_solve_ms.argtypes = [vp]
@@ -262,8 +263,19 @@ class Batch:
         self.lib.check(self.lib.L.pqp_batch_get_backward(self._h, int(idx), *ptrs))
         return out
 
+    def pack_results(self, out, first=0, count=None, stream=None):
+        """(x, y, z, status, iter) of QPs [first, first+count) -> rows of the fp64 buffer `out`
+        ([count][n + n_eq + n_c + 2], DEVICE memory: a torch ROCm tensor or a raw pointer), by a
+        device kernel on `stream` (int hipStream_t or None).  Not synchronised."""
+        count = self.B - first if count is None else count
+        ptr = out.data_ptr() if hasattr(out, "data_ptr") else (out.ctypes.data if hasattr(out, "ctypes") else int(out))
+        self.lib.check(self.lib.L.pqp_batch_pack_results(self._h, int(first), int(count), C.c_void_p(ptr),
+                                                         C.c_void_p(int(stream) if stream else None)))
+        return out
+
     def set_schedule(self, longest_first=True):
-        """Dispatch order of whole-batch solves: longest-processing-time first (default) or index order."""
+        """Dispatch order of whole-batch solves: index order (default) or longest-processing-time first
+        (uses the device cycle counts of the previous whole-batch solve of this handle)."""
         self.lib.check(self.lib.L.pqp_batch_set_schedule(self._h, int(bool(longest_first))))
 
     def set_stream(self, stream):

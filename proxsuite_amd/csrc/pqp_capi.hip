@@ -13,26 +13,11 @@
 #include <string>
 #include <vector>
 
-#include "proxqp_hip.h"
-#include "pqp_solver.hpp"
+#include "pqp_host.hpp"
 
 namespace {
 
 thread_local std::string g_err;
-
-int
-fail(int code, const std::string& msg)
-{
-  g_err = msg;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                               \
-  do {                                                                                              \
-    hipError_t e_ = (expr);                                                                         \
-    if (e_ != hipSuccess)                                                                           \
-      return fail(PQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
-  } while (0)
 
 bool
 absent(double v)
@@ -58,100 +43,12 @@ dense_backend_choice(int backend, int64_t dim, int64_t n_eq, int64_t n_in, bool 
 
 } // namespace
 
-template<int NT>
-__global__ __launch_bounds__(NT) void
-pqp_setup_kernel(pqp::Batch batch)
+int
+pqp_fail(int code, const std::string& msg)
 {
-  HIP_DYNAMIC_SHARED(double, smem)
-  pqp::setup_body<NT>(batch, (long)blockIdx.x, (pqp::lptr)smem);
+  g_err = msg;
+  return code;
 }
-
-// WPS = waves per SIMD the register allocator must leave room for (512 / WPS VGPRs per
-// lane): the knob that trades spills against resident workgroups per CU.
-template<int NT, int WPS, int SPEC>
-__global__ __launch_bounds__(NT, WPS) void
-pqp_solve_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
-{
-  HIP_DYNAMIC_SHARED(double, smem)
-  // `order` (optional) is the dispatch order of the QPs: workgroups are handed out in blockIdx
-  // order, so listing the expensive QPs first shortens the tail of the launch
-  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
-  pqp::solve_body<NT, SPEC>(batch, first + slot, (pqp::lptr)smem);
-}
-
-template<int NT>
-__global__ __launch_bounds__(NT, 2) void
-pqp_backward_kernel(pqp::Batch batch, pqp::BackwardArgs bw)
-{
-  HIP_DYNAMIC_SHARED(double, smem)
-  pqp::backward_body<NT>(batch, bw, (long)blockIdx.x, (pqp::lptr)smem);
-}
-
-// Dispatch order for the next whole-batch launch: QP i goes to position
-// rank(i) = #{ j : cycles_j > cycles_i  or  (cycles_j == cycles_i and j < i) }  (descending by the
-// device cycles of the solve that just finished; O(B^2) compares, a few microseconds for B ~ 10^3-10^4).
-__global__ __launch_bounds__(64) void
-pqp_order_kernel(const long long* __restrict__ stats, int stride, int B, int* __restrict__ order)
-{
-  // keys are compared as 32-bit values (cycle counts are clamped to 2^32 - 1: an ordering
-  // heuristic, exactness of huge counts does not matter)
-  constexpr int TILE = 4096;
-  __shared__ unsigned tile[TILE];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const long long raw = (i < B) ? stats[(long)i * stride] : 0;
-  const unsigned ci = raw > 0xffffffffll ? 0xffffffffu : (raw < 0 ? 0u : (unsigned)raw);
-  int rank = 0;
-  for (int j0 = 0; j0 < B; j0 += TILE) {
-    const int cnt = (B - j0 < TILE) ? (B - j0) : TILE;
-    __syncthreads();
-    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
-      const long long r = stats[(long)(j0 + t) * stride];
-      tile[t] = r > 0xffffffffll ? 0xffffffffu : (r < 0 ? 0u : (unsigned)r);
-    }
-    __syncthreads();
-    const int split = (i - j0 < 0) ? 0 : ((i - j0 < cnt) ? (i - j0) : cnt); // j < i  <=>  t < split
-    for (int t = 0; t < split; ++t)
-      rank += (tile[t] >= ci) ? 1 : 0;
-    for (int t = split; t < cnt; ++t)
-      rank += (tile[t] > ci) ? 1 : 0;
-  }
-  if (i < B)
-    order[rank] = i;
-}
-
-struct pqp_batch
-{
-  pqp::Batch dev{};
-  int device = 0;
-  int nt = 256;
-  int wps = 3; // register budget of the solve kernel: 512 / wps VGPRs (env PQP_WAVES_PER_SIMD); 3 = 168 VGPRs measured best at C2
-  int backend = PQP_BACKEND_PRIMAL_DUAL_LDLT;
-  size_t lds_solve = 0, lds_setup = 0;
-  std::vector<pqp_settings> settings;
-  std::vector<pqp_settings> settings_uploaded; // what the device holds
-  std::vector<pqp::Cmd> cmd;
-  std::vector<char> is_initialized;
-  bool settings_dirty = true;
-  bool cmd_pending = false;
-  pqp_settings* d_settings = nullptr;
-  pqp::Cmd* d_cmd = nullptr;
-  std::vector<void*> allocs;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float last_ms = 0.f;
-  hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
-  long range_first = 0, range_count = 0;
-  // Longest-processing-time-first dispatch: after a whole-batch solve the per-QP device cycle
-  // counts (stats[q][0]) order the NEXT whole-batch solve, most expensive QP first.  QPs are
-  // independent, so the order changes nothing but the tail of the launch.  PQP_SCHEDULE=fifo
-  // disables it.
-  // QPLayer backward outputs ([B][...], allocated at the first pqp_batch_backward)
-  double *bw_dH = nullptr, *bw_dg = nullptr, *bw_dA = nullptr, *bw_db = nullptr, *bw_dC = nullptr,
-         *bw_du = nullptr, *bw_dl = nullptr, *bw_ld = nullptr;
-  bool lpt = true;
-  bool order_valid = false;
-  int* d_order = nullptr;
-
-};
 
 namespace {
 
@@ -165,36 +62,6 @@ dalloc(pqp_batch* h, T** p, size_t count)
   HIP_TRY(hipMemset(q, 0, bytes));
   h->allocs.push_back(q);
   *p = static_cast<T*>(q);
-  return PQP_OK;
-}
-
-template<int NT>
-int
-launch_setup(pqp_batch* h)
-{
-  if (h->lds_setup > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_setup_kernel<NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_setup));
-  hipLaunchKernelGGL((pqp_setup_kernel<NT>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, h->stream,
-                     h->dev);
-  HIP_TRY(hipGetLastError());
-  return PQP_OK;
-}
-
-template<int NT, int WPS, int SPEC>
-int
-launch_solve(pqp_batch* h)
-{
-  if (h->lds_solve > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS, SPEC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
-  HIP_TRY(hipEventRecord(h->ev0, h->stream));
-  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
-  const int* order = (h->lpt && h->order_valid && whole) ? h->d_order : nullptr;
-  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS, SPEC>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
-                     h->stream, h->dev, h->range_first, order);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(h->ev1, h->stream));
   return PQP_OK;
 }
 
@@ -253,39 +120,6 @@ copy_out(double* dst, const double* src_base, int64_t idx, int64_t B, size_t per
   return PQP_OK;
 }
 
-int
-dispatch_setup(pqp_batch* h)
-{
-  switch (h->nt) {
-    case 256:
-      return launch_setup<256>(h);
-    case 512:
-      return launch_setup<512>(h);
-    default:
-      return launch_setup<1024>(h);
-  }
-}
-int
-dispatch_solve(pqp_batch* h)
-{
-  // SPEC = 1: no box constraints and a dense Hessian, both known at compile time
-  const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE;
-  switch (h->nt) {
-    case 256:
-      if (h->wps == 4)
-        return common ? launch_solve<256, 4, 1>(h) : launch_solve<256, 4, 0>(h);
-      if (h->wps == 2)
-        return common ? launch_solve<256, 2, 1>(h) : launch_solve<256, 2, 0>(h);
-      return common ? launch_solve<256, 3, 1>(h) : launch_solve<256, 3, 0>(h);
-    case 512:
-      // (512, 4) -- a 128-VGPR budget for an 8-wave workgroup -- produced NaNs on MI355X with
-      // ROCm 7.2 (heavy spilling; parity-checked OK at (512, 2)), so it is not instantiated
-      return common ? launch_solve<512, 2, 1>(h) : launch_solve<512, 2, 0>(h);
-    default:
-      return common ? launch_solve<1024, 4, 1>(h) : launch_solve<1024, 4, 0>(h);
-  }
-}
-
 // the scalar half of QP::init / QP::update that lives in `settings`
 // (reference dense/wrapper.hpp:375, 754-759; helpers.hpp:174-189, 678-705)
 void
@@ -323,7 +157,7 @@ enqueue_setup(pqp_batch* h, int64_t idx, bool update_call, const double* H, cons
     return fail(PQP_ERR_INVALID_ARGUMENT,
                 "wrong model setup: the QP object is designed without box constraints, but is "
                 "initialized or updated with lower or upper box inequalities.");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   const int64_t lo = idx < 0 ? 0 : idx, hi = idx < 0 ? h->dev.B : idx + 1;
   // one queued command per QP: run what is pending before stacking another one
   for (int64_t q = lo; q < hi; ++q)
@@ -375,21 +209,6 @@ enqueue_setup(pqp_batch* h, int64_t idx, bool update_call, const double* H, cons
 
 } // namespace
 
-namespace {
-template<int NT>
-int
-launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count)
-{
-  if (h->lds_solve > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_backward_kernel<NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
-  hipLaunchKernelGGL((pqp_backward_kernel<NT>), dim3((unsigned)count), dim3(NT), h->lds_solve, h->stream,
-                     h->dev, bw);
-  HIP_TRY(hipGetLastError());
-  return PQP_OK;
-}
-} // namespace
-
 extern "C" {
 
 const char*
@@ -426,7 +245,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     return fail(PQP_ERR_NO_DEVICE, "no HIP device: libproxqp_hip has no CPU fallback");
   if (device < 0 || device >= ndev)
     return fail(PQP_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard guard_(device);
 
   pqp_batch* h = new pqp_batch();
   h->device = device;
@@ -448,12 +267,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq+n_in(+n)) > 1024 is not supported by this build");
   }
   if (const char* e = std::getenv("PQP_SCHEDULE"))
-    h->lpt = std::string(e) != "fifo";
-  if (const char* e = std::getenv("PQP_WAVES_PER_SIMD")) {
-    int v = std::atoi(e);
-    if (v >= 2 && v <= 4)
-      h->wps = v;
-  }
+    h->lpt = std::string(e) == "lpt";
   h->lds_solve = pqp::lds_bytes(d, h->nt);
   h->lds_setup = pqp::setup_lds_bytes(d, h->nt);
   if (h->lds_solve > 160 * 1024) {
@@ -564,7 +378,7 @@ pqp_batch_destroy(pqp_batch* h)
 {
   if (!h)
     return;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard_(h->device);
   for (void* p : h->allocs)
     (void)hipFree(p);
   if (h->ev0)
@@ -625,7 +439,7 @@ pqp_batch_warm_start(pqp_batch* h, int64_t idx, const double* x, const double* y
     return rc;
   if (!x && !y && !z) // helpers.hpp:724-725
     return PQP_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   // the guess must land after any queued cleanup of the results
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
@@ -668,11 +482,11 @@ pqp_batch_flush(pqp_batch* h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
   if (!h->cmd_pending || h->dev.B == 0)
     return PQP_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   if (int rc = upload_settings(h))
     return rc;
   HIP_TRY(hipMemcpy(h->d_cmd, h->cmd.data(), h->cmd.size() * sizeof(pqp::Cmd), hipMemcpyHostToDevice));
-  if (int rc = dispatch_setup(h))
+  if (int rc = pqp_launch_setup(h))
     return rc;
   HIP_TRY(hipDeviceSynchronize());
   for (auto& c : h->cmd)
@@ -720,20 +534,19 @@ pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
     return PQP_OK;
   h->range_first = first;
   h->range_count = count;
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   if (int rc = pqp_batch_flush(h))
     return rc;
   if (int rc = upload_settings(h))
     return rc;
-  if (int rc = dispatch_solve(h))
+  if (int rc = pqp_launch_solve(h))
     return rc;
   HIP_TRY(hipEventSynchronize(h->ev1));
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   if (h->lpt && first == 0 && count == h->dev.B && count > 1) {
     // feedback for the next whole-batch launch: order by the device cycles this solve took
-    hipLaunchKernelGGL((pqp_order_kernel), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, h->stream,
-                       reinterpret_cast<const long long*>(h->dev.stats), (int)pqp::ST_COUNT, (int)count, h->d_order);
-    HIP_TRY(hipGetLastError());
+    if (int rc = pqp_launch_order(h, long(count)))
+      return rc;
     h->order_valid = true;
   }
   // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
@@ -757,7 +570,7 @@ pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const doubl
     return fail(PQP_ERR_INVALID_ARGUMENT, "loss_derivatives is required");
   if (count == 0)
     return PQP_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -798,17 +611,7 @@ pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const doubl
   bw.dL_du = h->bw_du;
   bw.dL_dl = h->bw_dl;
   bw.first = long(first);
-  int rc = 0;
-  switch (h->nt) {
-    case 256:
-      rc = launch_backward<256>(h, bw, long(count));
-      break;
-    case 512:
-      rc = launch_backward<512>(h, bw, long(count));
-      break;
-    default:
-      rc = launch_backward<1024>(h, bw, long(count));
-  }
+  int rc = pqp_launch_backward(h, bw, long(count));
   if (rc)
     return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -832,7 +635,7 @@ pqp_batch_get_backward(pqp_batch* h, int64_t idx, double* dL_dH, double* dL_dg, 
     return rc;
   if (!h->bw_dH)
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_backward has not been called on this batch");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   const pqp::Dims& d = h->dev.d;
   const size_t n = size_t(d.n), ne = size_t(d.n_eq), ni = size_t(d.n_in);
   const int64_t B = h->dev.B;
@@ -851,7 +654,7 @@ pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z
 {
   if (int rc = check_idx(h, idx))
     return rc;
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -886,6 +689,22 @@ pqp_batch_result_device_ptrs(pqp_batch* h, double** x, double** y, double** z)
 }
 
 int
+pqp_batch_pack_results(pqp_batch* h, int64_t first, int64_t count, double* out, void* stream)
+{
+  if (!h || !out)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
+  if (first < 0 || count < 0 || first + count > h->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "pack range outside the batch");
+  if (count == 0)
+    return PQP_OK;
+  DeviceGuard guard_(h->device);
+  if (h->cmd_pending)
+    if (int rc = pqp_batch_flush(h))
+      return rc;
+  return pqp_launch_pack(h, long(first), long(count), out, static_cast<hipStream_t>(stream));
+}
+
+int
 pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A, double* b, double* C,
                      double* l, double* u, double* delta, double* c)
 {
@@ -893,7 +712,7 @@ pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A,
     return rc;
   if (idx < 0)
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_get_scaled addresses one QP");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -921,7 +740,7 @@ pqp_batch_get_stats(pqp_batch* h, int64_t* stats)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
   static_assert(PQP_STATS_COUNT == pqp::ST_COUNT, "stats record size");
   static_assert(sizeof(long long) == sizeof(int64_t), "stats element size");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceGuard guard_(h->device);
   HIP_TRY(hipMemcpy(stats, h->dev.stats, size_t(h->dev.B) * pqp::ST_COUNT * sizeof(int64_t), hipMemcpyDefault));
   return PQP_OK;
 }

@@ -1,0 +1,95 @@
+// Host-side state of one batch handle and the launcher entry points, shared by the
+// translation units of libproxqp_hip.so:
+//   pqp_capi.hip      host only: the C-ABI of include/proxqp_hip.h
+//   pqp_kernels.hip   the kernels, compiled once per PQP_TU value (one object per kernel
+//                     family, built in parallel: every solve kernel is ~350 KB of inlined code)
+#ifndef PQP_HOST_HPP
+#define PQP_HOST_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "proxqp_hip.h"
+#include "pqp_solver.hpp"
+
+// records `msg` for pqp_last_error() of the calling thread and returns `code`
+int pqp_fail(int code, const std::string& msg);
+#define fail pqp_fail
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return pqp_fail(PQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+struct pqp_batch
+{
+  pqp::Batch dev{};
+  int device = 0;
+  int nt = 256;
+  int backend = PQP_BACKEND_PRIMAL_DUAL_LDLT;
+  size_t lds_solve = 0, lds_setup = 0;
+  std::vector<pqp_settings> settings;
+  std::vector<pqp_settings> settings_uploaded; // what the device holds
+  std::vector<pqp::Cmd> cmd;
+  std::vector<char> is_initialized;
+  bool settings_dirty = true;
+  bool cmd_pending = false;
+  pqp_settings* d_settings = nullptr;
+  pqp::Cmd* d_cmd = nullptr;
+  std::vector<void*> allocs;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  bool solve_in_flight = false; // ev1 recorded, elapsed time not read yet (asynchronous solves)
+  hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
+  long range_first = 0, range_count = 0;
+  // QPLayer backward outputs ([B][...], allocated at the first pqp_batch_backward)
+  double *bw_dH = nullptr, *bw_dg = nullptr, *bw_dA = nullptr, *bw_db = nullptr, *bw_dC = nullptr,
+         *bw_du = nullptr, *bw_dl = nullptr, *bw_ld = nullptr;
+  // Longest-processing-time-first dispatch (OFF by default, pqp_batch_set_schedule): after a
+  // whole-batch solve the per-QP device cycle counts order the NEXT whole-batch solve of the same
+  // handle, most expensive QP first.  QPs are independent, so the order changes nothing but the
+  // tail of the launch.
+  bool lpt = false;
+  bool order_valid = false;
+  int* d_order = nullptr;
+};
+
+// the caller's current device is restored when a C-ABI entry returns (PyTorch shares the
+// thread's current HIP device with this library)
+struct DeviceGuard
+{
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device)
+  {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) {
+      switched = hipSetDevice(device) == hipSuccess;
+    }
+  }
+  ~DeviceGuard()
+  {
+    if (switched)
+      (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// launchers (pqp_kernels.hip); each picks the instantiation for h->nt / the model signature
+int pqp_launch_setup(pqp_batch* h);
+int pqp_launch_solve(pqp_batch* h);
+int pqp_launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count);
+int pqp_launch_order(pqp_batch* h, long count);
+int pqp_launch_pack(pqp_batch* h, long first, long count, double* out, hipStream_t stream);
+
+#endif

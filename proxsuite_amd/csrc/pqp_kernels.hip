@@ -1,0 +1,259 @@
+// The kernels of libproxqp_hip.so and their launchers.  Compiled once per kernel family
+// (-DPQP_TU=1..6, objects built in parallel by proxsuite_amd/_build.py); PQP_TU undefined or 0
+// compiles everything in one translation unit (the CPU emulator build of tests/emu does that).
+//   1  pqp_solve_kernel<256, ., 1>    no box constraints, dense Hessian (the C2 kernel)
+//   2  pqp_solve_kernel<256, ., 0>
+//   3  pqp_solve_kernel<512, ., .>
+//   4  pqp_solve_kernel<1024, ., .>
+//   5  pqp_backward_kernel<.>
+//   6  pqp_setup_kernel<.>, pqp_order_kernel, the dispatchers
+#include "pqp_host.hpp"
+
+#ifndef PQP_TU
+#define PQP_TU 0
+#endif
+#define PQP_TU_HAS(k) (PQP_TU == 0 || PQP_TU == (k))
+
+// Waves per SIMD the register allocator must leave room for (512 / WPS VGPRs per lane): the
+// knob that trades spills against resident workgroups per CU.  Compile-time only.
+#ifndef PQP_WPS_256
+#define PQP_WPS_256 3
+#endif
+#ifndef PQP_WPS_512
+#define PQP_WPS_512 2
+#endif
+#ifndef PQP_WPS_1024
+#define PQP_WPS_1024 4
+#endif
+
+template<int NT, int WPS, int SPEC>
+__global__ __launch_bounds__(NT, WPS) void
+pqp_solve_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  // `order` (optional) is the dispatch order of the QPs: workgroups are handed out in blockIdx
+  // order, so listing the expensive QPs first shortens the tail of the launch
+  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
+  pqp::solve_body<NT, SPEC>(batch, first + slot, (pqp::lptr)smem);
+}
+
+template<int NT, int WPS, int SPEC>
+static int
+launch_solve(pqp_batch* h)
+{
+  if (h->lds_solve > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS, SPEC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
+  const int* order = (h->lpt && h->order_valid && whole) ? h->d_order : nullptr;
+  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS, SPEC>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
+                     h->stream, h->dev, h->range_first, order);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  return PQP_OK;
+}
+
+// SPEC = 1: no box constraints and a dense Hessian, both known at compile time
+int pqp_launch_solve_256_s1(pqp_batch* h);
+int pqp_launch_solve_256_s0(pqp_batch* h);
+int pqp_launch_solve_512(pqp_batch* h, bool common);
+int pqp_launch_solve_1024(pqp_batch* h, bool common);
+
+#if PQP_TU_HAS(1)
+int
+pqp_launch_solve_256_s1(pqp_batch* h)
+{
+  return launch_solve<256, PQP_WPS_256, 1>(h);
+}
+#endif
+#if PQP_TU_HAS(2)
+int
+pqp_launch_solve_256_s0(pqp_batch* h)
+{
+  return launch_solve<256, PQP_WPS_256, 0>(h);
+}
+#endif
+#if PQP_TU_HAS(3)
+int
+pqp_launch_solve_512(pqp_batch* h, bool common)
+{
+  return common ? launch_solve<512, PQP_WPS_512, 1>(h) : launch_solve<512, PQP_WPS_512, 0>(h);
+}
+#endif
+#if PQP_TU_HAS(4)
+int
+pqp_launch_solve_1024(pqp_batch* h, bool common)
+{
+  return common ? launch_solve<1024, PQP_WPS_1024, 1>(h) : launch_solve<1024, PQP_WPS_1024, 0>(h);
+}
+#endif
+
+#if PQP_TU_HAS(5)
+template<int NT>
+__global__ __launch_bounds__(NT, 2) void
+pqp_backward_kernel(pqp::Batch batch, pqp::BackwardArgs bw)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  pqp::backward_body<NT>(batch, bw, (long)blockIdx.x, (pqp::lptr)smem);
+}
+
+template<int NT>
+static int
+launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count)
+{
+  if (h->lds_solve > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_backward_kernel<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
+  hipLaunchKernelGGL((pqp_backward_kernel<NT>), dim3((unsigned)count), dim3(NT), h->lds_solve, h->stream,
+                     h->dev, bw);
+  HIP_TRY(hipGetLastError());
+  return PQP_OK;
+}
+
+int
+pqp_launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count)
+{
+  switch (h->nt) {
+    case 256:
+      return launch_backward<256>(h, bw, count);
+    case 512:
+      return launch_backward<512>(h, bw, count);
+    default:
+      return launch_backward<1024>(h, bw, count);
+  }
+}
+#endif
+
+#if PQP_TU_HAS(6)
+template<int NT>
+__global__ __launch_bounds__(NT) void
+pqp_setup_kernel(pqp::Batch batch)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  pqp::setup_body<NT>(batch, (long)blockIdx.x, (pqp::lptr)smem);
+}
+
+// Dispatch order for the next whole-batch launch: QP i goes to position
+// rank(i) = #{ j : cycles_j > cycles_i  or  (cycles_j == cycles_i and j < i) }  (descending by the
+// device cycles of the solve that just finished; O(B^2) compares, a few microseconds for B ~ 10^3-10^4).
+__global__ __launch_bounds__(64) void
+pqp_order_kernel(const long long* __restrict__ stats, int stride, int B, int* __restrict__ order)
+{
+  // keys are compared as 32-bit values (cycle counts are clamped to 2^32 - 1: an ordering
+  // heuristic, exactness of huge counts does not matter)
+  constexpr int TILE = 4096;
+  __shared__ unsigned tile[TILE];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long raw = (i < B) ? stats[(long)i * stride] : 0;
+  const unsigned ci = raw > 0xffffffffll ? 0xffffffffu : (raw < 0 ? 0u : (unsigned)raw);
+  int rank = 0;
+  for (int j0 = 0; j0 < B; j0 += TILE) {
+    const int cnt = (B - j0 < TILE) ? (B - j0) : TILE;
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+      const long long r = stats[(long)(j0 + t) * stride];
+      tile[t] = r > 0xffffffffll ? 0xffffffffu : (r < 0 ? 0u : (unsigned)r);
+    }
+    __syncthreads();
+    const int split = (i - j0 < 0) ? 0 : ((i - j0 < cnt) ? (i - j0) : cnt); // j < i  <=>  t < split
+    for (int t = 0; t < split; ++t)
+      rank += (tile[t] >= ci) ? 1 : 0;
+    for (int t = split; t < cnt; ++t)
+      rank += (tile[t] > ci) ? 1 : 0;
+  }
+  if (i < B)
+    order[rank] = i;
+}
+
+template<int NT>
+static int
+launch_setup(pqp_batch* h)
+{
+  if (h->lds_setup > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_setup_kernel<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_setup));
+  hipLaunchKernelGGL((pqp_setup_kernel<NT>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, h->stream,
+                     h->dev);
+  HIP_TRY(hipGetLastError());
+  return PQP_OK;
+}
+
+int
+pqp_launch_setup(pqp_batch* h)
+{
+  switch (h->nt) {
+    case 256:
+      return launch_setup<256>(h);
+    case 512:
+      return launch_setup<512>(h);
+    default:
+      return launch_setup<1024>(h);
+  }
+}
+
+int
+pqp_launch_order(pqp_batch* h, long count)
+{
+  hipLaunchKernelGGL((pqp_order_kernel), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, h->stream,
+                     reinterpret_cast<const long long*>(h->dev.stats), (int)pqp::ST_COUNT, (int)count, h->d_order);
+  HIP_TRY(hipGetLastError());
+  return PQP_OK;
+}
+
+// (x, y, z, status, iter) of the QPs first .. first+count-1 packed into one row-major
+// [count][n + n_eq + n_c + 2] fp64 buffer: the payload of the path's only collective (the final
+// all_gather of a sharded batch), built on the device so that the gather never touches the host.
+__global__ __launch_bounds__(256) void
+pqp_pack_kernel(pqp::Batch batch, long first, long count, double* __restrict__ out)
+{
+  const int n = batch.d.n, ne = batch.d.n_eq, nc = batch.d.nc;
+  const long width = (long)n + ne + nc + 2;
+  const long total = count * width;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const long i = o / width;
+    const int k = (int)(o - i * width);
+    const long q = first + i;
+    double v;
+    if (k < n)
+      v = batch.x[q * n + k];
+    else if (k < n + ne)
+      v = batch.y[q * ne + (k - n)];
+    else if (k < n + ne + nc)
+      v = batch.z[q * nc + (k - n - ne)];
+    else if (k == n + ne + nc)
+      v = (double)batch.info[q].status;
+    else
+      v = (double)batch.info[q].iter;
+    out[o] = v;
+  }
+}
+
+int
+pqp_launch_pack(pqp_batch* h, long first, long count, double* out, hipStream_t stream)
+{
+  const long width = (long)h->dev.d.n + h->dev.d.n_eq + h->dev.d.nc + 2;
+  long blocks = (count * width + 255) / 256;
+  if (blocks > 4096)
+    blocks = 4096;
+  if (blocks < 1)
+    blocks = 1;
+  hipLaunchKernelGGL((pqp_pack_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, h->dev, first, count, out);
+  HIP_TRY(hipGetLastError());
+  return PQP_OK;
+}
+
+int
+pqp_launch_solve(pqp_batch* h)
+{
+  const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE;
+  switch (h->nt) {
+    case 256:
+      return common ? pqp_launch_solve_256_s1(h) : pqp_launch_solve_256_s0(h);
+    case 512:
+      return pqp_launch_solve_512(h, common);
+    default:
+      return pqp_launch_solve_1024(h, common);
+  }
+}
+#endif

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY.
 
 Builds tests/emu/libpqp_emu.so: the *unmodified* HIP sources of the product
-(proxsuite_amd/csrc/pqp_capi.hip + headers) compiled with g++ against the fiber-based
+(proxsuite_amd/csrc/pqp_capi.hip, pqp_kernels.hip + headers) compiled with g++ against the fiber-based
 SIMT emulator (hip_emu.hpp/.cpp), exposing the same C-ABI as libproxqp_hip.so.
 It exists so that kernel logic can be validated against the oracle on a box without a
 GPU.  The product package never loads it (proxsuite_amd._native only ever opens
@@ -19,8 +19,8 @@ LIB = HERE / "libpqp_emu.so"
 
 def build(force=False, debug=False):
     csrc = ROOT / "proxsuite_amd" / "csrc"
-    srcs = [csrc / "pqp_capi.hip", HERE / "hip_emu.cpp"]
-    deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", HERE / "hip_emu.hpp",
+    srcs = [csrc / "pqp_capi.hip", csrc / "pqp_kernels.hip", HERE / "hip_emu.cpp"]
+    deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", csrc / "pqp_host.hpp", HERE / "hip_emu.hpp",
                    HERE / "include" / "hip" / "hip_runtime.h", ROOT / "include" / "proxqp_hip.h",
                    ROOT / "include" / "pqp_types.h", Path(__file__)]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
@@ -29,7 +29,7 @@ def build(force=False, debug=False):
     cmd = ["g++", "-std=gnu++17", "-fPIC", "-shared", *opt, "-pthread", "-fno-strict-aliasing",
            "-Wno-unknown-pragmas", "-Wno-attributes",
            "-I", str(HERE / "include"), "-I", str(ROOT / "include"), "-I", str(csrc),
-           "-x", "c++", str(srcs[0]), str(srcs[1]), "-o", str(LIB)]
+           "-x", "c++", *map(str, srcs), "-o", str(LIB)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulator build failed:\n" + r.stdout + r.stderr)

@@ -47,6 +47,14 @@ def _worker(rank, world, port, total, shape, emu_path, out_dir):
             s.eps_abs, s.eps_rel, s.initial_guess = 1e-9, 0.0, int(InitialGuess.NO_INITIAL_GUESS)
         sb.batch.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
         sb.solve()
+        # the device-side pack kernel (here: on the emulator, into a host buffer) must produce the
+        # rows the host path builds
+        buf = np.zeros((sb.local, sb.width))
+        sb.batch.pack_results(buf, 0, sb.local)
+        lx, ly, lz, lst, lit = sb.local_results()
+        assert np.array_equal(buf[:, :n], lx) and np.array_equal(buf[:, n:n + ne], ly)
+        assert np.array_equal(buf[:, n + ne:-2], lz)
+        assert np.array_equal(buf[:, -2].astype(np.int64), lst) and np.array_equal(buf[:, -1].astype(np.int64), lit)
         x, y, z, status, iters = sb.gather()
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, y=y, z=z, status=status, iters=iters)
     finally:
