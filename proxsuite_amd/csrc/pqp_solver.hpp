@@ -2362,6 +2362,10 @@ struct Solver
     UD pl_cache = 0, dl_cache = 0;
     while (!done) {
       tic();
+      // closest-feasible mode: the primal residual norm depends on info.status (utils.hpp:241-248),
+      // which the loop changes between evaluations at an unmoved iterate -- never reuse it there
+      if (st.primal_infeasibility_solving)
+        gpr_fresh = false;
       UD pl = pl_cache, dl = dl_cache;
       const bool want_primal = (stage != 2);
       const bool want_dual_pre = (stage != 1);

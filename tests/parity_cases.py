@@ -16,10 +16,30 @@ EPS = 1e-9
 XYZ_TOL = 1e-7
 
 
+def kkt_numpy(H, g, A, b, Cm, l, u, x, y, z, l_box=None, u_box=None):
+    """The reference's universal acceptance test (test/src/dense_qp_with_eq_and_in.cpp:46-56):
+    primal and dual residual of (x, y, z) on the UNSCALED model, in plain numpy -- independent of
+    both the device code and the oracle library."""
+    n_in = Cm.shape[0] if Cm is not None and np.size(Cm) else 0
+    pri = 0.0
+    dua = H @ x + g
+    if A is not None and np.size(A):
+        pri = max(pri, float(np.max(np.abs(A @ x - b))))
+        dua = dua + A.T @ y
+    if n_in:
+        Cx = Cm @ x
+        pri = max(pri, float(np.max(np.abs(np.maximum(Cx - u, 0) + np.minimum(Cx - l, 0)))))
+        dua = dua + Cm.T @ z[:n_in]
+    if l_box is not None:
+        pri = max(pri, float(np.max(np.abs(np.maximum(x - u_box, 0) + np.minimum(x - l_box, 0)))))
+        dua = dua + z[n_in:]
+    return pri, float(np.max(np.abs(dua)))
+
+
 def kkt(oracle, m, i, x, y, z, l_box=None, u_box=None):
     pick = (lambda a: a[i]) if i is not None else (lambda a: a)
-    return oracle.kkt_residuals(pick(m.H), pick(m.g), pick(m.A), pick(m.b), pick(m.C), pick(m.l), pick(m.u),
-                                x, y, z, l_box, u_box)
+    return kkt_numpy(pick(m.H), pick(m.g), pick(m.A), pick(m.b), pick(m.C), pick(m.l), pick(m.u),
+                     x, y, z, l_box, u_box)
 
 
 def close(a, ref):
@@ -59,11 +79,30 @@ def case_random_batch(lib, oracle, randqp, n, ne, ni, B, guess=InitialGuess.NO_I
         pri, dua = kkt(oracle, m, i, x[i], y[i], z[i])
         assert pri <= EPS and dua <= EPS, (i, pri, dua)
     if compare:
-        for i in range(min(B, 16)):
-            q = oracle_solve(oracle, m, i, n, ne, ni, guess)
+        # compare == True: the first 16 QPs; compare == "all": every QP of the batch, the oracle
+        # running under its solve_in_parallel (reference parallel/qp_solve.hpp:17-39)
+        idx = range(B) if compare == "all" else range(min(B, 16))
+        qs = oracle_solve_many(oracle, [(m.H[i], m.g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i]) for i in idx],
+                               n, ne, ni, guess)
+        for i, q in zip(idx, qs):
             assert close(x[i], q.results.x) and close(y[i], q.results.y) and close(z[i], q.results.z), i
+            assert info[i].status == q.results.info.status, i
     b.close()
     return x, y, z, info
+
+
+def oracle_solve_many(oracle, models, n, ne, ni, guess=InitialGuess.NO_INITIAL_GUESS, eps=EPS, **qpkw):
+    """init + solve_in_parallel of the oracle on a list of (H, g, A, b, C, l, u[, l_box, u_box])."""
+    qs = []
+    for mod in models:
+        q = oracle.QP(n, ne, ni, **qpkw)
+        q.settings.eps_abs = eps
+        q.settings.eps_rel = 0
+        q.settings.initial_guess = guess
+        q.init(*mod)
+        qs.append(q)
+    oracle.solve_in_parallel(qs)
+    return qs
 
 
 def case_ruiz(lib, oracle, randqp, n=40, ne=20, ni=20):
@@ -110,7 +149,7 @@ def case_state_machine(lib, oracle, randqp, guess):
     def check(H, g):
         x, y, z, se, si, info = b.results()
         for i in range(B):
-            pri, dua = oracle.kkt_residuals(H[i], g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i], x[i], y[i], z[i])
+            pri, dua = kkt_numpy(H[i], g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i], x[i], y[i], z[i])
             assert pri <= EPS and dua <= EPS, (i, pri, dua)
             r = qs[i].results
             assert close(x[i], r.x) and close(y[i], r.y) and close(z[i], r.z), i
@@ -211,7 +250,7 @@ def case_box_constraints(lib, oracle, randqp, seeds=20, hessian=HessianType.Dens
     b.solve()
     x, y, z, se, si, info = b.results()
     for s in range(seeds):
-        pri, dua = oracle.kkt_residuals(H[s], g[s], A[s], bb[s], Cm[s], l[s], u[s], x[s], y[s], z[s], lb[s], ub[s])
+        pri, dua = kkt_numpy(H[s], g[s], A[s], bb[s], Cm[s], l[s], u[s], x[s], y[s], z[s], lb[s], ub[s])
         assert pri <= EPS and dua <= EPS, (s, pri, dua)
         q = oracle.QP(dim, n_eq, n_in, box_constraints=True, hessian_type=hessian)
         q.settings.eps_abs = EPS
@@ -232,7 +271,7 @@ def case_families(lib, oracle, randqp, dim):
                m.l if ni else None, m.u if ni else None)
         b.solve()
         x, y, z, se, si, info = b.results(0)
-        pri, dua = oracle.kkt_residuals(m.H, m.g, m.A, m.b, m.C, m.l, m.u, x, y, z)
+        pri, dua = kkt_numpy(m.H, m.g, m.A, m.b, m.C, m.l, m.u, x, y, z)
         assert pri <= EPS and dua <= EPS, (pri, dua, info.status)
         b.close()
 
@@ -369,3 +408,200 @@ def case_backward(lib, oracle, randqp, n=10, ne=4, ni=7, B=6, with_dual_terms=Tr
     for k in one:
         assert np.array_equal(one[k], allr[k][2]), k
     b.close()
+
+
+def case_c4_shape(lib, oracle, randqp, B=8):
+    """BASELINE.json configs[3] at its real shape: n=512, n_eq=200, n_in=400 (1024-thread
+    workgroups, blocked matrix-core LDL^T, row-wise triangular inverse), every QP against the oracle."""
+    case_random_batch(lib, oracle, randqp, 512, 200, 400, B=B, compare="all")
+
+
+def c5_models(randqp, B, dim=200, seed0=0):
+    """BASELINE.json configs[4]: dense_box_constrained_qp(dim, 0, dim) (reference
+    utils/random_qp_problems.hpp:591-628) with H <- diag(H) (benchmark/timings-diagonal-hessian.cpp:43-56)."""
+    H = np.zeros((B, dim, dim))
+    g = np.zeros((B, dim))
+    Cm = np.zeros((B, dim, dim))
+    l = np.zeros((B, dim))
+    u = np.zeros((B, dim))
+    for s in range(B):
+        randqp.set_seed(seed0 + s)
+        m = randqp.dense_box_constrained_qp(dim, 0, dim, 0.15, 1e-2)
+        H[s] = np.diag(np.diag(m.H))
+        g[s], Cm[s], l[s], u[s] = m.g, m.C, m.l, m.u
+    return H, g, Cm, l, u
+
+
+def case_c5(lib, oracle, randqp, B, sample, box, dim=200):
+    """BASELINE.json configs[4] through both of its forms: `box=False` passes the bounds as general
+    inequalities C = I (timings-box-constraints shape), `box=True` through the box-constraint feature
+    (timings-diagonal-hessian.cpp:72-92).  Every QP is KKT-gated in numpy, `sample` of them are
+    compared with the oracle; the two forms must agree with each other as well."""
+    H, g, Cm, l, u = c5_models(randqp, B, dim)
+    hess = HessianType.Diagonal
+    if box:
+        b = N.Batch(B, dim, 0, 0, box_constraints=True, hessian_type=int(hess), lib=lib)
+        settings_all(b, eps_abs=EPS, eps_rel=0)
+        b.init(-1, H, g, None, None, None, None, None, l, u)
+    else:
+        b = N.Batch(B, dim, 0, dim, hessian_type=int(hess), lib=lib)
+        settings_all(b, eps_abs=EPS, eps_rel=0)
+        b.init(-1, H, g, None, None, Cm, l, u)
+    b.solve()
+    x, y, z, se, si, info = b.results()
+    z0 = np.zeros(0)
+    for s in range(B):
+        assert info[s].status == QPSolverOutput.PROXQP_SOLVED, (s, info[s].status)
+        if box:
+            pri, dua = kkt_numpy(H[s], g[s], None, None, None, z0, z0, x[s], y[s], z[s], l[s], u[s])
+        else:
+            pri, dua = kkt_numpy(H[s], g[s], None, None, Cm[s], l[s], u[s], x[s], y[s], z[s])
+        assert pri <= EPS and dua <= EPS, (s, pri, dua)
+    idx = list(range(min(sample, B)))
+    if box:
+        qs = oracle_solve_many(oracle, [(H[i], g[i], None, None, None, None, None, l[i], u[i]) for i in idx],
+                               dim, 0, 0, box_constraints=True, hessian_type=hess)
+    else:
+        qs = oracle_solve_many(oracle, [(H[i], g[i], None, None, Cm[i], l[i], u[i]) for i in idx],
+                               dim, 0, dim, hessian_type=hess)
+    for i, q in zip(idx, qs):
+        assert close(x[i], q.results.x) and close(z[i], q.results.z), i
+        assert info[i].status == q.results.info.status, i
+    b.close()
+    return x, z
+
+
+INFEASIBLE_QP = dict(  # reference test/src/dense_qp_eq.cpp:217-256 ("infeasible qp")
+    H=2.0 * np.eye(2), g=np.array([-18.0, -12.0]), C=np.array([[1.0, 0.0], [0.0, 1.0], [-1.0, 0.0]]),
+    u=np.array([10.0, 10.0, -20.0]), l=np.full(3, -np.inf))
+
+
+def _direction_close(a, ref, tol=1e-6):
+    """certificates are rays: compare after normalisation"""
+    na, nr = float(np.max(np.abs(a))), float(np.max(np.abs(ref)))
+    if nr == 0.0:
+        return na == 0.0
+    return na > 0 and float(np.max(np.abs(a / na - ref / nr))) <= tol
+
+
+def case_infeasibility_statuses(lib, oracle):
+    """PROXQP_PRIMAL_INFEASIBLE and PROXQP_DUAL_INFEASIBLE outcomes and their certificates
+    (reference dense/utils.hpp:269-419, dense/solver.hpp:1028-1063, 1572-1580): the reference's
+    known-answer instance plus unbounded QPs / LPs; status and certificate rays against the oracle."""
+    P = INFEASIBLE_QP
+    b = N.Batch(1, 2, 0, 3, lib=lib)
+    b.init(0, P["H"], P["g"], None, None, P["C"], P["l"], P["u"])
+    settings_all(b, eps_abs=1e-9, eps_rel=0)
+    b.solve()
+    x, y, z, se, si, info = b.results(0)
+    q = oracle.QP(2, 0, 3)
+    q.init(P["H"], P["g"], None, None, P["C"], P["l"], P["u"])
+    q.settings.eps_abs, q.settings.eps_rel = 1e-9, 0
+    q.solve()
+    assert q.results.info.status == QPSolverOutput.PROXQP_PRIMAL_INFEASIBLE  # the reference's own check
+    assert info.status == QPSolverOutput.PROXQP_PRIMAL_INFEASIBLE
+    assert info.iter == q.results.info.iter and info.iter_ext == q.results.info.iter_ext
+    # the certificate dz (solver.hpp:1572-1580 leaves (dx, dy, dz) in the results): C^T dz ~ 0 with
+    # u^T dz+ - l^T dz- < 0 (utils.hpp:269-324)
+    assert _direction_close(z, q.results.z)
+    dz = z / np.max(np.abs(z))
+    assert np.max(np.abs(P["C"].T @ dz)) <= 1e-3 and float(P["u"] @ np.maximum(dz, 0)) < 0
+    b.close()
+    # dual infeasible: a direction of zero curvature along which the cost decreases for ever
+    cases = [
+        (np.diag([1.0, 1.0, 0.0]), np.array([0.0, 0.0, -1.0]), np.array([[1.0, 0.0, 0.0]]),
+         np.array([-np.inf]), np.array([1.0]), HessianType.Dense),
+        (np.zeros((3, 3)), np.array([1.0, 0.0, -1.0]), np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]),
+         np.zeros(2), np.ones(2), HessianType.Zero),
+    ]
+    for H, g, Cm, l, u, ht in cases:
+        n, ni = H.shape[0], Cm.shape[0]
+        b = N.Batch(1, n, 0, ni, hessian_type=int(ht), lib=lib)
+        settings_all(b, eps_abs=1e-9, eps_rel=0)
+        b.init(0, H, g, None, None, Cm, l, u)
+        b.solve()
+        x, y, z, se, si, info = b.results(0)
+        q = oracle.QP(n, 0, ni, hessian_type=ht)
+        q.settings.eps_abs, q.settings.eps_rel = 1e-9, 0
+        q.init(H, g, None, None, Cm, l, u)
+        q.solve()
+        assert q.results.info.status == QPSolverOutput.PROXQP_DUAL_INFEASIBLE
+        assert info.status == QPSolverOutput.PROXQP_DUAL_INFEASIBLE
+        assert info.iter == q.results.info.iter
+        assert _direction_close(x, q.results.x)
+        dx = x / np.max(np.abs(x))
+        assert np.max(np.abs(H @ dx)) <= 1e-6 and float(g @ dx) < 0 and np.max(np.abs(Cm @ dx)) <= 1e-6
+        b.close()
+
+
+def infeasible_family(randqp, seeds, dim=20):
+    """reference test/src/dense_qp_wrapper.cpp:7153-7215: strongly convex QPs pushed out of
+    feasibility (b += 10, u -= 100)."""
+    ne = ni = dim // 4
+    out = []
+    for sd in seeds:
+        randqp.set_seed(sd)
+        m = randqp.dense_strongly_convex_qp(dim, ne, ni, 0.15, 1e-2)
+        out.append((m.H, m.g, m.A, m.b + 10.0, m.C, m.l, m.u - 100.0))
+    return out, dim, ne, ni
+
+
+def case_closest_feasible(lib, oracle, randqp, seeds, max_oracle_iter_ext=None):
+    """primal_infeasibility_solving (reference dense/solver.hpp:1581-1595, 1757-1767;
+    test/src/dense_qp_wrapper.cpp:7153-7215): same instances, with and without closest-feasible
+    solving.  Status, iteration counts and solutions against the oracle; for the closest-feasible
+    runs also the reference test's own acceptance lines."""
+    models, dim, ne, ni = infeasible_family(randqp, seeds)
+    eps = 1e-5
+    seen = set()
+    for pis in (False, True):
+        qs = []
+        for mod in models:
+            q = oracle.QP(dim, ne, ni)
+            s = q.settings
+            s.eps_abs, s.eps_rel, s.initial_guess = eps, 0, InitialGuess.NO_INITIAL_GUESS
+            s.primal_infeasibility_solving, s.eps_primal_inf, s.eps_dual_inf = pis, 1e-4, 1e-4
+            q.init(*mod)
+            qs.append(q)
+        oracle.solve_in_parallel(qs)
+        keep = [i for i, q in enumerate(qs)
+                if max_oracle_iter_ext is None or q.results.info.iter_ext <= max_oracle_iter_ext]
+        B = len(keep)
+        if B == 0:
+            continue
+        b = N.Batch(B, dim, ne, ni, lib=lib)
+        settings_all(b, eps_abs=eps, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS),
+                     primal_infeasibility_solving=int(pis), eps_primal_inf=1e-4, eps_dual_inf=1e-4)
+        stack = [np.stack([models[i][k] for i in keep]) for k in range(7)]
+        b.init(-1, *stack)
+        b.solve()
+        x, y, z, se, si, info = b.results()
+        for j, i in enumerate(keep):
+            r = qs[i].results
+            H, g, A, bb, Cm, l, u = models[i]
+            assert info[j].status == r.info.status, (pis, i, info[j].status, r.info.status)
+            seen.add(int(info[j].status))
+            assert info[j].iter_ext == r.info.iter_ext, (pis, i)
+            if info[j].status == QPSolverOutput.PROXQP_SOLVED:
+                assert close(x[j], r.x) and close(y[j], r.y) and close(z[j], r.z), (pis, i)
+            elif info[j].status == QPSolverOutput.PROXQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE:
+                # the closest-feasible point is unique; the multipliers of the violated constraints
+                # are not -- they grow by residual / mu at every outer iteration (1e13 after the
+                # 10^4 iterations these runs take) and the BCL acceptance test, fed with primal
+                # residuals at the 1e-14 rounding floor, shifts a mu update by one iteration between
+                # two correct implementations: x and the well-defined multipliers are compared
+                assert close(x[j], r.x), (pis, i)
+                if ni:
+                    live = np.abs(r.z) <= 1e6
+                    assert close(z[j][live], r.z[live]), (pis, i)
+            elif info[j].status == QPSolverOutput.PROXQP_PRIMAL_INFEASIBLE:
+                assert _direction_close(np.concatenate([y[j], z[j]]), np.concatenate([r.y, r.z])), (pis, i)
+            if pis and info[j].status != QPSolverOutput.PROXQP_MAX_ITER_REACHED:
+                # the reference test's acceptance lines (dense_qp_wrapper.cpp:7189-7212)
+                scaled_eps = float(np.max(np.abs(A.T @ np.ones(ne) + Cm.T @ np.ones(ni)))) * eps
+                Cx = Cm @ x[j]
+                pri = np.max(np.abs(A.T @ (A @ x[j] - bb) + Cm.T @ (np.maximum(Cx - u, 0) + np.minimum(Cx - l, 0))))
+                dua = np.max(np.abs(H @ x[j] + g + A.T @ y[j] + Cm.T @ z[j]))
+                assert pri <= scaled_eps and dua <= eps, (i, pri, dua)
+        b.close()
+    return seen

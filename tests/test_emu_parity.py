@@ -82,3 +82,20 @@ def test_errors(lib):
 
 def test_determinism(lib, randqp):
     pc.case_determinism(lib, randqp)
+
+
+def test_infeasibility_statuses(lib, oracle):
+    pc.case_infeasibility_statuses(lib, oracle)
+
+
+def test_closest_feasible(lib, oracle, randqp):
+    """seeds whose oracle run is short enough for the emulator (the GPU test runs all 20)"""
+    seen = pc.case_closest_feasible(lib, oracle, randqp, seeds=range(6), max_oracle_iter_ext=60)
+    assert 0 in seen
+
+
+def test_c5_forms_small(lib, oracle, randqp):
+    """BASELINE.json configs[4] generator at a small dimension: C = I form and box form."""
+    xa, za = pc.case_c5(lib, oracle, randqp, B=2, sample=2, box=False, dim=24)
+    xb, zb = pc.case_c5(lib, oracle, randqp, B=2, sample=2, box=True, dim=24)
+    assert np.max(np.abs(xa - xb)) <= 1e-7 * (1 + np.max(np.abs(xa)))

@@ -91,32 +91,31 @@ def test_determinism(lib, randqp):
     pc.case_determinism(lib, randqp, 100, 50, 100, B=64)
 
 
-def test_full_size_c2_properties(lib, oracle, randqp):
+def test_full_size_c2_all_against_oracle(lib, oracle, randqp):
     """BASELINE.json configs[1]: 2048 random dense QPs, n=100 n_eq=50 n_in=100.  Every QP must
-    reach SOLVED with unscaled KKT residuals <= 1e-9; a sample is compared with the oracle."""
-    pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=2048, compare=True)
+    reach SOLVED with unscaled KKT residuals <= 1e-9 (numpy), and EVERY solution is compared with
+    the oracle's (x, y, z) and status."""
+    pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=2048, compare="all")
 
 
-def test_c5_shape_diagonal_box(lib, oracle, randqp):
-    """BASELINE.json configs[4] shape (reduced batch): diagonal Hessian + box constraints,
-    benchmark/timings-diagonal-hessian.cpp:43-92."""
-    dim, B = 200, 16
-    H = np.zeros((B, dim, dim))
-    g = np.zeros((B, dim))
-    lb = np.zeros((B, dim))
-    ub = np.zeros((B, dim))
-    for s in range(B):
-        randqp.set_seed(s)
-        m = randqp.dense_box_constrained_qp(dim, 0, dim, 0.15, 1e-2)
-        H[s] = np.diag(np.arange(1, dim + 1, dtype=float))
-        g[s], lb[s], ub[s] = m.g, m.l, m.u
-    b = N.Batch(B, dim, 0, 0, box_constraints=True, hessian_type=int(HessianType.Diagonal), lib=lib)
-    pc.settings_all(b, eps_abs=1e-9, eps_rel=0)
-    b.init(-1, H, g, None, None, None, None, None, lb, ub)
-    b.solve()
-    x, y, z, se, si, info = b.results()
-    z0 = np.zeros(0)
-    for s in range(B):
-        pri, dua = oracle.kkt_residuals(H[s], g[s], None, None, None, z0, z0, x[s], y[s], z[s], lb[s], ub[s])
-        assert pri <= 1e-9 and dua <= 1e-9, (s, pri, dua)
-    b.close()
+def test_full_shape_c4_against_oracle(lib, oracle, randqp):
+    """BASELINE.json configs[3] at its real shape (512, 200, 400): 1024-thread workgroups."""
+    pc.case_c4_shape(lib, oracle, randqp, B=8)
+
+
+@pytest.mark.parametrize("box", [False, True])
+def test_full_shape_c5_against_oracle(lib, oracle, randqp, box):
+    """BASELINE.json configs[4] (n = 200, diagonal Hessian, 200 bound pairs) at a batch that fills
+    the GPU (768 = 3 workgroups x 256 CUs), both forms; 32 QPs against the oracle, all KKT-gated."""
+    pc.case_c5(lib, oracle, randqp, B=768, sample=32, box=box)
+
+
+def test_infeasibility_statuses(lib, oracle):
+    pc.case_infeasibility_statuses(lib, oracle)
+
+
+def test_closest_feasible(lib, oracle, randqp):
+    """reference test/src/dense_qp_wrapper.cpp:7153-7215, all 20 seeds, with and without
+    primal_infeasibility_solving"""
+    seen = pc.case_closest_feasible(lib, oracle, randqp, seeds=range(20))
+    assert {0, 2, 3} <= seen, seen  # SOLVED, PRIMAL_INFEASIBLE, SOLVED_CLOSEST_PRIMAL_FEASIBLE all occur
