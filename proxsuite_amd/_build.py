@@ -19,6 +19,9 @@ CSRC = ROOT / "proxsuite_amd" / "csrc"
 INCLUDE = ROOT / "include"
 
 HIP_LIB = CSRC / "libproxqp_hip.so"
+# the same library with the per-phase device timers and event counters compiled in (-DPQP_STATS):
+# used by bench.py OUTSIDE its timed region and by the profiling scripts, never by the product path
+HIP_STATS_LIB = CSRC / "libproxqp_hip_stats.so"
 RANDQP_LIB = CSRC / "libpqp_randqp.so"
 
 HOST_CXXFLAGS = ["-O3", "-march=x86-64-v3", "-mtune=generic", "-std=gnu++17", "-fPIC", "-fopenmp"]
@@ -90,6 +93,14 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
         list(ex.map(lambda j: _run(j[0]), todo))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *[str(j[1]) for j in jobs]])
     return lib
+
+
+def build_hip_stats(force: bool = False) -> Path:
+    lib = HIP_STATS_LIB
+    deps = list(hip_sources()) + hip_headers() + [Path(__file__)]
+    if not force and _newer(lib, deps):
+        return lib
+    return build_hip(force=True, extra_flags=("-DPQP_STATS",), out=lib)
 
 
 def build_oracle(force: bool = False) -> Path:

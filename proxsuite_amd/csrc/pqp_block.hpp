@@ -1012,6 +1012,150 @@ ldlt_factor_reg(LoadFn load, gptr U, int ld, int m, lptr d, lptr cbuf, PQP_LDS l
 }
 
 // ---------------------------------------------------------------------------
+// Register-resident LDL^T that hands back the INVERSE factor: on exit
+//     Wl[i][j] = (L^{-1})_ij  (j < i; unit diagonal written, strict upper never touched), d[] in LDS,
+// so that  S^{-1} = W^T D^{-1} W  is applied with two chain-free mat-vecs and edited in place by
+// the rank-1 routines of the solver (append a row, delete a row).
+// Same right-looking elimination as ldlt_factor_reg, run Gauss-Jordan style on [S | I]: the
+// elimination of column k, a_ij -= a_ik l_jk, is also applied to the identity block,
+//     E_ic -= l_ik E_kc   (i > k, c <= k),
+// which leaves E = L^{-1}.  Row k of E is final at step k and rides through LDS beside column k
+// of A under the SAME barrier, so the inverse costs no extra synchronisation.  E uses the
+// transposed thread mapping -- thread (ti, tj) owns E[16 bi + tj][16 bj + ti] -- so that its
+// multipliers l_ik are the `cj` values the A update already holds, and the final stores are
+// coalesced along a row of W.  Liveness: block (bi, bj) of E is born at block step bj and
+// stored at block step bi; block column kb of A dies after block step kb (L itself is not kept).
+// `cbuf`: 6 * 16 * MB doubles of LDS (raw column, scaled column, E row; double-buffered).
+// ---------------------------------------------------------------------------
+template<int NT, int MB, typename LoadFn>
+__device__ PQP_CALL void
+ldlt_inverse_reg(LoadFn load, gptr Wl, int ld, int m, lptr d, lptr cbuf)
+{
+  static_assert(NT == 256, "ldlt_inverse_reg lays the workgroup out as 16 x 16 threads");
+  constexpr int NB = 16;
+  const int ti = threadIdx.x & (NB - 1), tj = threadIdx.x / NB;
+  const int mb = (m + NB - 1) / NB;
+  double a[MB * (MB + 1) / 2];
+  double e[MB * (MB + 1) / 2];
+#pragma unroll
+  for (int bi = 0; bi < MB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = bi * NB + ti, j = bj * NB + tj;
+      const int ic = (i < m) ? i : m - 1;
+      const int jc = (j < ic) ? j : ic;
+      a[bi * (bi + 1) / 2 + bj] = load(ic, jc);
+      e[bi * (bi + 1) / 2 + bj] = 0.0;
+    }
+#pragma unroll
+  for (int bi = 0; bi < MB; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = bi * NB + ti, j = bj * NB + tj;
+      if (!(i < m && j <= i))
+        a[bi * (bi + 1) / 2 + bj] = 0.0;
+    }
+  int par = 0;
+#pragma unroll
+  for (int kb = 0; kb < MB; ++kb) {
+    if (kb < mb) {
+      const int nk = (m - kb * NB < NB) ? (m - kb * NB) : NB;
+      for (int kk = 0; kk < nk; ++kk) {
+        const int k = kb * NB + kk;
+        lptr cb = cbuf + par * (3 * MB * NB);
+        const double dkw = lane_bcast(a[kb * (kb + 1) / 2 + kb], ((kk & 3) << 4) + kk);
+        if (tj == kk) {
+          const double inv = 1.0 / dkw;
+#pragma unroll
+          for (int bi = kb; bi < MB; ++bi)
+            if (bi < mb) {
+              const double raw = a[bi * (bi + 1) / 2 + kb];
+              cb[bi * NB + ti] = raw;
+              cb[MB * NB + bi * NB + ti] = raw * inv;
+            }
+          // row k of E (thread (ti, tj = kk) owns E[16 kb + kk][16 bj + ti])
+#pragma unroll
+          for (int bj = 0; bj <= kb; ++bj) {
+            const int c = bj * NB + ti;
+            cb[2 * MB * NB + bj * NB + ti] = (c < k) ? e[kb * (kb + 1) / 2 + bj] : ((c == k) ? 1.0 : 0.0);
+          }
+          if (ti == kk)
+            d[k] = dkw;
+        }
+        __syncthreads();
+        double ci[MB], cj[MB], er[MB];
+#pragma unroll
+        for (int b = kb; b < MB; ++b) {
+          ci[b] = (b < mb) ? cb[b * NB + ti] : 0.0;
+          cj[b] = (b < mb) ? cb[MB * NB + b * NB + tj] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b <= kb; ++b)
+          er[b] = cb[2 * MB * NB + b * NB + ti];
+#pragma unroll
+        for (int bi = kb; bi < MB; ++bi)
+          if (bi < mb) { // uniform: block rows past the matrix are skipped
+#pragma unroll
+            for (int bj = kb + 1; bj <= bi; ++bj)
+              a[bi * (bi + 1) / 2 + bj] = fma(-ci[bi], cj[bj], a[bi * (bi + 1) / 2 + bj]);
+            // E[i][c] -= l_ik E[k][c] for the rows i = 16 bi + tj > k of this thread
+            const double lik = (bi * NB + tj > k) ? cj[bi] : 0.0;
+#pragma unroll
+            for (int bj = 0; bj <= kb; ++bj)
+              e[bi * (bi + 1) / 2 + bj] = fma(-lik, er[bj], e[bi * (bi + 1) / 2 + bj]);
+          }
+        if (tj > kk) { // the rest of block column kb of A
+#pragma unroll
+          for (int bi = kb; bi < MB; ++bi)
+            if (bi < mb)
+              a[bi * (bi + 1) / 2 + kb] = fma(-ci[bi], cj[kb], a[bi * (bi + 1) / 2 + kb]);
+        }
+        par ^= 1;
+      }
+      // block row kb of E is final: rows 16 kb + tj, columns 16 bj + ti (coalesced along ti)
+      const int row = kb * NB + tj;
+      if (row < m) {
+#pragma unroll
+        for (int bj = 0; bj <= kb; ++bj) {
+          const int c = bj * NB + ti;
+          if (c < row)
+            Wl[(long)row * ld + c] = e[kb * (kb + 1) / 2 + bj];
+          else if (c == row)
+            Wl[(long)row * ld + c] = 1.0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// inclusive prefix sum of one double per thread over the workgroup (threads past `count`
+// contribute 0).  `scratch`: NT / 64 doubles of LDS, free again after the call.  Two barriers.
+template<int NT>
+__device__ __forceinline__ double
+block_scan_inclusive(double v, lptr scratch)
+{
+  constexpr int NW = NT / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const double up = __shfl_up(v, o);
+    if (lane >= o)
+      v += up;
+  }
+  if (lane == WAVE - 1)
+    scratch[wid] = v;
+  __syncthreads();
+  double off = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w)
+    if (w < wid)
+      off += scratch[w];
+  __syncthreads();
+  return v + off;
+}
+
+// ---------------------------------------------------------------------------
 // Solve (L D L^T) x = v in place for an LDS vector v (length m <= NT) using the
 // upper-mirror factor of ldlt_factor<NT, false>.  Restates reference
 // include/proxsuite/linalg/dense/solve.hpp:15-26 (forward unit-lower sweep,
@@ -1518,7 +1662,7 @@ ldlt_factor_mfma(gptr M, int ld, int m, lptr d, lptr top)
 //     W_ij = -inv(L_ii) * sum_{k=j}^{i-1} L_ik W_kj,
 // W_kj read back from WL (rows k < i are complete: one barrier per block row).
 // ---------------------------------------------------------------------------
-template<int NT>
+template<int NT, bool WRITE_WU = true>
 __device__ PQP_CALL void
 tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
 {
@@ -1531,7 +1675,8 @@ tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
   // zero they were allocated with: only the unit diagonal is (re)written here
   for (int k = threadIdx.x; k < n; k += NT) {
     WL[(long)k * ld + k] = 1.0;
-    WU[(long)k * ld + k] = 1.0;
+    if (WRITE_WU)
+      WU[(long)k * ld + k] = 1.0;
   }
   __syncthreads();
   for (int j = w; j < nbk; j += NWV) {
@@ -1544,7 +1689,7 @@ tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
         const double v = F[(long)gr * ld + gc];
         if (row > col)
           WL[(long)gr * ld + gc] = v;
-        else
+        else if (WRITE_WU)
           WU[(long)gr * ld + gc] = v;
       }
     }
@@ -1595,7 +1740,7 @@ tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
         const int rowl = i0 + lk + 4 * q;
         if (rowl < n)
           WL[(long)rowl * ld + j0 + lr] = -Wij[q];
-        if (ir < n)
+        if (WRITE_WU && ir < n)
           WU[(long)(j0 + lk + 4 * q) * ld + ir] = -WijT[q];
       }
     }

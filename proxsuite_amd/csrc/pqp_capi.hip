@@ -319,10 +319,10 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   ALLOC(D.Zr, B * nd * n)
   ALLOC(D.Zc, B * nd * n)
   ALLOC(D.G, B * nd * nd)
+  ALLOC(D.WS, B * nd * nd)
   ALLOC(D.LS, B * nd * nd)
   ALLOC(D.dS, B * nd)
   ALLOC(D.act, B * nc)
-  ALLOC(D.zvalid, B * nd)
   ALLOC(D.stats, B * size_t(pqp::ST_COUNT))
   ALLOC(h->d_order, B)
   ALLOC(h->d_settings, B)

