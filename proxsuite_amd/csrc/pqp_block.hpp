@@ -220,8 +220,9 @@ row16_sum(double v)
 #endif
 
 // Block reductions with a parity-toggled LDS scratch: ONE barrier per reduction.
-// `red` points at 2 * 4 * (NT/64) doubles.  Every thread of the block must call
+// `red` points at 2 * RED_VALS * (NT/64) doubles.  Every thread of the block must call
 // these in the same order (the parity lives in a register).
+constexpr int RED_VALS = 16; // values one fused reduction can carry
 template<int NT>
 struct Reducer
 {
@@ -233,7 +234,49 @@ struct Reducer
     , parity(0)
   {
   }
-  __device__ __forceinline__ lptr slot() { return red + parity * 4 * NW; }
+  __device__ __forceinline__ lptr slot() { return red + parity * RED_VALS * NW; }
+
+  // NS sums and NM maxima in ONE barrier interval (a barrier interval of this kernel costs a few
+  // thousand cycles under load, the extra wave reductions a few hundred)
+  template<int NS, int NM>
+  __device__ __forceinline__ void mixed(double (&sv)[NS > 0 ? NS : 1], double (&mv)[NM > 0 ? NM : 1])
+  {
+    static_assert(NS + NM <= RED_VALS, "too many values for one fused reduction");
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      sv[i] = wave_sum(sv[i]);
+#pragma unroll
+    for (int i = 0; i < NM; ++i)
+      mv[i] = wave_max(mv[i]);
+    lptr s = slot();
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+      const int w = threadIdx.x / WAVE;
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+        s[i * NW + w] = sv[i];
+#pragma unroll
+      for (int i = 0; i < NM; ++i)
+        s[(NS + i) * NW + w] = mv[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      double r = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        r += s[i * NW + w];
+      sv[i] = uni(r);
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      double r = s[(NS + i) * NW];
+#pragma unroll
+      for (int w = 1; w < NW; ++w)
+        r = fmax(r, s[(NS + i) * NW + w]);
+      mv[i] = uni(r);
+    }
+    parity ^= 1;
+  }
 
   __device__ __forceinline__ double sum(double v)
   {

@@ -128,6 +128,9 @@ enum
   ST_N_DELETE,        // rows deleted from it (reference delete_at)
   ST_BYTES_ENGINE,    // compulsory HBM bytes of the engine: every matrix pass priced at its size
   ST_N_REFACTORIZE,   // refinement fallbacks that rebuilt an edited factor (reference solver.hpp:474-532)
+  ST_CYC_LS_EVAL,     // line search: phi'(alpha) at every breakpoint (sub-phase of ST_CYC_LINESEARCH)
+  ST_CYC_CERT,        // infeasibility certificates (sub-phase of ST_CYC_NEWTON_MISC)
+  ST_CYC_UPDATE,      // iterate update + inner stopping criterion (sub-phase of ST_CYC_NEWTON_MISC)
   ST_COUNT
 };
 
@@ -229,7 +232,7 @@ struct Lds
   PQP_LVEC(dS, o_nd, nd, 3)
 #undef PQP_LVEC
   __device__ __forceinline__ int part_len() const { return plen; }
-  __device__ __forceinline__ int red_len() const { return 2 * 4 * (nt / WAVE) + 8; }
+  __device__ __forceinline__ int red_len() const { return 2 * RED_VALS * (nt / WAVE) + 8; }
   __device__ __forceinline__ lptr t2() const { return at(o_t2); }
   __device__ __forceinline__ lptr part() const { return at(o_t2 + tmax); }
   __device__ __forceinline__ lptr red() const { return at(o_t2 + tmax + part_len()); }
@@ -279,7 +282,7 @@ lds_doubles(const Dims& d, int nt)
   s += n + nd;                           // dF dS
   s += n + tmax + nc;                    // t1 t2 zfull
   s += part_doubles(nt, (int)tmax, (int)n); // part
-  s += 2 * 4 * (nt / WAVE) + 8;          // red
+  s += 2 * RED_VALS * (nt / WAVE) + 8;   // red
   s += TOP_DOUBLES;                      // top
   s += PARK_DOUBLES;                     // outer-loop scalars parked during the Newton loop
   s += ST_COUNT + 1;                     // stat (long long) + the time mark
@@ -712,7 +715,7 @@ ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl
 __host__ __device__ inline size_t
 setup_lds_bytes(const Dims& d, int nt)
 {
-  return (size_t)(2 * d.ntot + 2 * 4 * (nt / WAVE) + 16) * sizeof(double);
+  return (size_t)(2 * d.ntot + 2 * RED_VALS * (nt / WAVE) + 16) * sizeof(double);
 }
 
 template<int NT>
@@ -974,6 +977,21 @@ struct Solver
       L.stat()[which] += t - L.stat()[ST_COUNT];
       L.stat()[ST_COUNT] = t;
     }
+#endif
+  }
+  // nested sub-phase timers (no shared mark: -t at the start, +t at the end)
+  __device__ __forceinline__ void sub_tic(int which)
+  {
+#ifdef PQP_STATS
+    if (threadIdx.x == 0)
+      L.stat()[which] -= clock64();
+#endif
+  }
+  __device__ __forceinline__ void sub_toc(int which)
+  {
+#ifdef PQP_STATS
+    if (threadIdx.x == 0)
+      L.stat()[which] += clock64();
 #endif
   }
   __device__ __forceinline__ void count(int which, long long v = 1)
@@ -2125,9 +2143,22 @@ struct Solver
       s_dz2 += L.dz()[k] * L.dz()[k];
       s_dzz += L.dz()[k] * L.z()[k];
     }
-    R.sum4(s_dxHdx, s_adx2, s_dx2, s_e2);
-    R.sum4(s_xHdx, s_errdx, s_adxres, s_eres);
-    R.sum2(s_dz2, s_dzz);
+    {
+      // the ten coefficient sums in one barrier interval
+      double sv[10] = { s_dxHdx, s_adx2, s_dx2, s_e2, s_xHdx, s_errdx, s_adxres, s_eres, s_dz2, s_dzz };
+      double none[1] = { 0.0 };
+      R.template mixed<10, 0>(sv, none);
+      s_dxHdx = sv[0];
+      s_adx2 = sv[1];
+      s_dx2 = sv[2];
+      s_e2 = sv[3];
+      s_xHdx = sv[4];
+      s_errdx = sv[5];
+      s_adxres = sv[6];
+      s_eres = sv[7];
+      s_dz2 = sv[8];
+      s_dzz = sv[9];
+    }
     const double nu = gpdal ? 1.0 : double(info.nu);
     double a0 = s_dxHdx + info.mu_eq_inv * s_adx2 + info.rho * s_dx2 + s_e2 * info.mu_eq_inv * nu;
     double b0 = s_xHdx + s_errdx + info.mu_eq_inv * s_adxres + nu * info.mu_eq_inv * s_eres;
@@ -2138,6 +2169,7 @@ struct Solver
     // breakpoints (linesearch.hpp:378-391): every breakpoint gets its own thread and
     // its own phi'(alpha) -- no sort, no sequential walk
     const double INF = __builtin_inf();
+    sub_tic(ST_CYC_LS_EVAL);
     double first_pos_alpha = INF;
     double my_alpha[2] = { -1.0, -1.0 };
     double my_grad[2] = { 0.0, 0.0 };
@@ -2166,9 +2198,16 @@ struct Solver
       }
     }
     count(ST_N_LS_BREAKPOINTS, cnt);
+    sub_toc(ST_CYC_LS_EVAL);
     // smallest breakpoint with a non-negative slope: the scan of :427-468 stops there
-    const double afp = R.min(first_pos_alpha);
-    const double cntd = R.sum((double)cnt);
+    double afp, cntd;
+    {
+      double sv[1] = { (double)cnt };
+      double mv[1] = { -first_pos_alpha };
+      R.template mixed<1, 1>(sv, mv);
+      cntd = sv[0];
+      afp = -mv[0];
+    }
     if (cntd == 0.0) { // :405-419
       double ai, bi;
       ls_ineq_terms(0.0, ai, bi);
@@ -2184,8 +2223,13 @@ struct Solver
           aln = fmax(aln, my_alpha[rep]); // last breakpoint strictly before it
       }
     }
-    gfp = R.max(gfp);
-    aln = R.max(aln);
+    {
+      double none[1] = { 0.0 };
+      double mv[2] = { gfp, aln };
+      R.template mixed<0, 2>(none, mv);
+      gfp = mv[0];
+      aln = mv[1];
+    }
     double gln = -INF;
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep)
@@ -2205,68 +2249,30 @@ struct Solver
     return fabs(aln - gln * (afp - aln) / (gfp - gln)); // :534-536
   }
 
-  // reference utils.hpp:269-324 ; mutates ATdy, CTdz, dy, dz in place
-  __device__ __forceinline__ bool primal_infeasibility_certificate()
-  {
-    const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
-    const double c = ruiz_c;
-    double ndy = 0, ndz = 0, zero = 0;
-    for (int k = threadIdx.x; k < ne; k += NT)
-      ndy = fmax(ndy, fabs(L.dy()[k]));
-    for (int k = threadIdx.x; k < nc; k += NT)
-      ndz = fmax(ndz, fabs(L.dz()[k]));
-    R.max3(ndy, ndz, zero);
-    if (!(ndy != 0 || ndz != 0))
-      return false;
-    double lb1 = 0, nrm_dy = 0, nrm_dz = 0, lb2 = 0;
-    {
-      cgptr dx = P.dlt_x();
-      for (int k = threadIdx.x; k < n; k += NT) {
-        L.ATdy()[k] /= dx[k] * c;
-        L.CTdz()[k] /= dx[k] * c;
-        lb2 = fmax(lb2, fabs(L.ATdy()[k] + L.CTdz()[k]));
-      }
-      cgptr de = P.dlt_eq();
-      for (int k = threadIdx.x; k < ne; k += NT) {
-        lb1 += L.dy()[k] * L.bs()[k];
-        L.dy()[k] = L.dy()[k] * de[k] / c;
-        nrm_dy = fmax(nrm_dy, fabs(L.dy()[k]));
-      }
-      cgptr di = P.dlt_in();
-      for (int k = threadIdx.x; k < ni; k += NT) {
-        double v = L.dz()[k];
-        lb1 += (v > 0 ? v : 0.0) * L.us()[k];
-        lb1 -= (v < 0 ? v : 0.0) * L.ls()[k];
-        L.dz()[k] = v * di[k] / c;
-        nrm_dz = fmax(nrm_dz, fabs(L.dz()[k]));
-      }
-      if (has_box()) {
-        cgptr db = P.dlt_box();
-        for (int k = threadIdx.x; k < n; k += NT) {
-          double v = L.dz()[ni + k];
-          lb1 += (v > 0 ? v : 0.0) * L.ubs()[k];
-          lb1 -= (v < 0 ? v : 0.0) * L.lbs()[k];
-          L.dz()[ni + k] = db[k] * v / c;
-          nrm_dz = fmax(nrm_dz, fabs(L.dz()[ni + k]));
-        }
-      }
-    }
-    lb1 = R.sum(lb1);
-    R.max3(nrm_dy, nrm_dz, lb2);
-    double upper_bound = st.eps_primal_inf * fmax(nrm_dy, nrm_dz);
-    return lb2 <= upper_bound && lb1 <= -upper_bound;
-  }
-
-  // reference utils.hpp:343-419 ; mutates Adx, Cdx, Hdx, dx in place
-  __device__ __forceinline__ bool dual_infeasibility_certificate()
+  // Both infeasibility certificates of one Newton step (reference utils.hpp:269-324 primal,
+  // :343-419 dual; like them, mutates ATdy, CTdz, dy, dz and Adx, Cdx, Hdx, dx in place) with ALL
+  // their norms and sums in ONE fused reduction -- the two tests are independent, and the reference's
+  // early exits and intermediate norms only gate arithmetic whose result is then unused:
+  //   * primal: dy = dz = 0  <=>  the unscaled norms nrm_dy = nrm_dz = 0 (the scalings are positive);
+  //   * dual: "some constraint breaks first_cond" is a maximum of a per-constraint signed value
+  //     against bound = |dx|_inf eps_dual_inf, which is known only after the reduction: the value
+  //     is reduced, the comparison made afterwards.
+  __device__ __forceinline__ void infeasibility_certificates(bool& primal_infeasible, bool& dual_infeasible)
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     const double c = ruiz_c;
-    double gdx = 0, ndx = 0, nadx = 0, nhdx = 0;
+    const double NEG = -__builtin_inf();
+    double lb1 = 0, gdx = 0;                          // sums
+    double nrm_dy = 0, nrm_dz = 0, lb2 = 0;           // primal maxima
+    double ndx = 0, nadx = 0, nhdx = 0, mviol = NEG;  // dual maxima
     {
       cgptr dx = P.dlt_x();
       for (int k = threadIdx.x; k < n; k += NT) {
-        L.Hdx()[k] /= dx[k] * c;
+        const double sc = dx[k] * c;
+        L.ATdy()[k] /= sc;
+        L.CTdz()[k] /= sc;
+        lb2 = fmax(lb2, fabs(L.ATdy()[k] + L.CTdz()[k]));
+        L.Hdx()[k] /= sc;
         nhdx = fmax(nhdx, fabs(L.Hdx()[k]));
         gdx += L.dx()[k] * L.gs()[k];
         L.dx()[k] *= dx[k];
@@ -2274,54 +2280,65 @@ struct Solver
       }
       cgptr de = P.dlt_eq();
       for (int k = threadIdx.x; k < ne; k += NT) {
+        lb1 += L.dy()[k] * L.bs()[k];
+        L.dy()[k] = L.dy()[k] * de[k] / c;
+        nrm_dy = fmax(nrm_dy, fabs(L.dy()[k]));
         L.Adx()[k] /= de[k];
         nadx = fmax(nadx, fabs(L.Adx()[k]));
       }
       cgptr di = P.dlt_in();
-      for (int k = threadIdx.x; k < ni; k += NT)
-        L.Cdx()[k] /= di[k];
+      for (int k = threadIdx.x; k < ni; k += NT) {
+        const double v = L.dz()[k];
+        lb1 += (v > 0 ? v : 0.0) * L.us()[k];
+        lb1 -= (v < 0 ? v : 0.0) * L.ls()[k];
+        L.dz()[k] = v * di[k] / c;
+        nrm_dz = fmax(nrm_dz, fabs(L.dz()[k]));
+        const double w = L.Cdx()[k] / di[k];
+        L.Cdx()[k] = w;
+        // utils.hpp:381-398: two-sided bound -> |w| <= bound; no upper bound -> -w <= bound;
+        // no lower bound -> w <= bound
+        const double val = (L.us()[k] <= 1.E20 && L.ls()[k] >= -1.E20) ? fabs(w) : ((L.us()[k] > 1.E20) ? -w : w);
+        mviol = fmax(mviol, val);
+      }
       if (has_box()) {
         cgptr db = P.dlt_box();
-        for (int k = threadIdx.x; k < n; k += NT)
+        for (int k = threadIdx.x; k < n; k += NT) {
+          const double v = L.dz()[ni + k];
+          lb1 += (v > 0 ? v : 0.0) * L.ubs()[k];
+          lb1 -= (v < 0 ? v : 0.0) * L.lbs()[k];
+          L.dz()[ni + k] = db[k] * v / c;
+          nrm_dz = fmax(nrm_dz, fabs(L.dz()[ni + k]));
           L.Cdx()[ni + k] /= db[k];
+          const double w = L.dx()[k]; // (scaled by this same thread in the first loop)
+          const double val =
+            (L.ubs()[k] <= 1.E20 && L.lbs()[k] >= -1.E20) ? fabs(w) : ((L.ubs()[k] > 1.E20) ? -w : w);
+          mviol = fmax(mviol, val);
+        }
       }
     }
-    gdx = R.sum(gdx);
-    R.max3(ndx, nadx, nhdx);
-    double bound = ndx * st.eps_dual_inf;
-    double bound_neg = -bound;
-    double viol = 0; // 1 when some constraint breaks first_cond
-    for (int k = threadIdx.x; k < ni; k += NT) {
-      double v = L.Cdx()[k];
-      bool ok = true;
-      if (L.us()[k] <= 1.E20 && L.ls()[k] >= -1.E20)
-        ok = v <= bound && v >= bound_neg;
-      else if (L.us()[k] > 1.E20)
-        ok = v >= bound_neg;
-      else if (L.ls()[k] < -1.E20)
-        ok = v <= bound;
-      if (!ok)
-        viol = 1;
+    double sv[2] = { lb1, gdx };
+    double mv[7] = { nrm_dy, nrm_dz, lb2, ndx, nadx, nhdx, mviol };
+    R.template mixed<2, 7>(sv, mv);
+    lb1 = sv[0];
+    gdx = sv[1];
+    nrm_dy = mv[0];
+    nrm_dz = mv[1];
+    lb2 = mv[2];
+    ndx = mv[3];
+    nadx = mv[4];
+    nhdx = mv[5];
+    mviol = mv[6];
+    {
+      const double upper_bound = st.eps_primal_inf * fmax(nrm_dy, nrm_dz);
+      primal_infeasible = (nrm_dy != 0 || nrm_dz != 0) && lb2 <= upper_bound && lb1 <= -upper_bound;
     }
-    if (has_box())
-      for (int k = threadIdx.x; k < n; k += NT) {
-        double v = L.dx()[k];
-        bool ok = true;
-        if (L.ubs()[k] <= 1.E20 && L.lbs()[k] >= -1.E20)
-          ok = v <= bound && v >= bound_neg;
-        else if (L.ubs()[k] > 1.E20)
-          ok = v >= bound_neg;
-        else if (L.lbs()[k] < -1.E20)
-          ok = v <= bound;
-        if (!ok)
-          viol = 1;
-      }
-    viol = R.max(viol);
-    bool first_cond = (nadx <= bound) && (viol == 0);
-    bound *= c;
-    bound_neg *= c;
-    bool second_cond_alt1 = nhdx <= bound && gdx <= bound_neg;
-    return first_cond && second_cond_alt1 && ndx != 0;
+    {
+      double bound = ndx * st.eps_dual_inf;
+      const bool first_cond = (nadx <= bound) && !(mviol > bound);
+      bound *= c;
+      const bool second_cond_alt1 = nhdx <= bound && gdx <= -bound;
+      dual_infeasible = first_cond && second_cond_alt1 && ndx != 0;
+    }
   }
 
   // reference solver.hpp:687-743
@@ -2475,6 +2492,7 @@ struct Solver
       if (ni > 0 || has_box())
         alpha = primal_dual_ls();
       toc(ST_CYC_LINESEARCH);
+      sub_tic(ST_CYC_UPDATE);
       {
         double m = 0;
         for (int k = threadIdx.x; k < n; k += NT)
@@ -2486,6 +2504,7 @@ struct Solver
         m = R.max(m);
         if (m < 1.E-11 && iter > 0) {
           info.iter += iter + 1;
+          sub_toc(ST_CYC_UPDATE);
           break;
         }
       }
@@ -2504,10 +2523,13 @@ struct Solver
       }
       __syncthreads();
       const UD err_in = inner_loop_saddle_point();
+      sub_toc(ST_CYC_UPDATE);
       bool stop = false;
       if (iter % st.frequence_infeasibility_check == 0 || st.primal_infeasibility_solving) {
-        bool is_primal_infeasible = primal_infeasibility_certificate();
-        bool is_dual_infeasible = dual_infeasibility_certificate();
+        sub_tic(ST_CYC_CERT);
+        bool is_primal_infeasible, is_dual_infeasible;
+        infeasibility_certificates(is_primal_infeasible, is_dual_infeasible);
+        sub_toc(ST_CYC_CERT);
         if (PQP_UNLIKELY(is_primal_infeasible)) {
           info.status = PQP_PRIMAL_INFEASIBLE;
           if (!st.primal_infeasibility_solving) {
