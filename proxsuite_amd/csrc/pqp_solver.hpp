@@ -1097,6 +1097,8 @@ struct Solver
       __syncthreads();
     }
     vstore(P.dF(), L.dF(), n);
+    if (hess() == PQP_HESSIAN_DENSE)
+      bytes((long)n * n * 8 * 3); // H_s read (upper triangle) + W and W^T written (lower triangle each), ~1.5 n^2 + margin for F
     build_ZG();
   }
 
@@ -1306,6 +1308,9 @@ struct Solver
       }
     }
     count(ST_N_NEW_ROWS, nd);
+    // Z build: W^T and B^T read once per tile row pair, Z written in both orientations; Gram: Zc read, G written
+    bytes(((hess() == PQP_HESSIAN_DENSE ? (long)n * n / 2 + (long)nb * n : (long)nd * n) + 2L * nd * n + (long)nd * n +
+           (long)nd * nd) * 8);
     __syncthreads();
   }
 
@@ -1937,6 +1942,7 @@ struct Solver
         m_in0 = fmax(m_in0, fabs(L.x()[k]));      // utils.hpp:230-231
       }
     }
+    bytes(((long)ne * n + (long)ni * n) * 8);
     R.max3(m_eq0, m_in0, m_eql);
     eq_rhs_0 = m_eq0;
     in_rhs_0 = m_in0;
@@ -1985,6 +1991,7 @@ struct Solver
         L.t1()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x()[k] : 0.0;
     }
     const bool have_products = aty_fresh; // A^T y, C^T z left by global_primal_residual
+    bytes(((hess() == PQP_HESSIAN_DENSE ? (long)n * n : (long)n) + (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
     if (!have_products) {
       if (ne > 0)
         mv(P.As(), n, ne, n, L.y(), L.t2());
@@ -2404,6 +2411,7 @@ struct Solver
           listed += tot;
         }
         __syncthreads();
+        bytes((long)listed * n * 8);
         if (listed > 0)
           gemv<NT>(P.Cs(), n, listed, n, L.t2(), L.CTzin(), L.part(), list, 0, nullptr, 0);
         else
@@ -2660,6 +2668,8 @@ struct Solver
       vload(S, P.delta(), d.ntot);
       __syncthreads();
       write_scaled<NT>(batch, q, S, ruiz_c, false);
+      // H, A, C read; H_s, A_s, A_s^T, C_s, C_s^T written
+      bytes(((long)n * n * 2 + 3L * ne * n + 3L * ni * n) * 8);
       toc(ST_CYC_SCALE);
     }
     vload(L.gs(), P.gs(), n);
@@ -3022,6 +3032,7 @@ struct Solver
       cgptr g = P.g();
       if (hess() == PQP_HESSIAN_DENSE) {
         mv(P.H(), n, n, n, L.x(), L.t1());
+        bytes((long)n * n * 8);
         for (int k = threadIdx.x; k < n; k += NT)
           obj += 0.5 * L.t1()[k] * L.x()[k] + g[k] * L.x()[k];
       } else {

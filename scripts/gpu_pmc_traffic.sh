@@ -1,0 +1,57 @@
+#!/bin/bash
+# HBM traffic and stall summary of the solve kernel per BASELINE.json configuration, collected as
+# /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3
+# --pmc passes (with --kernel-trace only), bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) -- the gfx950
+# correction calibrated on this access pattern in profiles/r01_hbm_counter_calibration.txt.
+#   scripts/gpu_pmc_traffic.sh [c2 c1 c4 c5 c5box]      -> gpurun_out/pmc_traffic_<w>.json (+ raw CSVs)
+# Copy the JSON files into profiles/ (scripts/merge_pmc_traffic.py) to make bench.py report them.
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+[ -z "$R" ] && R=$(cd $(dirname $0)/.. && pwd)
+mkdir -p $R/gpurun_out
+cd /tmp
+WL="$@"; [ -z "$WL" ] && WL="c2 c1 c4 c5 c5box"
+for w in $WL; do
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
+    p=$(echo $pass | cut -d' ' -f1)
+    rm -rf $R/gpurun_out/pmct_${w}_$p
+    timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmct_${w}_$p -- python $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --mpc-steps 0 > $R/gpurun_out/pmct_${w}_$p.log 2>&1
+  done
+done
+cd $R
+python - $WL <<'PY'
+import csv, glob, json, sys, collections
+for w in sys.argv[1:]:
+    acc = collections.defaultdict(list)          # counter -> one value per launch (summed over its dimension rows)
+    dur = []
+    names = set()
+    for f in glob.glob('gpurun_out/pmct_%s_*/**/*counter_collection.csv' % w, recursive=True):
+        per = collections.defaultdict(float)
+        for row in csv.DictReader(open(f)):
+            if 'pqp_solve_kernel' not in row.get('Kernel_Name', ''):
+                continue
+            names.add(row['Kernel_Name'])
+            per[(row['Counter_Name'], row['Dispatch_Id'])] += float(row['Counter_Value'])
+        for (c, _), v in per.items():
+            acc[c].append(v)
+    for f in glob.glob('gpurun_out/pmct_%s_FETCH_SIZE/**/*kernel_trace.csv' % w, recursive=True):
+        for row in csv.DictReader(open(f)):
+            if 'pqp_solve_kernel' in row.get('Kernel_Name', ''):
+                dur.append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) * 1e-6)
+    mean = {c: sum(v) / len(v) for c, v in acc.items() if v}
+    out = {"workload": w, "kernel": sorted(names), "launches_per_counter": {c: len(v) for c, v in acc.items()},
+           "per_launch": mean}
+    if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
+        out["hbm_bytes_per_launch"] = 1024.0 * (2.0 * mean['FETCH_SIZE'] + mean['WRITE_SIZE'])
+        out["formula"] = "1024 * (2 * FETCH_SIZE + WRITE_SIZE), separate --pmc passes (profiles/r01_hbm_counter_calibration.txt)"
+    if dur:
+        out["kernel_ms_under_profiler"] = sum(dur) / len(dur)
+    if 'SQ_WAVE_CYCLES' in mean and mean['SQ_WAVE_CYCLES']:
+        out["wait_any_over_wave_cycles"] = mean.get('SQ_WAIT_ANY', 0) / mean['SQ_WAVE_CYCLES']
+        out["valu_active_over_wave_cycles"] = mean.get('SQ_ACTIVE_INST_VALU', 0) / mean['SQ_WAVE_CYCLES']
+    if mean.get('TCC_HIT_sum') is not None and mean.get('TCC_MISS_sum') is not None:
+        t = mean['TCC_HIT_sum'] + mean['TCC_MISS_sum']
+        out["l2_hit_rate"] = mean['TCC_HIT_sum'] / t if t else None
+    json.dump(out, open('gpurun_out/pmc_traffic_%s.json' % w, 'w'), indent=1)
+    print(w, json.dumps({k: out.get(k) for k in ("hbm_bytes_per_launch", "kernel_ms_under_profiler", "wait_any_over_wave_cycles", "l2_hit_rate")}))
+PY

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""gpurun_out/pmc_traffic_<w>.json (scripts/gpu_pmc_traffic.sh) -> profiles/<tag>_pmc_<w>.json and the
+per-workload table profiles/pmc_traffic.json that bench.py reports as `roofline.traffic`."""
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+table_path = os.path.join(root, "profiles", "pmc_traffic.json")
+table = {}
+if os.path.exists(table_path):
+    old = json.load(open(table_path))
+    table = old if "workloads" in old else {"workloads": {}}
+table.setdefault("workloads", {})
+for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_traffic_*.json"))):
+    j = json.load(open(f))
+    w = j["workload"]
+    dst = os.path.join(root, "profiles", "%s_pmc_%s.json" % (tag, w))
+    json.dump(j, open(dst, "w"), indent=1)
+    if "hbm_bytes_per_launch" in j:
+        table["workloads"][w] = {"hbm_bytes_per_launch": j["hbm_bytes_per_launch"], "kernel": j["kernel"],
+                                 "source": "profiles/%s_pmc_%s.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+                                           "separate passes; bytes = 1024*(2*FETCH_SIZE+WRITE_SIZE))" % (tag, w)}
+    print("merged", w)
+json.dump(table, open(table_path, "w"), indent=1)
