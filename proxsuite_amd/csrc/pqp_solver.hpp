@@ -91,6 +91,8 @@ struct State
   int factor_valid; // primal block, Z and G in HBM match (model, rho)
   int ls_valid;     // the Schur factor in HBM matches (mu_eq_fact, mu_in_fact, active list)
   int n_slots;      // inequality slots of that factor (n_c live ones + the holes deletions left)
+  int c_diag;       // C has no off-diagonal entry and n_in == dim (e.g. bounds passed as C = I): set by init / update
+  int _pad1;
   double ruiz_c;
   double dual_feasibility_rhs_2;
   double correction_guess_rhs_g;
@@ -517,7 +519,7 @@ work_cleanup_flags(State& w)
 // ---------------------------------------------------------------------------
 template<int NT>
 __device__ PQP_CALL void
-write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp)
+write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool diag_only = false)
 {
   const QpRef P(batch, q);
   const Dims& d = batch.d;
@@ -526,6 +528,27 @@ write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp)
   clptr Se = S + n;
   clptr Si = S + n + ne;
   clptr Sb = S + n + ne + ni;
+  if (diag_only) {
+    // diagonal structure (see Solver::dm): only the diagonals of H and C carry information; the
+    // dense copies keep the zeros the init-time pass wrote, the compact ones feed the solver
+    cgptr H = P.H();
+    gptr Hs = P.Hs(), hd = P.F();
+    for (int k = threadIdx.x; k < n; k += NT) {
+      const double h = H[(long)k * n + k];
+      const double v = (d.hessian == PQP_HESSIAN_DIAGONAL) ? h * Sx[k] * Sx[k] * c : h * c;
+      Hs[(long)k * n + k] = v;
+      hd[k] = v;
+    }
+    if (ni > 0) {
+      cgptr C = P.C();
+      gptr Cs = P.Cs(), cd = P.CTs();
+      for (int k = threadIdx.x; k < n; k += NT) {
+        const double v = Si[k] * C[(long)k * n + k] * Sx[k];
+        Cs[(long)k * n + k] = v;
+        cd[k] = v;
+      }
+    }
+  } else {
   {
     cgptr H = P.H();
     gptr Hs = P.Hs();
@@ -563,6 +586,7 @@ write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp)
       Cs[o] = v;
       CTs[(long)k * ni + r] = v;
     }
+  }
   }
   for (int k = threadIdx.x; k < n; k += NT)
     P.gs()[k] = P.g()[k] * Sx[k] * c;
@@ -855,6 +879,27 @@ setup_body(const Batch& batch, long q, lptr lds_base)
   }
   write_scaled<NT>(batch, q, S, c, true);
   {
+    // structure detection for the diagonal fast path of the solve kernel (Solver::dm): no
+    // off-diagonal entry in C with n_in == dim (bounds handed over as C = I, reference
+    // utils/random_qp_problems.hpp:591-628), or no general inequality at all
+    const int ni = d.n_in;
+    double off = (ni == 0 || ni == n) ? 0.0 : 1.0;
+    if (ni == n) {
+      cgptr C = P.C();
+      for (int o = threadIdx.x; o < ni * n; o += NT) {
+        const int rr = o / n, k = o - rr * n;
+        if (rr != k && C[o] != 0.0)
+          off = 1.0;
+      }
+    }
+    off = R.max(off);
+    const bool dmode = d.hessian != PQP_HESSIAN_DENSE && ne == 0 && off == 0.0 && !(ni > 0 && d.box);
+    if (dmode)
+      write_scaled<NT>(batch, q, S, c, true, true); // compact diagonals beside the dense copies
+    if (threadIdx.x == 0)
+      W.c_diag = (off == 0.0) ? 1 : 0;
+  }
+  {
     double m = 0;
     for (int k = threadIdx.x; k < n; k += NT)
       m = fmax(m, fabs(P.g()[k] * S[k] * c));
@@ -929,6 +974,16 @@ struct Solver
   int n_c;       // active inequality count
   int n_slots;   // inequality slots of the Schur factor: the n_c active ones + holes left by deletions
   int r;         // n_eq + n_slots : size of the dual block
+  // Diagonal structure: H diagonal (or zero), no equality and every inequality row touching ONE
+  // variable (box constraints, or C without off-diagonal entries, not both).  Then L = I, every row
+  // of Z has one entry, the Gram matrix and the dual Schur block are DIAGONAL: nothing is factorised,
+  // no matrix is read in the solve -- every step of the engine of section "dual Schur block" becomes
+  // element-wise on vectors (BASELINE.json configs[4]: "bandwidth-bound, no MFMA").  Compact
+  // diagonals: hd = diag(H_s) in the F buffer, cd = diag(C_s) in the C_s^T buffer, zd / gd (entry of
+  // Z and of G per constraint) at the start of the Zr / G buffers.
+  bool diag_mode;
+  __device__ __forceinline__ bool dm() const { return SPEC == 1 ? false : diag_mode; }
+  __device__ __forceinline__ int dcol(int cid) const { return (cid < d.n_in) ? cid : cid - d.n_in; } // variable of constraint cid
   bool schur_dirty;       // the factor does not describe (active set, mu): re-factorise
   bool schur_incremental; // rows were appended / deleted since the last full factorisation
   bool aty_fresh; // L.ATdy / L.CTdz hold A^T y, C^T z of the current iterate (see global_primal_residual)
@@ -952,6 +1007,12 @@ struct Solver
     r = d.n_eq;
     schur_dirty = true;
     schur_incremental = false;
+    diag_mode = false;
+  }
+  __device__ __forceinline__ void set_diag_mode(const State& W)
+  {
+    diag_mode = (SPEC == 0) && d.hessian != PQP_HESSIAN_DENSE && d.n_eq == 0 && W.c_diag != 0 &&
+                !(d.n_in > 0 && d.box != 0);
   }
 
   // phase timers / event counters: thread 0 only, accumulated in LDS
@@ -1092,8 +1153,9 @@ struct Solver
     } else {
       // diagonal / zero Hessian: L = I
       cgptr Hs = P.Hs();
+      cgptr hd = P.F();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.dF()[k] = ((hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] : 0.0) + rho;
+        L.dF()[k] = ((hess() == PQP_HESSIAN_DIAGONAL) ? (dm() ? hd[k] : Hs[(long)k * n + k]) : 0.0) + rho;
       __syncthreads();
     }
     vstore(P.dF(), L.dF(), n);
@@ -1118,6 +1180,19 @@ struct Solver
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int lr = lane & 15, lk = lane >> 4;
     gptr Zc = P.Zc(), Zr = P.Zr();
+    if (dm()) {
+      // zd[c] = the one entry of row c of Z = B^T (L = I), gd[c] = zd[c]^2 / D_col(c)
+      cgptr cd = P.CTs();
+      gptr gd = P.G();
+      for (int c = threadIdx.x; c < nd; c += NT) {
+        const double z = (c < ni) ? cd[c] : L.isc()[c - ni];
+        Zr[c] = z;
+        gd[c] = z * z / L.dF()[dcol(c)];
+      }
+      bytes((long)nd * 8 * 3);
+      __syncthreads();
+      return;
+    }
     for (int k = threadIdx.x; k < n; k += NT)
       L.t1()[k] = 1.0 / L.dF()[k];
     if (hess() == PQP_HESSIAN_DENSE) {
@@ -1419,6 +1494,18 @@ struct Solver
     const int ne = d.n_eq;
     cgptr G = P.G();
     const double mu_eq = info.mu_eq, mu_in = info.mu_in;
+    if (dm()) {
+      // diagonal Schur block: D_S = mu_in + gd over the active constraints, W_S = I (never stored)
+      cgptr gd = P.G();
+      for (int a = threadIdx.x; a < rr; a += NT)
+        L.dS()[a] = mu_in + gd[L.act()[a]];
+      bytes((long)rr * 8);
+      __syncthreads();
+      schur_dirty = false;
+      schur_incremental = false;
+      count(ST_N_SCHUR_FACT);
+      return;
+    }
     bool done = false;
 #ifndef PQP_SCHUR_REG_ROWS
 #define PQP_SCHUR_REG_ROWS (16 * SCHUR_MB)
@@ -1469,6 +1556,12 @@ struct Solver
   __device__ __forceinline__ void schur_apply(lptr v)
   {
     const int rr = r;
+    if (dm()) {
+      for (int a = threadIdx.x; a < rr; a += NT)
+        v[a] /= L.dS()[a];
+      __syncthreads();
+      return;
+    }
     cgptr W = P.WS();
     // t = W v : row sums (16 lanes per row of the row-major factor)
     gemv_dual<NT, false>(W, d.nd, rr, rr, v, v, L.t2(), L.t2(), L.part());
@@ -1600,6 +1693,33 @@ struct Solver
   {
     const int n = d.n, nd = d.nd;
     const int rr = r;
+    if (dm()) {
+      // diagonal structure: K = [[D, Z_J^T], [Z_J, -mu I]] with one entry per row of Z_J and at
+      // most one active row per variable -- the block elimination of the general path, element-wise
+      cgptr zd = P.Zr();
+      for (int a = threadIdx.x; a < rr; a += NT) {
+        const int cid = L.act()[a];
+        const int k = dcol(cid);
+        const double za = zd[cid];
+        const double s = za * (bx[k] / L.dF()[k]) - bd[a];
+        bd[a] = s / L.dS()[a];
+      }
+      __syncthreads();
+      for (int k = threadIdx.x; k < n; k += NT)
+        L.t1()[k] = bx[k];
+      __syncthreads();
+      for (int a = threadIdx.x; a < rr; a += NT) {
+        const int cid = L.act()[a];
+        L.t1()[dcol(cid)] -= zd[cid] * bd[a]; // (one active row per variable: no two slots share k)
+      }
+      __syncthreads();
+      for (int k = threadIdx.x; k < n; k += NT)
+        bx[k] = L.t1()[k] / L.dF()[k];
+      __syncthreads();
+      bytes((long)rr * 16);
+      count(ST_N_KKT_SOLVES);
+      return;
+    }
     // The triangular solves on the Schur factor below are chains of dependent block steps, each
     // waiting for its panel of LS: touch every cache line of the factor's triangle NOW (one or
     // two loads per thread, results unused) so that those panels come from L2 instead of HBM by
@@ -1669,8 +1789,9 @@ struct Solver
       hess_mv(L.dx(), L.Hdx());
     } else {
       cgptr Hs = P.Hs();
+      cgptr hd = P.F();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.Hdx()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.dx()[k] : 0.0;
+        L.Hdx()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? (dm() ? hd[k] : Hs[(long)k * n + k]) * L.dx()[k] : 0.0;
     }
     if (ne > 0) {
       if constexpr (NT == 256) {
@@ -1683,7 +1804,14 @@ struct Solver
     } else {
       vzero(L.ATdy(), n);
     }
-    if (ni > 0) {
+    if (ni > 0 && dm()) {
+      cgptr cd = P.CTs();
+      for (int k = threadIdx.x; k < n; k += NT) {
+        const double ck = cd[k];
+        L.Cdx()[k] = ck * L.dx()[k];
+        L.CTdz()[k] = ck * L.zfull()[k];
+      }
+    } else if (ni > 0) {
       if constexpr (NT == 256) {
         gemv_dual<NT>(P.Cs(), n, ni, n, L.dx(), L.zfull(), L.Cdx(), L.CTdz(), L.part());
       } else {
@@ -1714,7 +1842,8 @@ struct Solver
     zero_holes(L.ed());
     {
       const long mats = (NT == 256) ? 1 : 2; // one pass over A_s / C_s, or A_s and its transpose
-      bytes((((hess() == PQP_HESSIAN_DENSE) ? (long)n * n : (long)n) + mats * ((long)ne * n + (long)ni * n)) * 8);
+      bytes((((hess() == PQP_HESSIAN_DENSE) ? (long)n * n : (long)n) +
+             (dm() ? (long)ni : mats * ((long)ne * n + (long)ni * n))) * 8);
     }
   }
 
@@ -1808,7 +1937,7 @@ struct Solver
       return;
     }
     // (holes are dead weight in every solve: past HOLE_MAX of them the block is re-packed)
-    const bool incremental = !schur_dirty && (na + nr) <= INCR_MAX && n_slots + na <= nc &&
+    const bool incremental = !dm() && !schur_dirty && (na + nr) <= INCR_MAX && n_slots + na <= nc &&
                              (n_slots - n_c) + nr <= HOLE_MAX;
     if (INCR_MAX > 0 && incremental) {
       // ids that leave -> chg[0 .. nr), ids that enter -> chg[INCR_MAX .. INCR_MAX + na), ascending
@@ -1887,7 +2016,20 @@ struct Solver
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     double m_eq0 = 0, m_in0 = 0, m_eql = 0, m_inl = 0;
-    if constexpr (NT == 256) {
+    if (dm()) {
+      vzero(L.ATdy(), n);
+      if (ni > 0) {
+        cgptr cd = P.CTs();
+        for (int k = threadIdx.x; k < n; k += NT) {
+          L.rup()[k] = cd[k] * L.x()[k];
+          L.CTdz()[k] = cd[k] * L.z()[k];
+        }
+      } else {
+        vzero(L.CTdz(), n);
+      }
+      aty_fresh = true;
+      __syncthreads();
+    } else if constexpr (NT == 256) {
       // one pass over A_s and C_s: the row sums are A x / C x; the column sums A^T y / C^T z are
       // what global_dual_residual needs at this same iterate, parked in the Newton by-product
       // vectors (idle between Newton loops) and flagged by `aty_fresh`
@@ -1942,7 +2084,7 @@ struct Solver
         m_in0 = fmax(m_in0, fabs(L.x()[k]));      // utils.hpp:230-231
       }
     }
-    bytes(((long)ne * n + (long)ni * n) * 8);
+    bytes(dm() ? (long)ni * 8 : ((long)ne * n + (long)ni * n) * 8);
     R.max3(m_eq0, m_in0, m_eql);
     eq_rhs_0 = m_eq0;
     in_rhs_0 = m_in0;
@@ -1987,8 +2129,9 @@ struct Solver
       hess_mv(L.x(), L.t1());
     } else {
       cgptr Hs = P.Hs();
+      cgptr hd = P.F();
       for (int k = threadIdx.x; k < n; k += NT)
-        L.t1()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? Hs[(long)k * n + k] * L.x()[k] : 0.0;
+        L.t1()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? (dm() ? hd[k] : Hs[(long)k * n + k]) * L.x()[k] : 0.0;
     }
     const bool have_products = aty_fresh; // A^T y, C^T z left by global_primal_residual
     bytes(((hess() == PQP_HESSIAN_DENSE ? (long)n * n : (long)n) + (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
@@ -1997,7 +2140,11 @@ struct Solver
         mv(P.As(), n, ne, n, L.y(), L.t2());
       else
         vzero(L.t2(), n);
-      if (ni > 0)
+      if (ni > 0 && dm()) {
+        cgptr cd = P.CTs();
+        for (int k = threadIdx.x; k < n; k += NT)
+          L.ex()[k] = cd[k] * L.z()[k];
+      } else if (ni > 0)
         mv(P.Cs(), n, ni, n, L.z(), L.ex());
       else
         vzero(L.ex(), n);
@@ -2391,7 +2538,11 @@ struct Solver
       for (int i = threadIdx.x; i < nc; i += NT)
         L.zfull()[i] = (L.slot_of()[i] >= 0) ? 0.0 : L.z()[i]; // inactive multipliers
       __syncthreads();
-      if (ni > 0) {
+      if (ni > 0 && dm()) {
+        cgptr cd = P.CTs();
+        for (int k = threadIdx.x; k < n; k += NT)
+          L.CTzin()[k] = cd[k] * L.zfull()[k];
+      } else if (ni > 0) {
         // C^T z over the INACTIVE rows: only rows that have just left the active set carry a
         // nonzero multiplier (the step drives them to zero), so the rows are compacted first --
         // indices behind the active list in L.act(), values in t2 -- and only those rows of C_s
@@ -2592,6 +2743,7 @@ struct Solver
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
     State W = *P.state();
+    set_diag_mode(W);
     info.load(*P.info());
     ruiz_c = W.ruiz_c;
     dual_feasibility_rhs_2 = W.dual_feasibility_rhs_2;
@@ -2667,9 +2819,9 @@ struct Solver
       lptr S = L.rd(); // scratch of ntot doubles: rd, ed, sd, dS, t2 (4 nd + max(n, nd)) are free here
       vload(S, P.delta(), d.ntot);
       __syncthreads();
-      write_scaled<NT>(batch, q, S, ruiz_c, false);
-      // H, A, C read; H_s, A_s, A_s^T, C_s, C_s^T written
-      bytes(((long)n * n * 2 + 3L * ne * n + 3L * ni * n) * 8);
+      write_scaled<NT>(batch, q, S, ruiz_c, false, dm());
+      // H, A, C read; H_s, A_s, A_s^T, C_s, C_s^T written (diagonal structure: the two diagonals)
+      bytes(dm() ? ((long)n * 3 + (long)ni * 3) * 8 : ((long)n * n * 2 + 3L * ne * n + 3L * ni * n) * 8);
       toc(ST_CYC_SCALE);
     }
     vload(L.gs(), P.gs(), n);
@@ -3039,6 +3191,7 @@ struct Solver
         cgptr H = P.H();
         for (int k = threadIdx.x; k < n; k += NT)
           obj += 0.5 * L.x()[k] * L.x()[k] * H[(long)k * n + k] + g[k] * L.x()[k];
+        bytes((long)n * 8);
       }
       info.objValue = R.sum(obj);
     }
@@ -3092,9 +3245,15 @@ struct Solver
     cgptr ld = (cgptr)(bw.ld + slot_in_launch * ntot);
     for (int k = threadIdx.x; k < ST_COUNT; k += NT)
       L.stat()[k] = 0;
-    State W = *P.state();
+    // (fields of the per-QP state are read and written in place: a by-value copy of the struct is
+    // a stack object here, and its 64-bit reloads trip a register-alignment check of this compiler)
+    {
+      const State& Wr = *P.state();
+      diag_mode = (SPEC == 0) && d.hessian != PQP_HESSIAN_DENSE && d.n_eq == 0 && Wr.c_diag != 0 &&
+                  !(d.n_in > 0 && d.box != 0);
+      ruiz_c = Wr.ruiz_c;
+    }
     info.load(*P.info());
-    ruiz_c = W.ruiz_c;
     const double c = ruiz_c;
     vload(L.x(), P.x(), n);
     vload(L.y(), P.y(), ne);
@@ -3109,7 +3268,14 @@ struct Solver
     __syncthreads();
     // active sets at the solution (compute_ECJ.hpp:48-57):  C x + z - u >= 0,  C x + z - l <= 0
     if (ni > 0) {
-      mv(P.CTs(), ni, n, ni, L.dx(), L.Cdx());
+      if (dm()) {
+        cgptr cd = P.CTs();
+        for (int i = threadIdx.x; i < ni; i += NT)
+          L.Cdx()[i] = cd[i] * L.dx()[i];
+        __syncthreads();
+      } else {
+        mv(P.CTs(), ni, n, ni, L.dx(), L.Cdx());
+      }
       cgptr gu = P.u(), gl = P.l();
       for (int i = threadIdx.x; i < ni; i += NT) {
         const double ctz = L.Cdx()[i] / dI[i] + L.z()[i];
@@ -3208,10 +3374,10 @@ struct Solver
       // like the reference, the proximal parameters of `results.info` keep the backward values;
       // the factorisation in HBM no longer belongs to a forward solve
       info.store(*P.info());
-      W.factor_valid = 0;
-      W.ls_valid = 0;
-      W.dirty = 1;
-      *P.state() = W;
+      State& Ww = *P.state();
+      Ww.factor_valid = 0;
+      Ww.ls_valid = 0;
+      Ww.dirty = 1;
     }
   }
 };
