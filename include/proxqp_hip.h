@@ -98,6 +98,16 @@ int pqp_batch_solve(pqp_batch* h);
  * count == 1).  pqp_batch_solve(h) == pqp_batch_solve_range(h, 0, B). */
 int pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count);
 
+/* dense::solve_in_parallel(std::vector<QP>&) (reference parallel/qp_solve.hpp:17-39): QP::solve() on
+ * the `count` QPs idx[0..count) of the batch, in ONE launch (workgroup i solves QP idx[i]). */
+int pqp_batch_solve_subset(pqp_batch* h, const int64_t* idx, int64_t count);
+
+/* Copy construction / assignment of a QP (reference dense/wrapper.hpp: QP<T> is copyable and
+ * BatchQP / std::vector<QP> rely on it): every per-QP device array, the settings and the
+ * initialisation state of QP src_idx of `src` go to QP dst_idx of `dst` (same shape required;
+ * the two handles may be the same). */
+int pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_idx);
+
 /* HIP stream (hipStream_t, passed as void*) the setup and solve kernels are launched on;
  * NULL (the default) is the null stream.  Calls stay synchronous with respect to the host. */
 int pqp_batch_set_stream(pqp_batch* h, void* stream);

@@ -7,9 +7,11 @@
 // against this header.  What differs is ownership: the numerical state of a QP lives on the
 // GPU inside a *pool* -- one C-ABI batch handle (include/proxqp_hip.h) holding `capacity`
 // QPs of one signature (dim, n_eq, n_in, box, Hessian type, backend).  A QP object is a
-// (pool, slot) view plus host copies of `settings`, `results`, `model`.  A standalone QP is a
-// pool of one; BatchQP::init_qp_in_place hands out slots of shared pools so that
-// solve_in_parallel (parallel/qp_solve.hpp) is one kernel launch per pool.
+// (pool, slot) view plus host copies of `settings`, `results`, `model`.  Standalone QPs of one
+// signature share pools too (a per-thread registry hands out and takes back slots), so that
+// dense::solve_in_parallel(std::vector<QP>&) -- the reference's most common calling form -- is one
+// kernel launch per pool exactly like the BatchQP overload.  Copying a QP copies its device state
+// into a fresh slot (the reference's QP is a value type; `qps.push_back(qp)` must not alias).
 //
 // Host protocol of every call: settings -> device record, C-ABI call, device record ->
 // settings (init/update/solve(x,y,z) change default_rho, compute_preconditioner,
@@ -21,9 +23,11 @@
 #ifndef PROXSUITE_AMD_PROXQP_DENSE_WRAPPER_HPP
 #define PROXSUITE_AMD_PROXQP_DENSE_WRAPPER_HPP
 
+#include <algorithm>
 #include <deque>
 #include <limits>
 #include <map>
+#include <vector>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -63,6 +67,7 @@ struct Pool
   pqp_batch* h = nullptr;
   isize capacity = 0, used = 0;
   isize dim = 0, n_eq = 0, n_in = 0, n_c = 0;
+  std::vector<isize> free_slots; // registry pools only: slots given back by destroyed QPs
   Pool(isize cap, isize dim_, isize n_eq_, isize n_in_, bool box, HessianType hessian, DenseBackend backend,
        int device)
     : capacity(cap)
@@ -85,6 +90,42 @@ opt_or_nan(const optional<T>& v)
   return v ? *v : std::numeric_limits<T>::quiet_NaN();
 }
 
+// Pools of the standalone QPs of this thread, by signature.  Slots are handed out in chunks sized
+// so that one pool stays below ~256 MB of device memory (1 .. 256 QPs).
+struct Registry
+{
+  using Key = std::tuple<isize, isize, isize, bool, int, int, int>;
+  std::map<Key, std::vector<std::shared_ptr<Pool>>> pools;
+  static Registry& instance()
+  {
+    static thread_local Registry r;
+    return r;
+  }
+  static isize chunk(isize dim, isize n_eq, isize n_in, bool box)
+  {
+    const double n = double(dim), nd = double(n_eq + n_in + (box ? dim : 0));
+    const double bytes = 8.0 * (5.0 * n * n + 6.0 * nd * n + 3.0 * nd * nd) + 4096.0;
+    const double cap = 268435456.0 / bytes;
+    return isize(std::max(1.0, std::min(256.0, cap)));
+  }
+  std::pair<std::shared_ptr<Pool>, isize> acquire(isize dim, isize n_eq, isize n_in, bool box, HessianType hessian,
+                                                  DenseBackend backend, int device)
+  {
+    auto& v = pools[Key{ dim, n_eq, n_in, box, int(hessian), int(backend), device }];
+    for (auto& p : v) {
+      if (!p->free_slots.empty()) {
+        const isize s = p->free_slots.back();
+        p->free_slots.pop_back();
+        return { p, s };
+      }
+      if (p->used < p->capacity)
+        return { p, p->used++ };
+    }
+    v.push_back(std::make_shared<Pool>(chunk(dim, n_eq, n_in, box), dim, n_eq, n_in, box, hessian, backend, device));
+    return { v.back(), v.back()->used++ };
+  }
+};
+
 } // namespace detail
 
 template<typename T>
@@ -98,6 +139,8 @@ struct QP
 private:
   std::shared_ptr<detail::Pool> pool_;
   isize slot_ = 0;
+  bool owns_slot_ = false; // slot taken from the registry (standalone QP): given back on destruction
+  int device_ = 0;
   DenseBackend dense_backend;
   bool box_constraints;
   HessianType hessian_type;
@@ -106,6 +149,70 @@ public:
   Results<T> results;
   Settings<T> settings;
   Model<T> model;
+
+  // value semantics of the reference's QP: a copy owns its own device state
+  QP(const QP& o)
+    : owns_slot_(true)
+    , device_(o.device_)
+    , dense_backend(o.dense_backend)
+    , box_constraints(o.box_constraints)
+    , hessian_type(o.hessian_type)
+    , results(o.results)
+    , settings(o.settings)
+    , model(o.model)
+  {
+    auto ps = detail::Registry::instance().acquire(model.dim, model.n_eq, model.n_in, box_constraints, hessian_type,
+                                                   o.requested_backend_, device_);
+    pool_ = ps.first;
+    slot_ = ps.second;
+    requested_backend_ = o.requested_backend_;
+    o.push_settings();
+    detail::check(pqp_batch_copy_qp(pool_->h, slot_, o.pool_->h, o.slot_));
+  }
+  QP& operator=(const QP& o)
+  {
+    if (this != &o) {
+      QP tmp(o);
+      swap(tmp);
+    }
+    return *this;
+  }
+  QP(QP&& o) noexcept
+    : pool_(std::move(o.pool_))
+    , slot_(o.slot_)
+    , owns_slot_(o.owns_slot_)
+    , device_(o.device_)
+    , dense_backend(o.dense_backend)
+    , box_constraints(o.box_constraints)
+    , hessian_type(o.hessian_type)
+    , results(std::move(o.results))
+    , settings(std::move(o.settings))
+    , model(std::move(o.model))
+    , requested_backend_(o.requested_backend_)
+  {
+    o.owns_slot_ = false;
+  }
+  QP& operator=(QP&& o) noexcept
+  {
+    if (this != &o)
+      swap(o);
+    return *this;
+  }
+  ~QP() { release(); }
+  void swap(QP& o) noexcept
+  {
+    std::swap(pool_, o.pool_);
+    std::swap(slot_, o.slot_);
+    std::swap(owns_slot_, o.owns_slot_);
+    std::swap(device_, o.device_);
+    std::swap(dense_backend, o.dense_backend);
+    std::swap(box_constraints, o.box_constraints);
+    std::swap(hessian_type, o.hessian_type);
+    std::swap(results, o.results);
+    std::swap(settings, o.settings);
+    std::swap(model, o.model);
+    std::swap(requested_backend_, o.requested_backend_);
+  }
 
   // the 8 constructor overloads of the reference (wrapper.hpp:140-333)
   QP(isize dim, isize n_eq, isize n_in, bool box, HessianType hessian, DenseBackend backend)
@@ -235,21 +342,38 @@ public:
 
 private:
   friend struct BatchQP<T>;
+  DenseBackend requested_backend_ = DenseBackend::Automatic; // as passed to the constructor (pool key)
+  void release() noexcept
+  {
+    if (owns_slot_ && pool_) {
+      // the slot goes back to its pool with a clean device state for the next owner
+      (void)pqp_batch_cleanup(pool_->h, slot_);
+      pool_->free_slots.push_back(slot_);
+    }
+    owns_slot_ = false;
+    pool_.reset();
+  }
   QP(isize dim, isize n_eq, isize n_in, bool box, HessianType hessian, DenseBackend backend,
      std::shared_ptr<detail::Pool> pool, isize slot, int device)
     : pool_(std::move(pool))
     , slot_(slot)
+    , device_(device)
     , dense_backend(backend)
     , box_constraints(box)
     , hessian_type(hessian)
     , results(dim, n_eq, n_in, box)
     , settings(DenseBackend::PrimalDualLDLT)
     , model(dim, n_eq, n_in, box)
+    , requested_backend_(backend)
   {
     if (!pool_) {
-      pool_ = std::make_shared<detail::Pool>(1, dim, n_eq, n_in, box, hessian, backend, device);
-      pool_->used = 1;
-      slot_ = 0;
+      if (dim <= 0) // reference dense/model.hpp:65-68 (checked here before a registry pool is created)
+        throw std::invalid_argument(
+          "wrong argument size: the dimension wrt the primal variable x should be strictly positive.");
+      auto ps = detail::Registry::instance().acquire(dim, n_eq, n_in, box, hessian, backend, device);
+      pool_ = ps.first;
+      slot_ = ps.second;
+      owns_slot_ = true;
     }
     dense_backend = DenseBackend(pqp_batch_dense_backend(pool_->h)); // Automatic resolved (wrapper.hpp:81-113)
     pull_settings();                                                  // defaults of that backend
@@ -455,6 +579,12 @@ struct BatchQP
     else
       q.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u, qp.settings.compute_preconditioner);
   }
+
+  // (the QPs of a BatchQP are views of its pools: the container is movable, not copyable)
+  BatchQP(const BatchQP&) = delete;
+  BatchQP& operator=(const BatchQP&) = delete;
+  BatchQP(BatchQP&&) = default;
+  BatchQP& operator=(BatchQP&&) = default;
 
   QP<T>& get(isize i) { return qps_[usize(i)]; }
   const QP<T>& get(isize i) const { return qps_[usize(i)]; }

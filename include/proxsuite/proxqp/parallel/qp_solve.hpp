@@ -9,6 +9,8 @@
 #define PROXSUITE_AMD_PROXQP_PARALLEL_QPSOLVE_HPP
 
 #include <cstring>
+#include <map>
+#include <vector>
 
 #include "proxsuite/proxqp/dense/compute_ECJ.hpp"
 
@@ -50,14 +52,47 @@ solve_in_parallel(BatchQP<T>& qps, const optional<usize> /*num_threads*/ = nullo
   }
 }
 
-// std::vector of standalone QPs (reference qp_solve.hpp:17-39): every QP is its own pool of
-// one, so this is a loop of single-workgroup launches.  Use BatchQP for throughput.
+// std::vector of QPs (reference qp_solve.hpp:17-39, the most common calling form): standalone QPs
+// of one signature share device pools (dense/wrapper.hpp, detail::Registry), so the QPs of the
+// vector are grouped by pool and every group is ONE launch -- pqp_batch_solve_subset, workgroup i
+// solves slot idx[i] -- followed by one bulk copy of that pool's results.
 template<typename T>
 void
 solve_in_parallel(std::vector<QP<T>>& qps, const optional<usize> /*num_threads*/ = nullopt)
 {
-  for (auto& qp : qps)
-    qp.solve();
+  std::map<const detail::Pool*, std::vector<usize>> groups;
+  for (usize i = 0; i < qps.size(); ++i)
+    groups[qps[i].pool().get()].push_back(i);
+  for (auto& kv : groups) {
+    const detail::Pool& p = *kv.first;
+    std::vector<int64_t> idx;
+    idx.reserve(kv.second.size());
+    for (usize i : kv.second) {
+      qps[i].push_settings();
+      idx.push_back(int64_t(qps[i].slot()));
+    }
+    detail::check(pqp_batch_solve_subset(p.h, idx.data(), int64_t(idx.size())));
+    const usize B = usize(p.capacity);
+    std::vector<T> x(B * usize(p.dim)), y(B * usize(p.n_eq)), z(B * usize(p.n_c)), se(B * usize(p.n_eq)),
+      si(B * usize(p.n_c));
+    std::vector<pqp_info> info(B);
+    detail::check(pqp_batch_get_results(p.h, -1, x.data(), y.data(), z.data(), se.data(), si.data(), info.data()));
+    for (usize i : kv.second) {
+      QP<T>& q = qps[i];
+      const usize s = usize(q.slot());
+      auto put = [s](Vec<T>& dst, const std::vector<T>& src) {
+        if (dst.size())
+          std::memcpy(dst.data(), src.data() + s * usize(dst.size()), usize(dst.size()) * sizeof(T));
+      };
+      put(q.results.x, x);
+      put(q.results.y, y);
+      put(q.results.z, z);
+      put(q.results.se, se);
+      put(q.results.si, si);
+      q.results.info.from_c(info[s]);
+      q.pull_settings();
+    }
+  }
 }
 
 // dense::qp_solve_backward_in_parallel (reference parallel/qp_solve.hpp:83-137): compute_backward

@@ -35,7 +35,7 @@ class NativeLib:
     SYMBOLS = ("pqp_last_error", "pqp_device_count", "pqp_batch_create", "pqp_batch_destroy",
                "pqp_batch_size", "pqp_batch_dense_backend", "pqp_batch_settings", "pqp_batch_init",
                "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_flush",
-               "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
+               "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_solve_subset", "pqp_batch_copy_qp", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
                "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs", "pqp_batch_pack_results",
                "pqp_batch_get_scaled", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
                "pqp_batch_launch_config")
@@ -61,6 +61,8 @@ class NativeLib:
         L.pqp_batch_flush.argtypes = [vp]
         L.pqp_batch_solve.argtypes = [vp]
         L.pqp_batch_solve_range.argtypes = [vp, C.c_int64, C.c_int64]
+        L.pqp_batch_solve_subset.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64]
+        L.pqp_batch_copy_qp.argtypes = [vp, C.c_int64, vp, C.c_int64]
         L.pqp_batch_set_stream.argtypes = [vp, vp]
         L.pqp_batch_set_schedule.argtypes = [vp, C.c_int]
         L.pqp_batch_backward.argtypes = [vp, _DP] + [C.c_double] * 3

@@ -282,7 +282,9 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   if ((rc = dalloc(h, &(ptr), (cnt)))) {                                                            \
     pqp_batch_destroy(h);                                                                           \
     return rc;                                                                                      \
-  }
+  }                                                                                                 \
+  if (B > 0 && size_t(cnt) % B == 0 && (void*)(ptr) != (void*)h->d_order && (void*)(ptr) != (void*)h->d_cmd)           \
+    h->per_qp.push_back({ reinterpret_cast<char*>(ptr), (size_t(cnt) / B) * sizeof(*(ptr)) });
   ALLOC(D.H, B * n * n)
   ALLOC(D.g, B * n)
   ALLOC(D.A, B * ne * n)
@@ -485,12 +487,24 @@ pqp_batch_flush(pqp_batch* h)
   DeviceGuard guard_(h->device);
   if (int rc = upload_settings(h))
     return rc;
-  HIP_TRY(hipMemcpy(h->d_cmd, h->cmd.data(), h->cmd.size() * sizeof(pqp::Cmd), hipMemcpyHostToDevice));
-  if (int rc = pqp_launch_setup(h))
-    return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  for (auto& c : h->cmd)
-    c.op = pqp::CMD_NONE;
+  // only the span of QPs that carry a command is uploaded and launched (a BatchQP filled QP by
+  // QP through the facade flushes once per QP: B launches of one workgroup, not B launches of B)
+  size_t lo = h->cmd.size(), hi = 0;
+  for (size_t q = 0; q < h->cmd.size(); ++q)
+    if (h->cmd[q].op != pqp::CMD_NONE) {
+      lo = std::min(lo, q);
+      hi = q + 1;
+    }
+  if (lo < hi) {
+    HIP_TRY(hipMemcpy(h->d_cmd + lo, h->cmd.data() + lo, (hi - lo) * sizeof(pqp::Cmd), hipMemcpyHostToDevice));
+    h->setup_first = long(lo);
+    h->setup_count = long(hi - lo);
+    if (int rc = pqp_launch_setup(h))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (size_t q = lo; q < hi; ++q)
+      h->cmd[q].op = pqp::CMD_NONE;
+  }
   h->cmd_pending = false;
   return PQP_OK;
 }
@@ -551,6 +565,73 @@ pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
   }
   // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
   std::fill(h->is_initialized.begin() + first, h->is_initialized.begin() + first + count, char(1));
+  return PQP_OK;
+}
+
+int
+pqp_batch_solve_subset(pqp_batch* h, const int64_t* idx, int64_t count)
+{
+  if (!h || (count > 0 && !idx))
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
+  if (count < 0 || count > h->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "subset larger than the batch");
+  if (count == 0)
+    return PQP_OK;
+  std::vector<int> order(static_cast<size_t>(count));
+  for (int64_t i = 0; i < count; ++i) {
+    if (idx[i] < 0 || idx[i] >= h->dev.B)
+      return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+    order[size_t(i)] = int(idx[i]);
+  }
+  DeviceGuard guard_(h->device);
+  if (int rc = pqp_batch_flush(h))
+    return rc;
+  if (int rc = upload_settings(h))
+    return rc;
+  // the dispatch-order array doubles as the subset list (a learned order is dropped)
+  HIP_TRY(hipMemcpy(h->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->order_valid = false;
+  h->range_first = 0;
+  h->range_count = long(count);
+  h->subset_order = h->d_order;
+  int rc = pqp_launch_solve(h);
+  h->subset_order = nullptr;
+  if (rc)
+    return rc;
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  for (int64_t i = 0; i < count; ++i)
+    h->is_initialized[size_t(idx[i])] = 1;
+  return PQP_OK;
+}
+
+int
+pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_idx)
+{
+  if (!dst || !src)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (dst_idx < 0 || dst_idx >= dst->dev.B || src_idx < 0 || src_idx >= src->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+  const pqp::Dims &a = dst->dev.d, &b = src->dev.d;
+  if (a.n != b.n || a.n_eq != b.n_eq || a.n_in != b.n_in || a.box != b.box || a.hessian != b.hessian ||
+      dst->per_qp.size() != src->per_qp.size())
+    return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_copy_qp: the two batches hold QPs of different shapes");
+  DeviceGuard guard_(src->device);
+  if (int rc = pqp_batch_flush(src))
+    return rc;
+  if (int rc = pqp_batch_flush(dst))
+    return rc;
+  for (size_t k = 0; k < src->per_qp.size(); ++k) {
+    const size_t nb = src->per_qp[k].bytes_per_qp;
+    if (nb != dst->per_qp[k].bytes_per_qp)
+      return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_copy_qp: layout mismatch");
+    HIP_TRY(hipMemcpy(dst->per_qp[k].base + size_t(dst_idx) * nb, src->per_qp[k].base + size_t(src_idx) * nb, nb,
+                      hipMemcpyDefault));
+  }
+  dst->settings[size_t(dst_idx)] = src->settings[size_t(src_idx)];
+  dst->is_initialized[size_t(dst_idx)] = src->is_initialized[size_t(src_idx)];
+  dst->settings_dirty = true;
+  dst->settings_uploaded.clear(); // (d_settings was overwritten by the array copy: force a re-upload)
   return PQP_OK;
 }
 

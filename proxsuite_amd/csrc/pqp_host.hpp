@@ -52,6 +52,15 @@ struct pqp_batch
   bool solve_in_flight = false; // ev1 recorded, elapsed time not read yet (asynchronous solves)
   hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
   long range_first = 0, range_count = 0;
+  long setup_first = 0, setup_count = 0; // QPs with a queued init / update / cleanup command
+  const int* subset_order = nullptr;     // pqp_batch_solve_subset: slot of workgroup i (device memory)
+  // every per-QP device array with its element size and per-QP element count (pqp_batch_copy_qp)
+  struct Arr
+  {
+    char* base;
+    size_t bytes_per_qp;
+  };
+  std::vector<Arr> per_qp;
   // QPLayer backward outputs ([B][...], allocated at the first pqp_batch_backward)
   double *bw_dH = nullptr, *bw_dg = nullptr, *bw_dA = nullptr, *bw_db = nullptr, *bw_dC = nullptr,
          *bw_du = nullptr, *bw_dl = nullptr, *bw_ld = nullptr;

@@ -46,7 +46,7 @@ launch_solve(pqp_batch* h)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
-  const int* order = (h->lpt && h->order_valid && whole) ? h->d_order : nullptr;
+  const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
   hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS, SPEC>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
                      h->stream, h->dev, h->range_first, order);
   HIP_TRY(hipGetLastError());
@@ -128,10 +128,10 @@ pqp_launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count)
 #if PQP_TU_HAS(6)
 template<int NT>
 __global__ __launch_bounds__(NT) void
-pqp_setup_kernel(pqp::Batch batch)
+pqp_setup_kernel(pqp::Batch batch, long first)
 {
   HIP_DYNAMIC_SHARED(double, smem)
-  pqp::setup_body<NT>(batch, (long)blockIdx.x, (pqp::lptr)smem);
+  pqp::setup_body<NT>(batch, first + (long)blockIdx.x, (pqp::lptr)smem);
 }
 
 // Dispatch order for the next whole-batch launch: QP i goes to position
@@ -173,8 +173,9 @@ launch_setup(pqp_batch* h)
   if (h->lds_setup > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_setup_kernel<NT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_setup));
-  hipLaunchKernelGGL((pqp_setup_kernel<NT>), dim3((unsigned)h->dev.B), dim3(NT), h->lds_setup, h->stream,
-                     h->dev);
+  // only the QPs [setup_first, setup_first + setup_count) carry a queued command
+  hipLaunchKernelGGL((pqp_setup_kernel<NT>), dim3((unsigned)h->setup_count), dim3(NT), h->lds_setup, h->stream,
+                     h->dev, h->setup_first);
   HIP_TRY(hipGetLastError());
   return PQP_OK;
 }

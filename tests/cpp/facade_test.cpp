@@ -101,6 +101,49 @@ main(int argc, char** argv)
     for (isize j = 0; j < dim; ++j)
       CHECK(qps[usize(i)].results.x[j] == qps_vector[i].results.x[j]);
 
+  // --- timings-parallel.cpp:151-176: `qps.push_back(qp)` COPIES an init-ed QP (value semantics): the
+  // copy owns its own device state, the vector is solved in one launch per pool, and solving or
+  // updating the copy leaves the original alone
+  {
+    std::vector<dense::QP<T>> copies;
+    dense::QP<T> original{ dim, n_eq, n_in };
+    original.settings.eps_abs = eps_abs;
+    original.settings.eps_rel = 0;
+    original.settings.initial_guess = InitialGuessStatus::NO_INITIAL_GUESS;
+    const auto& m0 = models[0];
+    original.init(m0.H, m0.g, m0.A, m0.b, m0.C, m0.l, m0.u);
+    for (int i = 0; i < num_qps; i++) {
+      dense::QP<T> qp{ dim, n_eq, n_in };
+      qp.settings.eps_abs = eps_abs;
+      qp.settings.eps_rel = 0;
+      qp.settings.initial_guess = InitialGuessStatus::NO_INITIAL_GUESS;
+      const auto& m = models[usize(i)];
+      qp.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+      copies.push_back(qp); // copy, then `qp` dies and gives its slot back
+    }
+    copies.push_back(original);
+    CHECK(copies.back().pool().get() != nullptr);
+    CHECK(!(copies.back().pool().get() == original.pool().get() && copies.back().slot() == original.slot()));
+    dense::solve_in_parallel(copies);
+    for (int i = 0; i < num_qps; i++)
+      for (isize j = 0; j < dim; ++j)
+        CHECK(copies[usize(i)].results.x[j] == qps_vector[i].results.x[j]);
+    // the original was not solved by solving its copy ...
+    CHECK(original.results.info.status == QPSolverOutput::PROXQP_MAX_ITER_REACHED);
+    original.solve();
+    // ... and gives the same answer as the copy (and as QP 0 of the batch) when it is
+    for (isize j = 0; j < dim; ++j) {
+      CHECK(original.results.x[j] == copies.back().results.x[j]);
+      CHECK(original.results.x[j] == qps_vector[0].results.x[j]);
+    }
+    // copy assignment of a solved QP carries the solution (warm re-solve needs 0 iterations)
+    dense::QP<T> assigned{ dim, n_eq, n_in };
+    assigned = original;
+    assigned.settings.initial_guess = InitialGuessStatus::WARM_START_WITH_PREVIOUS_RESULT;
+    assigned.solve();
+    CHECK(assigned.results.info.iter == 0);
+  }
+
   // --- dense_qp_wrapper.cpp style: update g, warm start with the previous result, then from (x,y,z)
   {
     dense::QP<T>& qp = qps[0];
