@@ -461,12 +461,54 @@ def solve_backward_in_parallel(num_threads=None, qps=None, loss_derivatives=None
         pool.touch()
 
 
-def solve(H=None, g=None, A=None, b=None, C=None, l=None, u=None, x=None, y=None, z=None, eps_abs=None,
-          eps_rel=None, rho=None, mu_eq=None, mu_in=None, verbose=None, compute_preconditioner=True,
-          compute_timings=False, max_iter=None, initial_guess=InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS,
-          check_duality_gap=False, eps_duality_gap_abs=None, eps_duality_gap_rel=None,
-          primal_infeasibility_solving=False, default_H_eigenvalue_estimate=None, l_box=None, u_box=None):
-    """One-shot `dense::solve` (reference dense/wrapper.hpp:1000-1092 and, with boxes, :1133-1236)."""
+_SOLVE_TAIL = ("x", "y", "z", "eps_abs", "eps_rel", "rho", "mu_eq", "mu_in", "verbose", "compute_preconditioner",
+               "compute_timings", "max_iter", "initial_guess", "check_duality_gap", "eps_duality_gap_abs",
+               "eps_duality_gap_rel", "primal_infeasibility_solving", "default_H_eigenvalue_estimate")
+_SOLVE_HEAD = ("H", "g", "A", "b", "C", "l", "u")
+
+
+def solve(*args, **kwargs):
+    """One-shot `dense::solve`: both overloads of the reference's binding
+    (bindings/python/src/expose-solve.hpp; dense/wrapper.hpp:1000-1092 and, with boxes, :1133-1236):
+
+        solve(H, g, A, b, C, l, u, x, y, z, eps_abs, ...)
+        solve(H, g, A, b, C, l, u, l_box, u_box, x, y, z, eps_abs, ...)
+
+    Python cannot overload on types, so a positional call is read as the box overload when its 8th
+    and 9th arguments are vectors of the primal dimension and the 9th cannot be `y` (n_eq != dim), or
+    when twelve or more leading arguments are arrays / None; `l_box=` / `u_box=` keywords always work."""
+    def is_vec(v, length):
+        try:
+            return v is not None and not np.isscalar(v) and np.asarray(v).ndim == 1 and np.asarray(v).shape[0] == length
+        except Exception:
+            return False
+
+    box_names = _SOLVE_HEAD + ("l_box", "u_box") + _SOLVE_TAIL
+    plain_names = _SOLVE_HEAD + _SOLVE_TAIL + ("l_box", "u_box")
+    names = plain_names
+    if len(args) >= 9 and "l_box" not in kwargs and "u_box" not in kwargs:
+        H0 = _host(args[0])
+        n0 = H0.shape[0] if H0 is not None else (len(args[1]) if args[1] is not None else 0)
+        A0 = _host(args[2])
+        ne0 = A0.shape[0] if A0 is not None else 0
+        arrays12 = len(args) >= 12 and all(a is None or (not np.isscalar(a) and hasattr(a, "__len__")) for a in args[:12])
+        if is_vec(args[7], n0) and is_vec(args[8], n0) and (ne0 != n0 or arrays12):
+            names = box_names
+    if len(args) > len(names):
+        raise TypeError("solve() takes at most %d positional arguments" % len(names))
+    bound = dict(zip(names, args))
+    for k, v in kwargs.items():
+        if k in bound:
+            raise TypeError("solve() got multiple values for argument %r" % k)
+        bound[k] = v
+    return _solve_impl(**bound)
+
+
+def _solve_impl(H=None, g=None, A=None, b=None, C=None, l=None, u=None, x=None, y=None, z=None, eps_abs=None,
+                eps_rel=None, rho=None, mu_eq=None, mu_in=None, verbose=None, compute_preconditioner=True,
+                compute_timings=False, max_iter=None, initial_guess=InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS,
+                check_duality_gap=False, eps_duality_gap_abs=None, eps_duality_gap_rel=None,
+                primal_infeasibility_solving=False, default_H_eigenvalue_estimate=None, l_box=None, u_box=None):
     H_, A_, C_ = _host(H), _host(A), _host(C)
     n = H_.shape[0] if H_ is not None else (len(g) if g is not None else 0)
     n_eq = A_.shape[0] if A_ is not None else 0

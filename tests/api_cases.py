@@ -107,6 +107,9 @@ def case_box(dense, oracle, randqp):
     assert max(pri, dua) <= 1e-9
     # one-shot solve with boxes gives the same answer
     r2 = dense.solve(H, g, None, None, C, l, u, eps_abs=1e-9, l_box=lb, u_box=ub)
+    # the reference binding's positional box overload: (..., u, l_box, u_box, x, y, z, eps_abs)
+    r3 = dense.solve(H, g, None, None, C, l, u, lb, ub, None, None, None, 1e-9)
+    assert np.array_equal(r3.x, r2.x) and np.array_equal(r3.z, r2.z)
     np.testing.assert_allclose(r2.x, r.x, atol=1e-8)
 
 
