@@ -103,6 +103,24 @@ def build_hip_stats(force: bool = False) -> Path:
     return build_hip(force=True, extra_flags=("-DPQP_STATS",), out=lib)
 
 
+VARIANT_DIR = CSRC / "variants"
+
+
+def build_hip_variants(force: bool = False):
+    """Register-budget variants of the 512-thread solve kernel (PQP_WPS_512 = 3 and 4; the product
+    uses 2), for the GPU regression test that sweeps them (tests/test_gpu_parity.py): round 1 saw
+    NaNs at (512, 4) with a kernel that has since been rewritten; the sweep keeps watch."""
+    VARIANT_DIR.mkdir(exist_ok=True)
+    out = []
+    deps = list(hip_sources()) + hip_headers() + [Path(__file__)]
+    for w in (3, 4):
+        lib = VARIANT_DIR / ("libproxqp_hip_wps512_%d.so" % w)
+        if force or not _newer(lib, deps):
+            build_hip(force=True, extra_flags=("-DPQP_WPS_512=%d" % w,), out=lib)
+        out.append(lib)
+    return out
+
+
 def build_oracle(force: bool = False) -> Path:
     odir = ROOT / "oracle"
     lib = odir / "liboracle.so"

@@ -119,3 +119,16 @@ def test_closest_feasible(lib, oracle, randqp):
     primal_infeasibility_solving"""
     seen = pc.case_closest_feasible(lib, oracle, randqp, seeds=range(20))
     assert {0, 2} <= seen and (3 in seen or 0 in seen), seen  # SOLVED, PRIMAL_INFEASIBLE (+ closest-feasible runs)
+
+
+@pytest.mark.parametrize("wps", [3, 4])
+def test_register_budget_sweep_512_threads(oracle, randqp, wps):
+    """512-thread workgroups at 170 and 128 VGPRs per lane (the product runs them at 256): round 1
+    recorded NaNs at (512, 4) and simply did not instantiate it.  The kernel has been rewritten since
+    (inverse-factor Schur block, no substitution chains) and the variants are correct; this keeps it so."""
+    from proxsuite_amd import _build
+    path = _build.VARIANT_DIR / ("libproxqp_hip_wps512_%d.so" % wps)
+    assert path.exists(), "build the variants first (__graft_entry__.build())"
+    vlib = N.NativeLib(path)
+    for n, ne, ni, B in ((300, 40, 120, 8), (40, 5, 300, 8), (200, 100, 200, 8)):
+        pc.case_random_batch(vlib, oracle, randqp, n, ne, ni, B=B)
