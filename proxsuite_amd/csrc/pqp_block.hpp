@@ -1791,6 +1791,80 @@ tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
   }
 }
 
+// ---------------------------------------------------------------------------
+// Symmetric rank-K accumulation on the FP64 matrix cores:
+//     out[i][j] = base[i][j] + alpha * sum_{k < K} M[row(k)][i] * M[row(k)][j]        i, j < m
+// M row-major (leading dimension ldm), rows optionally gathered through `rowmap` (LDS; row(k) =
+// rowmap[k]); out / base row-major m x m (leading dimension ld), base may be null (zero) or alias
+// out.  One 16x16 lower tile per wavefront at a time; the mirror tile comes from the same operand
+// registers with the roles swapped, so both are written with coalesced stores and the result is
+// exactly symmetric.  Used by the PrimalLDLT engine for A^T A and C_J^T C_J.
+// ---------------------------------------------------------------------------
+template<int NT>
+__device__ PQP_CALL void
+syrk_mfma(cgptr M, int ldm, int K, cliptr rowmap, int m, double alpha, cgptr base, gptr out, int ld)
+{
+  constexpr int NWV = NT / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int MT = (m + 15) / 16;
+  const int tiles = MT * (MT + 1) / 2;
+  for (int t = w; t < tiles; t += NWV) {
+    int ct = 0, rem = t;
+    while (rem >= ct + 1) {
+      rem -= ct + 1;
+      ++ct;
+    }
+    const int dt = rem; // dt <= ct
+    const int c0 = ct * 16, d0 = dt * 16;
+    const int c = c0 + lr, dcol = d0 + lr;
+    const bool c_ok = c < m, d_ok = dcol < m;
+    const int cc = c_ok ? c : m - 1, dc = d_ok ? dcol : m - 1;
+    pqp_d4 acc1 = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+    constexpr int DEPTH = 8;
+    for (int k0 = 0; k0 < K; k0 += 4 * DEPTH) {
+      double a[DEPTH], b[DEPTH];
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int k = k0 + 4 * u + lk;
+        const int kc = (k < K) ? k : K - 1;
+        const long row = rowmap ? (long)rowmap[kc] : (long)kc;
+        a[u] = M[row * ldm + cc];
+        b[u] = M[row * ldm + dc];
+      }
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int k = k0 + 4 * u + lk;
+        const double av = (k < K && c_ok) ? a[u] : 0.0;
+        const double bv = (k < K && d_ok) ? b[u] : 0.0;
+        acc1 = mfma_f64_16x16x4(av, bv, acc1);
+        acc2 = mfma_f64_16x16x4(bv, av, acc2);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cr = c0 + lk + 4 * q; // row of the (ct, dt) tile
+      if (ct != dt) {
+        if (cr < m && d_ok) {
+          const long o = (long)cr * ld + dcol;
+          out[o] = (base ? base[o] : 0.0) + alpha * acc1[q];
+        }
+        const int dr = d0 + lk + 4 * q; // row of the mirror tile
+        if (dr < m && c_ok) {
+          const long o = (long)dr * ld + c;
+          out[o] = (base ? base[o] : 0.0) + alpha * acc2[q];
+        }
+      } else if (cr < m && d_ok && cr >= dcol) {
+        const long o = (long)cr * ld + dcol, ot = (long)dcol * ld + cr;
+        const double v = (base ? base[o] : 0.0) + alpha * acc1[q];
+        out[o] = v;
+        out[ot] = v;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // exclusive prefix count of a per-thread flag over the block; returns this
 // thread's rank among the set flags and the total through `total`.
 // `cnt` is LDS scratch of NT/64 + 1 ints.

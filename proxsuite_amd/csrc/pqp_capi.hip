@@ -259,6 +259,8 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   d.nd = d.n_eq + d.nc;
   d.ntot = d.n + d.nd;
   d.hessian = hessian_type;
+  d.backend = h->backend;
+  d._pad = 0;
   h->dev.B = batch_size;
   const int need = d.nd > d.n ? d.nd : d.n;
   h->nt = need <= 256 ? 256 : (need <= 512 ? 512 : 1024);

@@ -247,7 +247,9 @@ pqp_launch_pack(pqp_batch* h, long first, long count, double* out, hipStream_t s
 int
 pqp_launch_solve(pqp_batch* h)
 {
-  const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE;
+  // SPEC = 1: no box constraints, dense Hessian, PrimalDualLDLT engine -- all known at compile time
+  const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE &&
+                      h->dev.d.backend != PQP_BACKEND_PRIMAL_LDLT;
   switch (h->nt) {
     case 256:
       return common ? pqp_launch_solve_256_s1(h) : pqp_launch_solve_256_s0(h);

@@ -61,6 +61,8 @@ struct Dims
   int ntot;          // n + nd
   int box;           // box constraints present
   int hessian;       // pqp_hessian_type
+  int backend;       // resolved pqp_dense_backend (PrimalDualLDLT / PrimalLDLT)
+  int _pad;
 };
 
 // commands consumed by the setup kernel (reference dense/wrapper.hpp init/update)
@@ -983,6 +985,16 @@ struct Solver
   // Z and of G per constraint) at the start of the Zr / G buffers.
   bool diag_mode;
   __device__ __forceinline__ bool dm() const { return SPEC == 1 ? false : diag_mode; }
+  // DenseBackend::PrimalLDLT (reference dense/solver.hpp:88-109, 171-227, 336-388; chosen by
+  // dense_backend_choice when n_eq + n_c is large against dim): the DUAL block of the KKT matrix is
+  // eliminated instead of the primal one,
+  //     P_J = H_s + rho I + A_s^T A_s / mu_eq + C_J^T C_J / mu_in          (dim x dim, SPD)
+  //     P_J x = b_x + B_J^T M^{-1} b_d ,     d = M^{-1} (B_J x - b_d),
+  // so the factorisation stays dim x dim however many constraints are active.  P_J is kept in the
+  // same inverse-factor form as the dual Schur block of the default engine (W = L^{-1} in the WL
+  // buffer, D in L.dF): two chain-free mat-vecs per solve; an active-set change or a mu update
+  // re-assembles P_J on the matrix cores (syrk_mfma) and re-factorises it.
+  __device__ __forceinline__ bool pm() const { return SPEC == 1 ? false : (d.backend == PQP_BACKEND_PRIMAL_LDLT && !diag_mode); }
   __device__ __forceinline__ int dcol(int cid) const { return (cid < d.n_in) ? cid : cid - d.n_in; } // variable of constraint cid
   bool schur_dirty;       // the factor does not describe (active set, mu): re-factorise
   bool schur_incremental; // rows were appended / deleted since the last full factorisation
@@ -1119,6 +1131,13 @@ struct Solver
   {
     const int n = d.n;
     const double rho = info.rho;
+    if (pm()) {
+      // the model-only part of P_J: A_s^T A_s (WU buffer), once per solve
+      if (d.n_eq > 0)
+        syrk_mfma<NT>(P.As(), n, d.n_eq, nullptr, n, 1.0, nullptr, P.WU(), n);
+      bytes(((long)d.n_eq * n + (long)n * n) * 8);
+      return;
+    }
     if (hess() == PQP_HESSIAN_DENSE) {
       gptr F = P.F();
       cgptr Hs = P.Hs();
@@ -1494,6 +1513,10 @@ struct Solver
     const int ne = d.n_eq;
     cgptr G = P.G();
     const double mu_eq = info.mu_eq, mu_in = info.mu_in;
+    if (pm()) {
+      factor_pm();
+      return;
+    }
     if (dm()) {
       // diagonal Schur block: D_S = mu_in + gd over the active constraints, W_S = I (never stored)
       cgptr gd = P.G();
@@ -1546,6 +1569,69 @@ struct Solver
     }
     debug_check_factor("factor_schur");
     tic();
+    schur_dirty = false;
+    schur_incremental = false;
+    count(ST_N_SCHUR_FACT);
+  }
+
+  // PrimalLDLT: assemble P_J = H_s + rho I + A^T A / mu_eq + C_J^T C_J / mu_in (+ box rows) in the F
+  // buffer and factorise it into (W = L^{-1} -> WL buffer, D -> L.dF)
+  __device__ __forceinline__ void factor_pm()
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in;
+    const double rho = info.rho, mu_eq_inv = 1.0 / double(info.mu_eq), mu_in_inv = 1.0 / double(info.mu_in);
+    gptr Pm = P.F();
+    {
+      cgptr Hs = P.Hs();
+      cgptr PA = P.WU();
+      for (int o = threadIdx.x; o < n * n; o += NT) {
+        const int i = o / n, k = o - i * n;
+        double v = 0.0;
+        if (hess() == PQP_HESSIAN_DENSE)
+          v = Hs[o];
+        else if (hess() == PQP_HESSIAN_DIAGONAL && i == k)
+          v = Hs[o];
+        if (i == k)
+          v += rho;
+        if (ne > 0)
+          v += mu_eq_inv * PA[o];
+        Pm[o] = v;
+      }
+    }
+    __syncthreads();
+    // active general inequalities: rows act[a] < n_in of C_s, gathered (the list is ascending, so
+    // they come first); active box rows add i_k^2 / mu_in on the diagonal
+    int n_gen = 0;
+    {
+      double cnt = 0;
+      for (int a = threadIdx.x; a < n_c; a += NT)
+        cnt += (L.act()[a] < ni) ? 1.0 : 0.0;
+      n_gen = (int)R.sum(cnt);
+    }
+    if (n_gen > 0)
+      syrk_mfma<NT>(P.Cs(), n, n_gen, L.act(), n, mu_in_inv, Pm, Pm, n);
+    if (has_box()) {
+      for (int a = n_gen + threadIdx.x; a < n_c; a += NT) {
+        const int k = L.act()[a] - ni;
+        const double ik = L.isc()[k];
+        Pm[(long)k * n + k] += mu_in_inv * ik * ik;
+      }
+      __syncthreads();
+    }
+    bytes(((long)n * n * 4 + (long)n_gen * n) * 8);
+    bool done = false;
+    if constexpr (NT == 256) {
+      if (n <= 16 * SCHUR_MB) {
+        auto load = [&](int i, int j) -> double { return Pm[(long)i * n + j]; };
+        ldlt_inverse_reg<NT, SCHUR_MB>(load, P.WL(), n, n, L.dF(), L.top());
+        done = true;
+      }
+    }
+    if (!done) {
+      ldlt_factor_mfma<NT, true>(Pm, n, n, L.dF(), L.top());
+      tri_inverse_mfma_rows<NT, false>(Pm, n, n, P.WL(), P.WL());
+    }
+    bytes((long)n * n * 8 * 2);
     schur_dirty = false;
     schur_incremental = false;
     count(ST_N_SCHUR_FACT);
@@ -1687,12 +1773,83 @@ struct Solver
     return delta > 0.0;
   }
 
+  // PrimalLDLT form of the KKT solve:  P_J x = bx + B_J^T M^{-1} bd ,  d = M^{-1} (B_J x - bd).
+  // Scratch: t1, t2, part and the by-product vectors of kkt_residual (Hdx, ATdy, CTdz, Adx, Cdx),
+  // which are idle between two residual evaluations.
+  __device__ __forceinline__ void kkt_solve_pm(lptr bx, lptr bd)
+  {
+    const int n = d.n, ne = d.n_eq, ni = d.n_in, rr = r;
+    const double mu_eq_inv = 1.0 / double(info.mu_eq), mu_in_inv = 1.0 / double(info.mu_in);
+    lptr sdv = L.t2(); // M^{-1} bd, slot order
+    for (int a = threadIdx.x; a < rr; a += NT)
+      sdv[a] = bd[a] * ((a < ne) ? mu_eq_inv : mu_in_inv);
+    int n_gen = n_c; // active general inequalities (ascending list: they precede the box rows)
+    if (has_box()) {
+      double cnt = 0;
+      for (int a = threadIdx.x; a < n_c; a += NT)
+        cnt += (L.act()[a] < ni) ? 1.0 : 0.0;
+      n_gen = (int)R.sum(cnt);
+    } else {
+      __syncthreads();
+    }
+    if (ne > 0)
+      gemv<NT>(P.As(), n, ne, n, sdv, L.Hdx(), L.part(), nullptr, 0, nullptr, 0);
+    else
+      vzero(L.Hdx(), n);
+    if (n_gen > 0)
+      gemv<NT>(P.Cs(), n, n_gen, n, sdv + ne, L.ATdy(), L.part(), L.act(), 0, nullptr, 0);
+    else
+      vzero(L.ATdy(), n);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.t1()[k] = bx[k] + L.Hdx()[k] + L.ATdy()[k];
+    __syncthreads();
+    if (has_box()) {
+      for (int a = n_gen + threadIdx.x; a < n_c; a += NT) {
+        const int k = L.act()[a] - ni;
+        L.t1()[k] += L.isc()[k] * sdv[ne + a];
+      }
+      __syncthreads();
+    }
+    // x = P_J^{-1} t1 = W^T D^{-1} W t1
+    gemv_dual<NT, false>(P.WL(), n, n, n, L.t1(), L.t1(), L.CTdz(), L.CTdz(), L.part());
+    for (int k = threadIdx.x; k < n; k += NT)
+      L.CTdz()[k] /= L.dF()[k];
+    __syncthreads();
+    gemv<NT>(P.WL(), n, n, n, L.CTdz(), bx, L.part(), nullptr, 0, nullptr, 0, -1);
+    // d = M^{-1} (B_J x - bd)
+    if (ne > 0)
+      gemv_dual<NT, false>(P.As(), n, ne, n, bx, bx, L.Adx(), L.Adx(), L.part());
+    if (n_gen > 0)
+      gemv_dual<NT, false, true>(P.Cs(), n, n_gen, n, bx, bx, L.Cdx(), L.Cdx(), L.part(), L.act(), 0);
+    __syncthreads();
+    for (int a = threadIdx.x; a < rr; a += NT) {
+      double bxv;
+      if (a < ne)
+        bxv = L.Adx()[a];
+      else if (a - ne < n_gen)
+        bxv = L.Cdx()[a - ne];
+      else {
+        const int k = L.act()[a - ne] - ni;
+        bxv = L.isc()[k] * bx[k];
+      }
+      bd[a] = (bxv - bd[a]) * ((a < ne) ? mu_eq_inv : mu_in_inv);
+    }
+    __syncthreads();
+    bytes(((long)n * (n + 1) + 2L * ne * n + 2L * n_gen * n) * 8);
+    count(ST_N_KKT_SOLVES);
+  }
+
   // Solve K [sx; sd] = [bx; bd] in place, K = [[H_s+rho I, B_J^T],[B_J, -M_J]].
   // (reference solver.hpp:320-335 -> ldlt.hpp:767-782)
   __device__ __forceinline__ void kkt_solve_in_place(lptr bx, lptr bd)
   {
     const int n = d.n, nd = d.nd;
     const int rr = r;
+    if (pm()) {
+      kkt_solve_pm(bx, bd);
+      return;
+    }
     if (dm()) {
       // diagonal structure: K = [[D, Z_J^T], [Z_J, -mu I]] with one entry per row of Z_J and at
       // most one active row per variable -- the block elimination of the general path, element-wise
@@ -1937,7 +2094,7 @@ struct Solver
       return;
     }
     // (holes are dead weight in every solve: past HOLE_MAX of them the block is re-packed)
-    const bool incremental = !dm() && !schur_dirty && (na + nr) <= INCR_MAX && n_slots + na <= nc &&
+    const bool incremental = !dm() && !pm() && !schur_dirty && (na + nr) <= INCR_MAX && n_slots + na <= nc &&
                              (n_slots - n_c) + nr <= HOLE_MAX;
     if (INCR_MAX > 0 && incremental) {
       // ids that leave -> chg[0 .. nr), ids that enter -> chg[INCR_MAX .. INCR_MAX + na), ascending
@@ -2003,7 +2160,7 @@ struct Solver
     r = ne + n_slots;
     schur_dirty = true; // the slots were renumbered
     toc(ST_CYC_ZG);
-    if (r > 0)
+    if (r > 0 || pm()) // (PrimalLDLT factorises P_J even with no constraint in it)
       factor_schur();
     else
       schur_dirty = false;
@@ -3202,6 +3359,8 @@ struct Solver
     vstore(P.se(), L.se(), ne);
     vstore(P.si(), L.si(), nc);
     vstore(P.dS(), L.dS(), d.nd);
+    if (pm())
+      vstore(P.dF(), L.dF(), n); // D of P_J, beside its inverse factor in the WL buffer
     {
       // the slots of the Schur factor kept for WARM_START_WITH_PREVIOUS_RESULT: constraint id of a
       // live slot, -1 for a hole

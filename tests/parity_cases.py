@@ -621,3 +621,57 @@ def case_closest_feasible(lib, oracle, randqp, seeds, max_oracle_iter_ext=None):
                 assert pri <= scaled_eps and dua <= eps, (i, pri, dua)
         b.close()
     return seen
+
+
+def case_primal_ldlt(lib, oracle, randqp, dim, B, seed0=1):
+    """DenseBackend::PrimalLDLT at the shape of benchmark/timings-dense-backend.cpp:25-75: n_eq = n_in =
+    2 dim with box constraints around a known feasible point (b = A x_sol, u = C x_sol + delta).  The
+    device factorises the dim x dim primal matrix P_J; the oracle solves the same Newton systems through
+    the reference's rank-updated KKT factorisation.  With 2 dim equalities on dim variables the
+    multipliers are not unique: x, the KKT residuals and the status are compared."""
+    from proxsuite_amd._ctypes_defs import DenseBackend
+    ne = ni = 2 * dim
+    H = np.zeros((B, dim, dim))
+    g = np.zeros((B, dim))
+    A = np.zeros((B, ne, dim))
+    bb = np.zeros((B, ne))
+    Cm = np.zeros((B, ni, dim))
+    l = np.zeros((B, ni))
+    u = np.zeros((B, ni))
+    lb = np.zeros((B, dim))
+    ub = np.zeros((B, dim))
+    for s in range(B):
+        randqp.set_seed(seed0 + s)
+        m = randqp.dense_strongly_convex_qp(dim, ne, ni, 0.75, 1e-2)
+        x_sol = np.array([randqp.normal_rand() for _ in range(dim)])
+        delta = np.array([randqp.uniform_rand() for _ in range(ni)])
+        shift = np.array([randqp.uniform_rand() for _ in range(dim)])
+        H[s], g[s], A[s], Cm[s], l[s] = m.H, m.g, m.A, m.C, m.l
+        u[s] = m.C @ x_sol + delta
+        bb[s] = m.A @ x_sol
+        ub[s], lb[s] = x_sol + shift, x_sol - shift
+    b = N.Batch(B, dim, ne, ni, box_constraints=True, dense_backend=int(DenseBackend.PrimalLDLT), lib=lib)
+    assert b.dense_backend == int(DenseBackend.PrimalLDLT)
+    settings_all(b, eps_abs=EPS, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS))
+    b.init(-1, H, g, A, bb, Cm, l, u, lb, ub)
+    b.solve()
+    x, y, z, se, si, info = b.results()
+    qs = oracle_solve_many(oracle, [(H[i], g[i], A[i], bb[i], Cm[i], l[i], u[i], lb[i], ub[i]) for i in range(B)],
+                           dim, ne, ni, box_constraints=True, dense_backend=DenseBackend.PrimalLDLT)
+    solved = 0
+    for i in range(B):
+        # (2 dim equalities on dim variables: a few seeds trip the primal-infeasibility certificate at the
+        # default eps_primal_inf although b = A x_sol is consistent -- in the oracle and on the device alike)
+        assert info[i].status == qs[i].results.info.status, (i, info[i].status, qs[i].results.info.status)
+        if info[i].status != QPSolverOutput.PROXQP_SOLVED:
+            continue
+        solved += 1
+        pri, dua = kkt_numpy(H[i], g[i], A[i], bb[i], Cm[i], l[i], u[i], x[i], y[i], z[i], lb[i], ub[i])
+        assert pri <= EPS and dua <= EPS, (i, pri, dua)
+        assert close(x[i], qs[i].results.x), i
+    assert solved >= (3 * B) // 4, solved
+    # automatic choice picks this engine at this shape (reference dense/wrapper.hpp:81-113)
+    b2 = N.Batch(1, dim, ne, ni, box_constraints=True, lib=lib)
+    assert b2.dense_backend == int(DenseBackend.PrimalLDLT)
+    b2.close()
+    b.close()

@@ -99,3 +99,29 @@ def test_c5_forms_small(lib, oracle, randqp):
     xa, za = pc.case_c5(lib, oracle, randqp, B=2, sample=2, box=False, dim=24)
     xb, zb = pc.case_c5(lib, oracle, randqp, B=2, sample=2, box=True, dim=24)
     assert np.max(np.abs(xa - xb)) <= 1e-7 * (1 + np.max(np.abs(xa)))
+
+
+def test_primal_ldlt_engine(lib, oracle, randqp):
+    pc.case_primal_ldlt(lib, oracle, randqp, dim=12, B=2)
+
+
+def test_primal_ldlt_engine_without_box(lib, oracle, randqp):
+    """forced PrimalLDLT on an ordinary shape (dense Hessian, no box): same answers as the default engine"""
+    from proxsuite_amd._ctypes_defs import DenseBackend
+    n, ne, ni, B = 30, 7, 9, 3
+    m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2)
+    out = []
+    for backend in (DenseBackend.PrimalLDLT, DenseBackend.PrimalDualLDLT):
+        b = N.Batch(B, n, ne, ni, dense_backend=int(backend), lib=lib)
+        pc.settings_all(b, eps_abs=pc.EPS, eps_rel=0)
+        b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
+        b.solve()
+        x, y, z, se, si, info = b.results()
+        for i in range(B):
+            assert info[i].status == 0
+            pri, dua = pc.kkt(oracle, m, i, x[i], y[i], z[i])
+            assert pri <= pc.EPS and dua <= pc.EPS
+        out.append((x, y, z))
+        b.close()
+    for a, r in zip(out[0], out[1]):
+        assert pc.close(a, r)

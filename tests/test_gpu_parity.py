@@ -132,3 +132,10 @@ def test_register_budget_sweep_512_threads(oracle, randqp, wps):
     vlib = N.NativeLib(path)
     for n, ne, ni, B in ((300, 40, 120, 8), (40, 5, 300, 8), (200, 100, 200, 8)):
         pc.case_random_batch(vlib, oracle, randqp, n, ne, ni, B=B)
+
+
+@pytest.mark.parametrize("dim,B", [(20, 16), (100, 8)])
+def test_primal_ldlt_engine(lib, oracle, randqp, dim, B):
+    """DenseBackend::PrimalLDLT at benchmark/timings-dense-backend.cpp's shape (n_eq = n_in = 2 dim, box):
+    256-thread (dim 20) and 512-thread (dim 100: 500 constraints) workgroups"""
+    pc.case_primal_ldlt(lib, oracle, randqp, dim=dim, B=B)
