@@ -40,18 +40,25 @@ constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * 
 // ldlt_factor_reg: 4 * 16 * MB; ldlt_inverse_reg: 6 * 16 * MB)
 constexpr int TOP_DOUBLES = (6 * 16 * SCHUR_MB > 2 * PQP_NB * PQP_NB + 2 * PQP_NB) ? 6 * 16 * SCHUR_MB
                                                                                  : 2 * PQP_NB * PQP_NB + 2 * PQP_NB;
-// An active-set change of at most INCR_MAX constraints (insertions + deletions) edits the inverse
+// An active-set change of at most incr_max(r) constraints (insertions + deletions) edits the inverse
 // factor of the dual Schur block in place (one rank-1 sweep each); larger ones, and every mu
-// update, re-factorise it.
+// update, re-factorise it.  A sweep costs O(r^2) and a few barrier intervals, the re-factorisation
+// O(r^3) and r of them: the break-even grows with r (measured: ~8 edits at r ~ 85, C2; more than
+// 30 at r ~ 380, C4).  INCR_MAX is the capacity of the change lists.
 #ifndef PQP_INCR_MAX
-#define PQP_INCR_MAX 8
+#define PQP_INCR_MAX 32
 #endif
 constexpr int INCR_MAX = PQP_INCR_MAX;
 constexpr int PARK_DOUBLES = 48;
-#ifndef PQP_HOLE_MAX
-#define PQP_HOLE_MAX 8
+#ifndef PQP_INCR_BASE
+#define PQP_INCR_BASE 8
 #endif
-constexpr int HOLE_MAX = PQP_HOLE_MAX;
+__host__ __device__ inline int
+incr_max(int r)
+{
+  const int v = r / 10;
+  return v < PQP_INCR_BASE ? (PQP_INCR_BASE < INCR_MAX ? PQP_INCR_BASE : INCR_MAX) : (v > INCR_MAX ? INCR_MAX : v);
+}
 
 struct Dims
 {
@@ -2093,9 +2100,10 @@ struct Solver
       toc(ST_CYC_ZG);
       return;
     }
-    // (holes are dead weight in every solve: past HOLE_MAX of them the block is re-packed)
-    const bool incremental = !dm() && !pm() && !schur_dirty && (na + nr) <= INCR_MAX && n_slots + na <= nc &&
-                             (n_slots - n_c) + nr <= HOLE_MAX;
+    // (holes are dead weight in every solve: past the same limit the block is re-packed)
+    const int lim = incr_max(r); // edits allowed in one change, and holes tolerated in the factor
+    const bool incremental = !dm() && !pm() && !schur_dirty && (na + nr) <= lim && n_slots + na <= nc &&
+                             (n_slots - n_c) + nr <= lim;
     if (INCR_MAX > 0 && incremental) {
       // ids that leave -> chg[0 .. nr), ids that enter -> chg[INCR_MAX .. INCR_MAX + na), ascending
       int tot_rm = 0, tot_add = 0;

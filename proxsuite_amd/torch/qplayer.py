@@ -55,7 +55,12 @@ _KEEP = 4
 def _checkout(key):
     free = _FREE.setdefault(key, [])
     if free:
-        return free.pop()
+        batch = free.pop()
+        # a reused handle must look like the fresh QP objects the reference builds at every forward:
+        # QP::cleanup() resets results and the proximal parameters (the previous backward left
+        # rho = rho_backward, mu = mu_backward in results.info, and init(..., rho=...) keeps mu)
+        batch.cleanup(-1)
+        return batch
     nbatch, nz, neq, nineq, index = key
     return _native.Batch(nbatch, nz, neq, nineq, box_constraints=False, hessian_type=int(HessianType.Dense),
                          dense_backend=int(DenseBackend.Automatic), device=index)
