@@ -429,8 +429,10 @@ gemv_part_len(int nt, int jmax)
 template<int NT>
 __device__ PQP_CALL void
 gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap, int rowsplit,
-     cliptr colmap, int colsplit, int tri = 0)
+     cliptr colmap, int colsplit, int tri = 0, lptr out2 = nullptr, clptr div = nullptr)
 {
+  // out2 / div (optional epilogue, compile-time constant at every call site): out2[j] = out[j] / div[j]
+  // in the same pass that writes out[j] -- saves the caller a loop and a barrier interval
   // tri = +1: M[k][j] == 0 for k > j (only k <= j is read);  tri = -1: M[k][j] == 0 for k < j.
   // Honoured on the plain (no row gather) k-split path; the skipped terms are exact zeros.
   constexpr int NW = NT / WAVE;
@@ -571,6 +573,8 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
     for (int q = 1; q < KS; ++q)
       s += part[q * J + j];
     out[j] = s;
+    if (out2)
+      out2[j] = s / div[j];
   }
   __syncthreads();
 }
@@ -616,10 +620,22 @@ load_pair(cgptr p)
 
 // W = doubles per lane and load: 2 (16-byte loads, 32-column stripes; needs even ld / n and a
 // 16-byte aligned M) or 1.
+// Epilogues (compile-time constants at the call sites; they fold an element-wise loop and its barrier
+// interval of the caller into the pass):
+//   EPI_ROW_RSUB : rowout[r] = (row sum) - rowout[r]           (in place)
+//   EPI_ROW_DIV  : rowout[r] = (row sum) / ea[r]
+//   EPI_COL_SUBDIV: colout[j] = (ea[j] - (column sum)) / eb[j]
+enum
+{
+  EPI_NONE = 0,
+  EPI_ROW_RSUB = 1,
+  EPI_ROW_DIV = 2,
+  EPI_COL_SUBDIV = 3
+};
 template<int NT, bool COLS, bool GATHER, bool ROWS, int W>
 __device__ __forceinline__ void
 gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
-               cliptr rowmap, int rowsplit)
+               cliptr rowmap, int rowsplit, int epi, clptr ea, clptr eb)
 {
   constexpr int NW = NT / WAVE;
   constexpr int CH = 8 / W; // stripes of 16 * W columns per lane and column block (128 columns)
@@ -684,8 +700,12 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
                 p0 = fma(m[u][c][e], vv[c][e], p0);
             }
           const double pr = row16_sum(p0 + p1);
-          if (valid[u] && s == 15)
-            rowout[r[u]] = (c0 == 0) ? pr : rowout[r[u]] + pr;
+          if (valid[u] && s == 15) {
+            double o = (c0 == 0) ? ((epi == EPI_ROW_RSUB) ? pr - rowout[r[u]] : pr) : rowout[r[u]] + pr;
+            if (epi == EPI_ROW_DIV && c0 + 128 >= n)
+              o /= ea[r[u]];
+            rowout[r[u]] = o;
+          }
         }
         if (COLS) {
           const double wr = valid[u] ? w[valid[u] ? r[u] : 0] : 0.0;
@@ -718,7 +738,7 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
 #pragma unroll
       for (int q = 1; q < NW; ++q)
         a += part[q * n + j];
-      colout[j] = a;
+      colout[j] = (epi == EPI_COL_SUBDIV) ? (ea[j] - a) / eb[j] : a;
     }
     __syncthreads();
   }
@@ -728,13 +748,13 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
 template<int NT, bool COLS = true, bool GATHER = false, bool ROWS = true>
 __device__ PQP_CALL void
 gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
-          cliptr rowmap = nullptr, int rowsplit = 0)
+          cliptr rowmap = nullptr, int rowsplit = 0, int epi = EPI_NONE, clptr ea = nullptr, clptr eb = nullptr)
 {
   const bool wide = (((ld | n) & 1) == 0) && ((reinterpret_cast<unsigned long long>(M) & 15ull) == 0);
   if (wide)
-    gemv_dual_impl<NT, COLS, GATHER, ROWS, 2>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
+    gemv_dual_impl<NT, COLS, GATHER, ROWS, 2>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit, epi, ea, eb);
   else
-    gemv_dual_impl<NT, COLS, GATHER, ROWS, 1>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit);
+    gemv_dual_impl<NT, COLS, GATHER, ROWS, 1>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit, epi, ea, eb);
 }
 
 // ---------------------------------------------------------------------------

@@ -1416,14 +1416,20 @@ struct Solver
   }
 
   // out = L^{-1} v  /  out = L^{-T} v   (LDS vectors, may alias)
-  __device__ __forceinline__ void apply_Linv(clptr v, lptr out, bool transposed)
+  // (out2 / div: optional epilogue out2 = out / div written in the same pass)
+  __device__ __forceinline__ void apply_Linv(clptr v, lptr out, bool transposed, lptr out2 = nullptr, clptr div = nullptr)
   {
     if (hess() == PQP_HESSIAN_DENSE) {
       // W = L^{-1} is lower triangular: WU[k][j] = W[j][k] vanishes for k > j, WL[k][j] for k < j
       gemv<NT>(transposed ? (cgptr)P.WL() : (cgptr)P.WU(), d.n, d.n, d.n, v, out, L.part(), nullptr, 0, nullptr,
-               0, transposed ? -1 : +1);
-    } else if (v != out) {
-      vcopy(out, v, d.n);
+               0, transposed ? -1 : +1, out2, div);
+    } else {
+      for (int k = threadIdx.x; k < d.n; k += NT) {
+        const double t = v[k];
+        out[k] = t;
+        if (out2)
+          out2[k] = t / div[k];
+      }
       __syncthreads();
     }
   }
@@ -1657,10 +1663,7 @@ struct Solver
     }
     cgptr W = P.WS();
     // t = W v : row sums (16 lanes per row of the row-major factor)
-    gemv_dual<NT, false>(W, d.nd, rr, rr, v, v, L.t2(), L.t2(), L.part());
-    for (int a = threadIdx.x; a < rr; a += NT)
-      L.t2()[a] /= L.dS()[a];
-    __syncthreads();
+    gemv_dual<NT, false>(W, d.nd, rr, rr, v, v, L.t2(), L.t2(), L.part(), nullptr, 0, EPI_ROW_DIV, L.dS());
     // v = W^T (t / D) : thread per column, rows below the diagonal only
     gemv<NT>(W, d.nd, rr, rr, L.t2(), v, L.part(), nullptr, 0, nullptr, 0, -1);
     bytes((long)rr * (rr + 1) * 8);
@@ -1900,20 +1903,14 @@ struct Solver
         touched += WSp[(e <= last) ? e : last];
       }
     }
-    apply_Linv(bx, L.t1(), false); // t = L^{-1} bx
-    for (int k = threadIdx.x; k < n; k += NT)
-      L.t2()[k] = L.t1()[k] / L.dF()[k];
-    __syncthreads();
+    apply_Linv(bx, L.t1(), false, L.t2(), L.dF()); // t = L^{-1} bx ; t2 = t / D
     if (rr > 0) {
       // s_a = z_a . (t / D) - bd_a : row sums over the ACTIVE rows of Zr (contiguous rows; a column
       // gather of Zc would touch every cache line of that matrix).  `part` is free scratch here
       // (gemv_dual only uses it for column sums) and holds at least n_d doubles.
-      gemv_dual<NT, false, true>(P.Zr(), n, rr, n, L.t2(), L.t2(), L.part(), L.part(), L.part(), L.act(),
-                                        d.n_eq);
-      const bool holes = n_slots > n_c;
-      for (int a = threadIdx.x; a < rr; a += NT)
-        bd[a] = (holes && !slot_live(a)) ? 0.0 : L.part()[a] - bd[a];
-      __syncthreads();
+      // (written in place: bd_a <- z_a . t2 - bd_a; the holes are zeroed afterwards)
+      gemv_dual<NT, false, true>(P.Zr(), n, rr, n, L.t2(), L.t2(), bd, bd, L.part(), L.act(), d.n_eq, EPI_ROW_RSUB);
+      zero_holes(bd);
       // (M + G) dvec = s
       toc(ST_CYC_KKT_SOLVE);
 #ifndef PQP_EXP_NOAPPLY
@@ -1921,13 +1918,16 @@ struct Solver
 #endif
       toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
-      if constexpr (NT == 256)
-        gemv_dual<NT, true, true, false>(P.Zr(), n, rr, n, bd, bd, L.t2(), L.t2(), L.part(), L.act(), d.n_eq);
-      else
+      if constexpr (NT == 256) {
+        // t1 <- (t1 - Z_J^T dvec) / D in the epilogue of the column sums
+        gemv_dual<NT, true, true, false>(P.Zr(), n, rr, n, bd, bd, L.t1(), L.t1(), L.part(), L.act(), d.n_eq,
+                                         EPI_COL_SUBDIV, L.t1(), L.dF());
+      } else {
         gemv<NT>(P.Zr(), n, rr, n, bd, L.t2(), L.part(), L.act(), d.n_eq, nullptr, 0);
-      for (int k = threadIdx.x; k < n; k += NT)
-        L.t1()[k] = (L.t1()[k] - L.t2()[k]) / L.dF()[k];
-      __syncthreads();
+        for (int k = threadIdx.x; k < n; k += NT)
+          L.t1()[k] = (L.t1()[k] - L.t2()[k]) / L.dF()[k];
+        __syncthreads();
+      }
     } else {
       vcopy(L.t1(), L.t2(), n);
       __syncthreads();
