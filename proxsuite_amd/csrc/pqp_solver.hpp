@@ -1940,15 +1940,12 @@ struct Solver
 
   // err = rhs - K * sol for sol = (L.dx(), L.sd()); by-products Hdx, Adx, ATdy, the
   // ACTIVE part of C^T dz in CTdz and C dx for all rows in Cdx (solver.hpp:243-318)
-  __device__ __forceinline__ void kkt_residual()
+  // (L.zfull() must hold the inequality part of the solution by constraint id, zero where inactive:
+  // iterative_solve scatters it while it accumulates the solution.  Returns the infinity norm of err.)
+  __device__ __forceinline__ double kkt_residual()
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
     const double rho = info.rho;
-    for (int i = threadIdx.x; i < nc; i += NT) {
-      int s = L.slot_of()[i];
-      L.zfull()[i] = (s >= 0) ? L.sd()[ne + s] : 0.0;
-    }
-    __syncthreads();
     if (hess() == PQP_HESSIAN_DENSE) {
       hess_mv(L.dx(), L.Hdx());
     } else {
@@ -1993,32 +1990,34 @@ struct Solver
       }
       __syncthreads();
     }
-    for (int k = threadIdx.x; k < n; k += NT)
-      L.ex()[k] = L.rx()[k] - rho * L.dx()[k] - L.Hdx()[k] - L.ATdy()[k] - L.CTdz()[k];
-    for (int k = threadIdx.x; k < ne; k += NT)
-      L.ed()[k] = L.rd()[k] - L.Adx()[k] + L.sd()[k] * info.mu_eq;
+    // err and its norm in one pass (the reduction's barrier publishes ex / ed; holes hold zeros)
+    double m = 0;
+    for (int k = threadIdx.x; k < n; k += NT) {
+      const double e = L.rx()[k] - rho * L.dx()[k] - L.Hdx()[k] - L.ATdy()[k] - L.CTdz()[k];
+      L.ex()[k] = e;
+      m = fmax(m, fabs(e));
+    }
+    for (int k = threadIdx.x; k < ne; k += NT) {
+      const double e = L.rd()[k] - L.Adx()[k] + L.sd()[k] * info.mu_eq;
+      L.ed()[k] = e;
+      m = fmax(m, fabs(e));
+    }
     for (int i = threadIdx.x; i < nc; i += NT) {
       int s = L.slot_of()[i];
-      if (s >= 0)
-        L.ed()[ne + s] = L.rd()[ne + s] - (L.Cdx()[i] - L.sd()[ne + s] * info.mu_in);
+      if (s >= 0) {
+        const double e = L.rd()[ne + s] - (L.Cdx()[i] - L.sd()[ne + s] * info.mu_in);
+        L.ed()[ne + s] = e;
+        m = fmax(m, fabs(e));
+      }
     }
-    __syncthreads();
+    const double nrm = R.max(m);
     zero_holes(L.ed());
     {
       const long mats = (NT == 256) ? 1 : 2; // one pass over A_s / C_s, or A_s and its transpose
       bytes((((hess() == PQP_HESSIAN_DENSE) ? (long)n * n : (long)n) +
              (dm() ? (long)ni : mats * ((long)ne * n + (long)ni * n))) * 8);
     }
-  }
-
-  __device__ __forceinline__ double err_norm()
-  {
-    double m = 0;
-    for (int k = threadIdx.x; k < d.n; k += NT)
-      m = fmax(m, fabs(L.ex()[k]));
-    for (int k = threadIdx.x; k < r; k += NT)
-      m = fmax(m, fabs(L.ed()[k]));
-    return R.max(m);
+    return nrm;
   }
 
   // reference solver.hpp:406-541: solve + iterative refinement on the unfactorised
@@ -2044,14 +2043,22 @@ struct Solver
       kkt_solve_in_place(L.ex(), L.ed());
       for (int k = threadIdx.x; k < n; k += NT)
         L.dx()[k] += L.ex()[k];
-      for (int k = threadIdx.x; k < r; k += NT)
-        L.sd()[k] += L.ed()[k];
+      // the dual part of the solution, also scattered by constraint id for the residual's C^T dz
+      // (zero where a constraint is inactive; hole slots carry zeros and own no constraint)
+      for (int a = threadIdx.x; a < r; a += NT) {
+        const double v = L.sd()[a] + L.ed()[a];
+        L.sd()[a] = v;
+        if (a >= d.n_eq && slot_live(a))
+          L.zfull()[L.act()[a - d.n_eq]] = v;
+      }
+      for (int i = threadIdx.x; i < d.nc; i += NT)
+        if (L.slot_of()[i] < 0)
+          L.zfull()[i] = 0.0;
       __syncthreads();
       toc(ST_CYC_KKT_SOLVE);
-      kkt_residual();
+      cur = kkt_residual();
       toc(ST_CYC_RESIDUAL);
       ++it;
-      cur = err_norm();
 #ifdef PQP_TRACE
       if (threadIdx.x == 0)
         printf("  refine q=%ld it=%ld r=%d n_c=%d slots=%d err=%.3e eps=%.1e\n", q, it, r, n_c, n_slots, (double)cur, eps);
