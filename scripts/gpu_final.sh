@@ -1,0 +1,33 @@
+#!/bin/bash
+# End-of-round measurement set (run on the GPU box): bench lines of every BASELINE config, the
+# rocprofv3 kernel-trace --stats summary of the default bench command, PMC traffic per config.
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+[ -z "$R" ] && R=$(cd $(dirname $0)/.. && pwd)
+TAG=${1:-r02}
+mkdir -p $R/gpurun_out/final
+cd $R
+python bench.py --steps 10 --warmup 2 --stats > gpurun_out/final/${TAG}_bench_c2.log 2>&1
+tail -1 gpurun_out/final/${TAG}_bench_c2.log > gpurun_out/final/${TAG}_bench_c2.json
+for w in c1 c4 c5 c5box; do
+  python bench.py --workload $w --steps 5 --warmup 1 --stats > gpurun_out/final/${TAG}_bench_$w.log 2>&1
+  tail -1 gpurun_out/final/${TAG}_bench_$w.log > gpurun_out/final/${TAG}_bench_$w.json
+done
+python bench.py --workload backend --steps 5 --warmup 1 --mpc-steps 0 --cpu-sample 256 > gpurun_out/final/${TAG}_bench_backend_primal_ldlt.log 2>&1
+PQP_BENCH_ONE_DEVICE=1 PQP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --mpc-steps 0 > gpurun_out/final/${TAG}_bench_2ranks_one_gpu.log 2>&1
+cd /tmp
+rm -rf $R/gpurun_out/final/trace
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/trace -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --mpc-steps 0 > $R/gpurun_out/final/${TAG}_trace_bench.log 2>&1
+cd $R
+f=$(find gpurun_out/final/trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f gpurun_out/final/${TAG}_kernel_stats.csv
+scripts/gpu_pmc_traffic.sh c2 c1 c4 c5 c5box 2>&1 | tail -6
+for w in c2 c1 c4 c5 c5box; do python - $w $TAG <<'PY'
+import json, sys
+w, tag = sys.argv[1:3]
+j = json.loads(open('gpurun_out/final/%s_bench_%s.json' % (tag, w)).read())
+r = j['roofline']
+print(w, round(j['value']), '%.3f ms' % j['ms_per_step'], 'unsolved', j['unsolved'], 'kkt %.2e' % j['max_kkt_residual'],
+      'engineMB %.2f' % (r.get('engine_bytes_per_qp', 0) / 1e6), 'frac %.3f' % (r.get('frac') or 0), 'cpu', round(j['cpu_baseline']['value']))
+PY
+done
