@@ -758,159 +758,6 @@ gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr col
 }
 
 // ---------------------------------------------------------------------------
-// Blocked left-looking LDL^T of a symmetric m x m matrix stored FULL row-major
-// in HBM (leading dimension ld, m <= NT: thread i owns row i of the panel in
-// registers).  Only the UPPER triangle of the input is read.  On exit:
-//   M[k][i], k<i : L[i][k]   (upper part = L^T; every load/store of the
-//                             factorisation is coalesced along i)
-//   M[j][j]      : d_j       (also d[j] in LDS)
-// FULL = true additionally leaves (for tri_inverse, primal block only)
-//   M[i][k], k<i, outside the diagonal blocks : L[i][k]  (lower mirror)
-//   diagonal 16x16 blocks: strict lower = inv(L_bb), strict upper = inv(L_bb)^T
-// Restates what the reference's factorization computes
-// (reference include/proxsuite/linalg/dense/factorize.hpp:89-148, 215-280:
-// D from the diagonal recurrence, L = unit lower) with a static pivot order.
-// `top` is LDS scratch of 2*PQP_NB*PQP_NB doubles; `prof` (optional, LDS) receives
-// the cycles of the five sub-phases.
-// ---------------------------------------------------------------------------
-template<int NT, bool FULL>
-__device__ PQP_CALL void
-ldlt_factor(gptr M, int ld, int m, lptr d, lptr top, PQP_LDS long long* prof = nullptr)
-{
-  constexpr int NB = PQP_NB;
-  const int i = threadIdx.x;
-  lptr tl = top + NB * NB; // normalised top block (unit lower), for the inverse
-  long long t0 = 0;
-#define PQP_PROF(slot)                                                                            \
-  if (prof && threadIdx.x == 0) {                                                                  \
-    long long t1 = clock64();                                                                      \
-    prof[slot] += t1 - t0;                                                                         \
-    t0 = t1;                                                                                       \
-  }
-  if (prof && threadIdx.x == 0)
-    t0 = clock64();
-  for (int j0 = 0; j0 < m; j0 += NB) {
-    const int nb = (m - j0 < NB) ? (m - j0) : NB;
-    double p[NB];
-    const bool row_active = (i >= j0 && i < m);
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-      p[c] = 0.0;
-    if (row_active) {
-#pragma unroll
-      for (int c = 0; c < NB; ++c)
-        if (c < nb && i >= j0 + c)
-          p[c] = M[(long)(j0 + c) * ld + i];
-    }
-    PQP_PROF(0)
-    // left-looking update with the factorised columns k < j0, 16 columns at a time.
-    // Both operands come from the upper mirror: the thread's own 16 values
-    // L[i][k0+kk] = M[k0+kk][i] (coalesced along i) and the 16 x 16 block
-    // W[c][kk] = L[j0+c][k0+kk] * d[k0+kk] staged through LDS.  All loads of a chunk
-    // are issued before its barrier: one HBM round trip per 16 columns.
-    constexpr int KC = 8; // columns per chunk: li[KC] stays live across the barrier
-    for (int k0 = 0; k0 < j0; k0 += KC) {
-      double li[KC];
-      if (row_active) {
-        cgptr col = M + (long)k0 * ld + i;
-#pragma unroll
-        for (int kk = 0; kk < KC; ++kk)
-          li[kk] = col[(long)kk * ld];
-      }
-      for (int o = threadIdx.x; o < NB * KC; o += NT) {
-        const int kk = o / NB, c = o % NB;
-        top[c * KC + kk] = (c < nb) ? M[(long)(k0 + kk) * ld + j0 + c] * d[k0 + kk] : 0.0;
-      }
-      __syncthreads();
-      if (row_active) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
-          double acc = p[c];
-#pragma unroll
-          for (int kk = 0; kk < KC; ++kk)
-            acc = fma(-li[kk], top[c * KC + kk], acc);
-          p[c] = acc;
-        }
-      }
-      __syncthreads();
-    }
-    PQP_PROF(1)
-    // in-panel right-looking elimination; one barrier per column
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      if (c < nb) {
-        if (row_active && i >= j0 + c && i < j0 + nb)
-          top[c * NB + (i - j0)] = p[c];
-        __syncthreads();
-        if (row_active && i > j0 + c) {
-          double dc = top[c * NB + c];
-          double lic = p[c] / dc;
-#pragma unroll
-          for (int c2 = c + 1; c2 < NB; ++c2)
-            if (c2 < nb && i >= j0 + c2)
-              p[c2] = fma(-lic, top[c * NB + c2], p[c2]);
-          p[c] = lic;
-        }
-      }
-    }
-    PQP_PROF(2)
-    // write back: diagonal + upper mirror (coalesced along i)
-    if (row_active) {
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        if (c < nb) {
-          if (i == j0 + c) {
-            d[i] = p[c];
-            M[(long)i * ld + i] = p[c];
-          } else if (i > j0 + c) {
-            if (!FULL || i >= j0 + nb)
-              M[(long)(j0 + c) * ld + i] = p[c];
-            if (FULL) {
-              if (i >= j0 + nb)
-                M[(long)i * ld + (j0 + c)] = p[c];
-              else
-                tl[(i - j0) * NB + c] = p[c];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    PQP_PROF(3)
-    if (FULL) {
-      // inverse of the unit-lower diagonal block: thread c solves column c
-      if (i >= j0 && i < j0 + nb) {
-        const int c = i - j0;
-        double xcol[NB];
-#pragma unroll
-        for (int r = 0; r < NB; ++r)
-          xcol[r] = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int r = 1; r < NB; ++r) {
-          if (r < nb && r > c) {
-            double acc = 0;
-#pragma unroll
-            for (int q = 0; q < NB; ++q)
-              if (q >= c && q < r)
-                acc = fma(tl[r * NB + q], xcol[q], acc);
-            xcol[r] = -acc;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < NB; ++r)
-          if (r < nb && r > c) {
-            M[(long)(j0 + r) * ld + (j0 + c)] = xcol[r]; // inv(L_bb)[r][c]
-            M[(long)(j0 + c) * ld + (j0 + r)] = xcol[r]; // its transpose
-          }
-      }
-      __syncthreads();
-    }
-    PQP_PROF(4)
-  }
-#undef PQP_PROF
-}
-
-// ---------------------------------------------------------------------------
 // FP64 matrix core: D(16x16) += A(16x4) * B(4x16), one wavefront, v_mfma_f64_16x16x4_f64.
 // Operand layout (lane l of 64): a = A[l & 15][l >> 4], b = B[l >> 4][l & 15];
 // result register r (0..3) of lane l = D[(l >> 4) + 4 r][l & 15].
@@ -934,9 +781,8 @@ mfma_f64_16x16x4(double a, double b, pqp_d4 c)
 // ---------------------------------------------------------------------------
 // Register-resident LDL^T for m <= 16*MB, NT = 256 threads as a 16 x 16 grid.
 //
-// The HBM-resident ldlt_factor above pays an HBM round trip per 8-column chunk
-// and a barrier per column; at the sizes of the dual Schur block (m ~ 50..110)
-// that is ~100 dependent memory latencies per factorisation.  Here the lower
+// An HBM-resident factorisation pays a memory round trip per column chunk; at sizes
+// of m ~ 50..110 that is ~100 dependent memory latencies.  Here the lower
 // triangle lives in VGPRs for the whole factorisation: thread (ti, tj) owns
 // the element (16*bi + ti, 16*bj + tj) of every 16 x 16 block bi >= bj
 // (block-cyclic, MB*(MB+1)/2 doubles per thread), `load(i, j)` is called once
@@ -946,7 +792,7 @@ mfma_f64_16x16x4(double a, double b, pqp_d4 c)
 // a_ij -= a_ik a_jk / d_k to its own registers.  The block-column index kb is
 // unrolled so every register index is static.
 // Output: the upper mirror U[j][i] = l_ij (i > j) and U[j][j] = d_j in global
-// memory, d[] in LDS -- the layout ldlt_solve consumes.
+// memory, d[] in LDS.
 // `cbuf`: 4 * 16 * MB doubles of LDS (raw + scaled column, double-buffered).
 // ---------------------------------------------------------------------------
 // value of `v` in lane `src` (uniform) of the calling wavefront, through scalar registers
@@ -1218,109 +1064,6 @@ block_scan_inclusive(double v, lptr scratch)
   return v + off;
 }
 
-// ---------------------------------------------------------------------------
-// Solve (L D L^T) x = v in place for an LDS vector v (length m <= NT) using the
-// upper-mirror factor of ldlt_factor<NT, false>.  Restates reference
-// include/proxsuite/linalg/dense/solve.hpp:15-26 (forward unit-lower sweep,
-// diagonal scaling, backward sweep).  Per 16-row block: the in-block
-// substitution runs inside one wavefront with lane shuffles (no LDS, no
-// barrier), the block's 16 results are broadcast through LDS (double-buffered:
-// ONE barrier per block) and every other row applies its 16 coalesced updates,
-// whose loads were issued before the barrier.  `blk`: 2*PQP_NB doubles of LDS.
-// ---------------------------------------------------------------------------
-template<int NT>
-__device__ PQP_CALL void
-ldlt_solve(cgptr M, int ld, int m, clptr d, lptr v, lptr blk)
-{
-  constexpr int NB = 32; // rows per block step (one wavefront holds two blocks)
-  const int a = threadIdx.x;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wid = threadIdx.x / WAVE;
-  double val = (a < m) ? v[a] : 0.0;
-  int buf = 0;
-  // forward: L y = v
-  for (int j0 = 0; j0 < m; j0 += NB) {
-    const int nb = (m - j0 < NB) ? (m - j0) : NB;
-    const int c = a - j0; // position inside / below the block
-    double u[NB];
-#pragma unroll
-    for (int q = 0; q < NB; ++q)
-      u[q] = 0.0;
-    if (c > 0 && a < m) {
-#pragma unroll
-      for (int q = 0; q < NB; ++q)
-        if (q < nb && q < c)
-          u[q] = M[(long)(j0 + q) * ld + a]; // L[a][j0+q]
-    }
-    if (wid == j0 / WAVE) {
-      const int base = j0 & (WAVE - 1);
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        double yq = lane_bcast(val, base + q); // v_readlane: the source lane is wave-uniform
-        if (q < nb && c > q && c < nb)
-          val = fma(-u[q], yq, val);
-      }
-      if (c >= 0 && c < nb)
-        blk[buf * NB + c] = val;
-    }
-    __syncthreads();
-    if (c >= nb && a < m) {
-      double acc = val;
-#pragma unroll
-      for (int q = 0; q < NB; ++q)
-        if (q < nb)
-          acc = fma(-u[q], blk[buf * NB + q], acc);
-      val = acc;
-    }
-    buf ^= 1;
-  }
-  if (a < m)
-    val /= d[a];
-  // backward: L^T x = y
-  const int last = ((m - 1) / NB) * NB;
-  for (int j0 = last; j0 >= 0; j0 -= NB) {
-    const int nb = (m - j0 < NB) ? (m - j0) : NB;
-    const int c = a - j0;
-    double u[NB];
-#pragma unroll
-    for (int q = 0; q < NB; ++q)
-      u[q] = 0.0;
-    if (a < j0 + nb && a < m) {
-      // own row a, columns j0 .. j0+nb-1:  L[j0+q][a] = M[a][j0+q]  (q > c inside the block)
-      cgptr row = M + (long)a * ld + j0;
-#pragma unroll
-      for (int q = 0; q < NB; ++q)
-        if (q < nb && q > c)
-          u[q] = row[q];
-    }
-    if (wid == j0 / WAVE) {
-      const int base = j0 & (WAVE - 1);
-#pragma unroll
-      for (int qq = 0; qq < NB; ++qq) {
-        const int q = NB - 1 - qq;
-        double xq = lane_bcast(val, base + q);
-        if (q < nb && c >= 0 && c < q)
-          val = fma(-u[q], xq, val);
-      }
-      if (c >= 0 && c < nb)
-        blk[buf * NB + c] = val;
-    }
-    __syncthreads();
-    if (c < 0) {
-      double acc = val;
-#pragma unroll
-      for (int q = 0; q < NB; ++q)
-        if (q < nb)
-          acc = fma(-u[q], blk[buf * NB + q], acc);
-      val = acc;
-    }
-    buf ^= 1;
-  }
-  if (a < m)
-    v[a] = val;
-  __syncthreads();
-}
-
 // (the explicit inverse W = L^{-1} is computed on the matrix cores: tri_inverse_mfma /
 // tri_inverse_mfma_rows below)
 
@@ -1407,9 +1150,9 @@ diag_block_inverses_mfma(gptr F, int ld, int n)
 }
 
 // ---------------------------------------------------------------------------
-// tri_inverse on the FP64 matrix cores, n <= 16 * MB.  Same input (the FULL layout of
-// ldlt_factor: L in both mirrors, inv(L_bb) / inv(L_bb)^T in the diagonal blocks) and the same
-// output (WL = L^{-1}, WU = WL^T) as tri_inverse above.
+// tri_inverse on the FP64 matrix cores, n <= 16 * MB.  Input: the FULL layout of the
+// factorisation routines (L in both mirrors, inv(L_bb) / inv(L_bb)^T in the diagonal blocks, d_j on
+// the diagonal); output: WL = L^{-1} (row-major, lower) and WU = WL^T.
 // Block forward substitution, one block COLUMN j of W per wavefront:
 //     W_jj = inv(L_jj),    W_ij = -inv(L_ii) * sum_{k=j}^{i-1} L_ik W_kj     (i > j)
 // Every product is a 16x16x16 tile product = 4 MFMAs.  The W_kj tiles of the column stay in
@@ -1529,7 +1272,9 @@ wave_sync()
 
 // ---------------------------------------------------------------------------
 // Blocked LDL^T on the FP64 matrix cores for any m <= NT, matrix in HBM / L2 (full symmetric
-// row-major input, leading dimension ld).  Same outputs as ldlt_factor<NT, FULL>:
+// row-major input, leading dimension ld; only the upper triangle is read).  Restates what the
+// reference's factorisation computes (include/proxsuite/linalg/dense/factorize.hpp:89-148, 215-280:
+// D from the diagonal recurrence, L = unit lower) with a static pivot order.  Outputs:
 //   upper mirror  M[k][i] = L[i][k] (i > k),   M[j][j] = d_j,   d[] in LDS;
 //   FULL: lower mirror outside the diagonal blocks, diagonal blocks = inv(L_bb) / inv(L_bb)^T.
 // Left-looking over 16-column panels kb, three phases per panel, one barrier after each:

@@ -1913,9 +1913,7 @@ struct Solver
       zero_holes(bd);
       // (M + G) dvec = s
       toc(ST_CYC_KKT_SOLVE);
-#ifndef PQP_EXP_NOAPPLY
       schur_apply(bd);
-#endif
       toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
       if constexpr (NT == 256) {
