@@ -498,7 +498,10 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
           cgptr p = col + (long)k * ld;
           // 16, then 8, independent loads issued back to back before their first use: the
           // kernel is bound by HBM round trips, so bytes in flight per lane is the lever
-          for (; k + 15 * KS < Kj; k += 16 * KS) {
+#ifndef PQP_GEMV_DEEP
+#define PQP_GEMV_DEEP 1 // 16 loads in flight per lane (0: 8 -- for register budgets below 168 VGPRs)
+#endif
+          for (; PQP_GEMV_DEEP && k + 15 * KS < Kj; k += 16 * KS) {
             double m[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u)

@@ -56,7 +56,10 @@ constexpr int PARK_DOUBLES = 48;
 __host__ __device__ inline int
 incr_max(int r)
 {
-  const int v = r / 10;
+#ifndef PQP_INCR_DIV
+#define PQP_INCR_DIV 10
+#endif
+  const int v = r / PQP_INCR_DIV;
   return v < PQP_INCR_BASE ? (PQP_INCR_BASE < INCR_MAX ? PQP_INCR_BASE : INCR_MAX) : (v > INCR_MAX ? INCR_MAX : v);
 }
 
@@ -1783,6 +1786,73 @@ struct Solver
     return delta > 0.0;
   }
 
+  // PrimalLDLT: a constraint entering (sign +1) or leaving (sign -1) the active set changes P_J by
+  // +- c c^T / mu_in -- a rank-1 update of its factorisation, done on the inverse factor exactly like
+  // the trailing update of schur_delete (reference update.hpp:219-287): p = L^{-1} c = W c (one
+  // mat-vec; for a box row, a column of W), the recurrence scalars from a prefix sum
+  // (1/alpha_{i+1} = 1/alpha_i + p_i^2/d_i, 1/alpha_0 = +- mu_in), then W' = Ltilde^{-1} W down every
+  // column independently.  Returns false when a pivot of the downdated factor is not positive
+  // (rounding on a nearly singular P_J): the caller re-assembles and re-factorises.
+  __device__ __forceinline__ bool pm_rank1(int cid, double sign)
+  {
+    const int n = d.n, ni = d.n_in;
+    gptr W = P.WL();
+    lptr pv = L.Hdx(), beta = L.ATdy(); // by-product vectors, idle while the active set is installed
+    if (cid < ni) {
+      vload(L.t1(), P.Cs() + (long)cid * n, n);
+      __syncthreads();
+      gemv_dual<NT, false>(W, n, n, n, L.t1(), L.t1(), pv, pv, L.part());
+    } else {
+      const int k = cid - ni;
+      const double ik = L.isc()[k];
+      for (int i = threadIdx.x; i < n; i += NT)
+        pv[i] = (i >= k) ? ik * W[(long)i * n + k] : 0.0;
+      __syncthreads();
+    }
+    const int i_own = threadIdx.x; // NT >= n
+    double my_p = 0.0, my_d = 1.0, my_e = 0.0;
+    if (i_own < n) {
+      my_p = pv[i_own];
+      my_d = L.dF()[i_own];
+      my_e = my_p * my_p / my_d;
+    }
+    const double incl = block_scan_inclusive<NT>(my_e, L.part());
+    const double inv_a0 = sign * double(info.mu_in); // 1 / alpha_0, alpha_0 = +- 1 / mu_in
+    double bad = 0.0;
+    if (i_own < n) {
+      const double c_i = inv_a0 + incl, c_im1 = c_i - my_e;
+      const double dn = my_d * (c_i / c_im1);
+      beta[i_own] = my_p / (my_d * c_i);
+      L.dF()[i_own] = dn;
+      if (!(dn > 0.0) || !(c_i * c_im1 > 0.0))
+        bad = 1.0;
+    }
+    bad = R.max(bad);
+    for (int c = threadIdx.x; c < n; c += NT) {
+      double sacc = 0.0;
+      gptr col = W + c;
+      constexpr int U = 16;
+      for (int i = 0; i < n; i += U) {
+        double y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          y[u] = col[(long)((i + u < n) ? (i + u) : (n - 1)) * n];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (i + u < n) {
+            const double x = fma(-pv[i + u], sacc, y[u]);
+            sacc = fma(beta[i + u], x, sacc);
+            if (i + u >= c)
+              col[(long)(i + u) * n] = x;
+          }
+      }
+    }
+    bytes((long)n * n * 16 + (long)n * 16);
+    count(sign > 0 ? ST_N_APPEND : ST_N_DELETE);
+    __syncthreads();
+    return bad == 0.0;
+  }
+
   // PrimalLDLT form of the KKT solve:  P_J x = bx + B_J^T M^{-1} bd ,  d = M^{-1} (B_J x - bd).
   // Scratch: t1, t2, part and the by-product vectors of kkt_residual (Hdx, ATdy, CTdz, Adx, Cdx),
   // which are idle between two residual evaluations.
@@ -2106,6 +2176,55 @@ struct Solver
       return;
     }
     // (holes are dead weight in every solve: past the same limit the block is re-packed)
+    if (pm() && !schur_dirty && (na + nr) <= PQP_INCR_BASE) {
+      // PrimalLDLT: the factor of P_J does not depend on the slot order, so the slot map is simply
+      // re-packed; the factor takes one rank-1 update per constraint that left or entered
+      int tot_rm = 0, tot_add = 0;
+      for (int base = 0; base < nc; base += NT) {
+        const int i = base + threadIdx.x;
+        const bool want = (i < nc) && ((L.aflags()[i] & 4) != 0);
+        const bool had = (i < nc) && (L.slot_of()[i] >= 0);
+        int t1, t2;
+        const int rk1 = block_rank<NT>(!want && had, L.icnt(), t1);
+        if (!want && had)
+          L.chg()[tot_rm + rk1] = i;
+        const int rk2 = block_rank<NT>(want && !had, L.icnt(), t2);
+        if (want && !had)
+          L.chg()[INCR_MAX + tot_add + rk2] = i;
+        tot_rm += t1;
+        tot_add += t2;
+      }
+      int total = 0;
+      for (int base = 0; base < nc; base += NT) {
+        int i = base + threadIdx.x;
+        bool want = (i < nc) && ((L.aflags()[i] & 4) != 0);
+        int tot;
+        int rank = block_rank<NT>(want, L.icnt(), tot);
+        if (want) {
+          L.slot_of()[i] = total + rank;
+          L.act()[total + rank] = i;
+        } else if (i < nc) {
+          L.slot_of()[i] = -1;
+        }
+        total += tot;
+      }
+      __syncthreads();
+      n_c = total;
+      n_slots = total;
+      r = ne + n_slots;
+      toc(ST_CYC_ZG);
+      bool ok = true;
+      for (int t = 0; t < nr && ok; ++t)
+        ok = pm_rank1(uni(L.chg()[t]), -1.0);
+      for (int t = 0; t < na && ok; ++t)
+        ok = pm_rank1(uni(L.chg()[INCR_MAX + t]), +1.0);
+      schur_incremental = true;
+      toc(ST_CYC_SCHUR);
+      if (PQP_LIKELY(ok))
+        return;
+      schur_dirty = true; // a pivot went non-positive: the full path below re-assembles P_J
+      tic();
+    }
     const int lim = incr_max(r); // edits allowed in one change, and holes tolerated in the factor
     const bool incremental = !dm() && !pm() && !schur_dirty && (na + nr) <= lim && n_slots + na <= nc &&
                              (n_slots - n_c) + nr <= lim;
