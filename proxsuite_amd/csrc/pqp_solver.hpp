@@ -2374,11 +2374,15 @@ struct Solver
       }
     }
     bytes(dm() ? (long)ni * 8 : ((long)ne * n + (long)ni * n) * 8);
-    R.max3(m_eq0, m_in0, m_eql);
-    eq_rhs_0 = m_eq0;
-    in_rhs_0 = m_in0;
-    eq_lhs = m_eql;
-    in_lhs = R.max(m_inl);
+    {
+      double none[1] = { 0.0 };
+      double mv[4] = { m_eq0, m_in0, m_eql, m_inl };
+      R.template mixed<0, 4>(none, mv);
+      eq_rhs_0 = mv[0];
+      in_rhs_0 = mv[1];
+      eq_lhs = mv[2];
+      in_lhs = mv[3];
+    }
     lhs = fmax(eq_lhs, in_lhs);
     if (PQP_UNLIKELY(st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)) {
       // utils.hpp:241-248 : || A^T se + C^T si ||_inf on the unscaled model
@@ -2464,12 +2468,8 @@ struct Solver
         ml = fmax(ml, fabs(dr / sc));
       }
     }
-    R.max3(m0, m1, m3);
-    rhs_0 = (hess() == PQP_HESSIAN_ZERO) ? 0.0 : m0;
-    rhs_1 = m1;
-    rhs_3 = m3;
-    lhs = R.max(ml);
-    // duality gap terms (utils.hpp:482-586)
+    // duality gap terms (utils.hpp:482-586); the four norms above and the seven sums below close in
+    // ONE fused reduction
     double by = 0, zu = 0, zl = 0, zub = 0, zlb = 0;
     const double ib = 1.3407807929942596e+154; // sqrt(DBL_MAX), helpers/common.hpp:17-25
     {
@@ -2502,9 +2502,22 @@ struct Solver
         }
       }
     }
-    R.sum4(gx, xHx, by, zu);
-    R.sum2(zl, zub);
-    zlb = R.sum(zlb);
+    {
+      double sv[7] = { gx, xHx, by, zu, zl, zub, zlb };
+      double mv[4] = { m0, m1, m3, ml };
+      R.template mixed<7, 4>(sv, mv);
+      gx = sv[0];
+      xHx = sv[1];
+      by = sv[2];
+      zu = sv[3];
+      zl = sv[4];
+      zub = sv[5];
+      zlb = sv[6];
+      rhs_0 = (hess() == PQP_HESSIAN_ZERO) ? 0.0 : mv[0];
+      rhs_1 = mv[1];
+      rhs_3 = mv[2];
+      lhs = mv[3];
+    }
     duality_gap = gx;
     rhs_duality_gap = fabs(gx);
     if (hess() != PQP_HESSIAN_ZERO) {
@@ -2559,7 +2572,7 @@ struct Solver
     }
   }
 
-  __device__ __forceinline__ double primal_dual_ls()
+  __device__ __forceinline__ double primal_dual_ls(double& dw_max)
   {
     const int n = d.n, ne = d.n_eq, nc = d.nc;
     const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
@@ -2567,8 +2580,10 @@ struct Solver
     double s_dxHdx = 0, s_adx2 = 0, s_dx2 = 0, s_e2 = 0;
     double s_xHdx = 0, s_errdx = 0, s_adxres = 0, s_eres = 0;
     double s_dz2 = 0, s_dzz = 0;
+    double dwm = 0;
     for (int k = threadIdx.x; k < n; k += NT) {
       double dxk = L.dx()[k];
+      dwm = fmax(dwm, fabs(dxk));
       s_dxHdx += dxk * L.Hdx()[k];
       s_dx2 += dxk * dxk;
       s_xHdx += L.x()[k] * L.Hdx()[k];
@@ -2577,20 +2592,23 @@ struct Solver
     for (int k = threadIdx.x; k < ne; k += NT) {
       double adx = L.Adx()[k];
       double e = adx - L.dy()[k] * info.mu_eq;
+      dwm = fmax(dwm, fabs(L.dy()[k]));
       s_adx2 += adx * adx;
       s_e2 += e * e;
       s_adxres += adx * (L.se()[k] + L.y()[k] * info.mu_eq);
       s_eres += e * L.se()[k];
     }
     for (int k = threadIdx.x; k < nc; k += NT) {
+      dwm = fmax(dwm, fabs(L.dz()[k]));
       s_dz2 += L.dz()[k] * L.dz()[k];
       s_dzz += L.dz()[k] * L.z()[k];
     }
     {
       // the ten coefficient sums in one barrier interval
       double sv[10] = { s_dxHdx, s_adx2, s_dx2, s_e2, s_xHdx, s_errdx, s_adxres, s_eres, s_dz2, s_dzz };
-      double none[1] = { 0.0 };
-      R.template mixed<10, 0>(sv, none);
+      double mx[1] = { dwm };
+      R.template mixed<10, 1>(sv, mx);
+      dw_max = mx[0];
       s_dxHdx = sv[0];
       s_adx2 = sv[1];
       s_dx2 = sv[2];
@@ -2700,7 +2718,11 @@ struct Solver
   //   * dual: "some constraint breaks first_cond" is a maximum of a per-constraint signed value
   //     against bound = |dx|_inf eps_dual_inf, which is known only after the reduction: the value
   //     is reduced, the comparison made afterwards.
-  __device__ __forceinline__ void infeasibility_certificates(bool& primal_infeasible, bool& dual_infeasible)
+  // The inner stopping criterion of the same step (reference solver.hpp:687-743, the saddle-point
+  // error at the updated iterate) rides in the same reduction: `err_in`.  do_cert = false (uniform):
+  // only the stopping criterion is evaluated, nothing is mutated.
+  __device__ __forceinline__ void saddle_point_and_certificates(bool do_cert, double& err_in, bool& primal_infeasible,
+                                                                bool& dual_infeasible)
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in;
     const double c = ruiz_c;
@@ -2708,7 +2730,21 @@ struct Solver
     double lb1 = 0, gdx = 0;                          // sums
     double nrm_dy = 0, nrm_dz = 0, lb2 = 0;           // primal maxima
     double ndx = 0, nadx = 0, nhdx = 0, mviol = NEG;  // dual maxima
+    double e1 = 0, e2 = 0, e3 = 0;                    // saddle-point error
     {
+      const int nc = d.nc;
+      const double zf = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
+      for (int i = threadIdx.x; i < nc; i += NT) {
+        double up = L.rup()[i], lo = L.si()[i];
+        double v = (up > 0 ? up : 0.0) + (lo < 0 ? lo : 0.0) - zf * L.z()[i] * info.mu_in;
+        e1 = fmax(e1, fabs(v));
+      }
+      for (int k = threadIdx.x; k < ne; k += NT)
+        e2 = fmax(e2, fabs(L.se()[k]));
+      for (int k = threadIdx.x; k < n; k += NT)
+        e3 = fmax(e3, fabs(L.dres()[k]));
+    }
+    if (do_cert) {
       cgptr dx = P.dlt_x();
       for (int k = threadIdx.x; k < n; k += NT) {
         const double sc = dx[k] * c;
@@ -2760,8 +2796,8 @@ struct Solver
       }
     }
     double sv[2] = { lb1, gdx };
-    double mv[7] = { nrm_dy, nrm_dz, lb2, ndx, nadx, nhdx, mviol };
-    R.template mixed<2, 7>(sv, mv);
+    double mv[10] = { nrm_dy, nrm_dz, lb2, ndx, nadx, nhdx, mviol, e1, e2, e3 };
+    R.template mixed<2, 10>(sv, mv);
     lb1 = sv[0];
     gdx = sv[1];
     nrm_dy = mv[0];
@@ -2771,6 +2807,11 @@ struct Solver
     nadx = mv[4];
     nhdx = mv[5];
     mviol = mv[6];
+    err_in = fmax(mv[7], fmax(mv[8], mv[9]));
+    primal_infeasible = false;
+    dual_infeasible = false;
+    if (!do_cert)
+      return;
     {
       const double upper_bound = st.eps_primal_inf * fmax(nrm_dy, nrm_dz);
       primal_infeasible = (nrm_dy != 0 || nrm_dz != 0) && lb2 <= upper_bound && lb1 <= -upper_bound;
@@ -2782,25 +2823,6 @@ struct Solver
       const bool second_cond_alt1 = nhdx <= bound && gdx <= -bound;
       dual_infeasible = first_cond && second_cond_alt1 && ndx != 0;
     }
-  }
-
-  // reference solver.hpp:687-743
-  __device__ __forceinline__ double inner_loop_saddle_point()
-  {
-    const int n = d.n, ne = d.n_eq, nc = d.nc;
-    const double zf = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
-    double e1 = 0, e2 = 0, e3 = 0;
-    for (int i = threadIdx.x; i < nc; i += NT) {
-      double up = L.rup()[i], lo = L.si()[i];
-      double v = (up > 0 ? up : 0.0) + (lo < 0 ? lo : 0.0) - zf * L.z()[i] * info.mu_in;
-      e1 = fmax(e1, fabs(v));
-    }
-    for (int k = threadIdx.x; k < ne; k += NT)
-      e2 = fmax(e2, fabs(L.se()[k]));
-    for (int k = threadIdx.x; k < n; k += NT)
-      e3 = fmax(e3, fabs(L.dres()[k]));
-    R.max3(e1, e2, e3);
-    return fmax(e1, fmax(e2, e3));
   }
 
   // One linear step.  mode 0: semismooth Newton step (reference solver.hpp:754-869);
@@ -2937,24 +2959,26 @@ struct Solver
         __syncthreads();
       }
       UD alpha = 1.0;
-      if (ni > 0 || has_box())
-        alpha = primal_dual_ls();
+      // |dw|_inf of the step: the line search's first reduction carries it (solver.hpp:944-951 tests
+      // |alpha dw|_inf, and max_k fl(|alpha| |dw_k|) = fl(|alpha| max_k |dw_k|): rounding is monotone)
+      double dw_max = 0;
+      if (ni > 0 || has_box()) {
+        alpha = primal_dual_ls(dw_max);
+        // (the tail of the line search still reads rup / si / z / dz, which the update below rewrites)
+        __syncthreads();
+      } else {
+        for (int k = threadIdx.x; k < n; k += NT)
+          dw_max = fmax(dw_max, fabs(L.dx()[k]));
+        for (int k = threadIdx.x; k < ne; k += NT)
+          dw_max = fmax(dw_max, fabs(L.dy()[k]));
+        dw_max = R.max(dw_max);
+      }
       toc(ST_CYC_LINESEARCH);
       sub_tic(ST_CYC_UPDATE);
-      {
-        double m = 0;
-        for (int k = threadIdx.x; k < n; k += NT)
-          m = fmax(m, fabs(alpha * L.dx()[k]));
-        for (int k = threadIdx.x; k < ne; k += NT)
-          m = fmax(m, fabs(alpha * L.dy()[k]));
-        for (int k = threadIdx.x; k < nc; k += NT)
-          m = fmax(m, fabs(alpha * L.dz()[k]));
-        m = R.max(m);
-        if (m < 1.E-11 && iter > 0) {
-          info.iter += iter + 1;
-          sub_toc(ST_CYC_UPDATE);
-          break;
-        }
+      if (fabs(alpha) * dw_max < 1.E-11 && iter > 0) {
+        info.iter += iter + 1;
+        sub_toc(ST_CYC_UPDATE);
+        break;
       }
       for (int k = threadIdx.x; k < n; k += NT) {
         L.x()[k] += alpha * L.dx()[k];
@@ -2970,13 +2994,16 @@ struct Solver
         L.y()[k] += alpha * L.dy()[k];
       }
       __syncthreads();
-      const UD err_in = inner_loop_saddle_point();
       sub_toc(ST_CYC_UPDATE);
       bool stop = false;
-      if (iter % st.frequence_infeasibility_check == 0 || st.primal_infeasibility_solving) {
+      UD err_in = 0.0;
+      {
         sub_tic(ST_CYC_CERT);
+        const bool do_cert = iter % st.frequence_infeasibility_check == 0 || st.primal_infeasibility_solving;
         bool is_primal_infeasible, is_dual_infeasible;
-        infeasibility_certificates(is_primal_infeasible, is_dual_infeasible);
+        double e;
+        saddle_point_and_certificates(do_cert, e, is_primal_infeasible, is_dual_infeasible);
+        err_in = e;
         sub_toc(ST_CYC_CERT);
         if (PQP_UNLIKELY(is_primal_infeasible)) {
           info.status = PQP_PRIMAL_INFEASIBLE;
