@@ -32,6 +32,15 @@
 #define PQP_CALL __forceinline__
 #endif
 
+#ifndef PQP_STREAM_LOADS
+#define PQP_STREAM_LOADS 0
+#endif
+#if PQP_STREAM_LOADS && !defined(PQP_EMULATED_MFMA)
+#define PQP_LDG(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define PQP_LDG(ptr) (*(ptr))
+#endif
+
 namespace pqp {
 
 typedef PQP_LDS double* lptr;
@@ -498,14 +507,16 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
           cgptr p = col + (long)k * ld;
           // 16, then 8, independent loads issued back to back before their first use: the
           // kernel is bound by HBM round trips, so bytes in flight per lane is the lever
-#ifndef PQP_GEMV_DEEP
-#define PQP_GEMV_DEEP 1 // 16 loads in flight per lane (0: 8 -- for register budgets below 168 VGPRs)
+#ifndef PQP_GEMV_DEEP_256
+#define PQP_GEMV_DEEP_256 1 // (0 in the translation unit of the 128-VGPR C2 kernel: 8 loads in flight)
 #endif
-          for (; PQP_GEMV_DEEP && k + 15 * KS < Kj; k += 16 * KS) {
+          // 16 loads in flight per lane where the register budget allows
+          constexpr bool DEEP = (NT == 256) ? (PQP_GEMV_DEEP_256 != 0) : true;
+          for (; DEEP && k + 15 * KS < Kj; k += 16 * KS) {
             double m[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-              m[u] = p[u * step];
+              m[u] = PQP_LDG(p + u * step);
 #pragma unroll
             for (int u = 0; u < 16; u += 4) {
               a0 = fma(m[u], v[k + u * KS], a0);
@@ -614,7 +625,11 @@ load_pair(cgptr p)
 {
 #ifndef PQP_EMULATED_MFMA
   typedef double pqp_d2 __attribute__((ext_vector_type(2)));
+#if PQP_STREAM_LOADS
+  const pqp_d2 t = __builtin_nontemporal_load(reinterpret_cast<const PQP_GLOBAL pqp_d2*>(p));
+#else
   const pqp_d2 t = *reinterpret_cast<const PQP_GLOBAL pqp_d2*>(p);
+#endif
   return Pair{ t.x, t.y };
 #else
   return Pair{ p[0], p[1] };
@@ -659,7 +674,10 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
       }
     }
     // U row steps per trip: the loads of all of them are issued before the first use
-    constexpr int U = 2;
+#ifndef PQP_DUAL_U
+#define PQP_DUAL_U 2
+#endif
+    constexpr int U = PQP_DUAL_U;
     for (int base = 0; base < R; base += U * 4 * NW) {
       int r[U];
       bool valid[U];
@@ -680,7 +698,7 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
               m[u][c][0] = t.x;
               m[u][c][W - 1] = t.y;
             } else {
-              m[u][c][0] = row[off[c]];
+              m[u][c][0] = PQP_LDG(row + off[c]);
             }
           } else {
 #pragma unroll

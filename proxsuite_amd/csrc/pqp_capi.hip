@@ -249,6 +249,11 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
 
   pqp_batch* h = new pqp_batch();
   h->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      h->n_cu = cus;
+  }
   h->backend = dense_backend_choice(dense_backend, dim, n_eq, n_in, box_constraints != 0);
   pqp::Dims& d = h->dev.d;
   d.n = int(dim);

@@ -35,6 +35,7 @@ struct pqp_batch
 {
   pqp::Batch dev{};
   int device = 0;
+  int n_cu = 256; // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int nt = 256;
   int backend = PQP_BACKEND_PRIMAL_DUAL_LDLT;
   size_t lds_solve = 0, lds_setup = 0;

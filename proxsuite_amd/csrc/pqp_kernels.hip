@@ -1,21 +1,31 @@
 // The kernels of libproxqp_hip.so and their launchers.  Compiled once per kernel family
-// (-DPQP_TU=1..6, objects built in parallel by proxsuite_amd/_build.py); PQP_TU undefined or 0
+// (-DPQP_TU=1..7, objects built in parallel by proxsuite_amd/_build.py); PQP_TU undefined or 0
 // compiles everything in one translation unit (the CPU emulator build of tests/emu does that).
-//   1  pqp_solve_kernel<256, ., 1>    no box constraints, dense Hessian (the C2 kernel)
-//   2  pqp_solve_kernel<256, ., 0>
+//   1  pqp_solve_kernel<256, 4, 1>    no box constraints, dense Hessian (the C2 kernel): 128 VGPRs per
+//                                     lane, FOUR workgroups per CU -- launches that fill the device
+//   7  pqp_solve_kernel<256, 3, 1>    the same solve with 168 VGPRs per lane, three workgroups per CU:
+//                                     lower latency per QP, used when the launch leaves CUs idle anyway
+//   2  pqp_solve_kernel<256, 3, 0>
 //   3  pqp_solve_kernel<512, ., .>
 //   4  pqp_solve_kernel<1024, ., .>
 //   5  pqp_backward_kernel<.>
 //   6  pqp_setup_kernel<.>, pqp_order_kernel, the dispatchers
-#include "pqp_host.hpp"
-
 #ifndef PQP_TU
 #define PQP_TU 0
 #endif
+// 8 instead of 16 matrix loads in flight per lane in gemv for the 128-VGPR kernel (pqp_block.hpp)
+#if PQP_TU == 1 && !defined(PQP_GEMV_DEEP_256)
+#define PQP_GEMV_DEEP_256 0
+#endif
+#include "pqp_host.hpp"
+
 #define PQP_TU_HAS(k) (PQP_TU == 0 || PQP_TU == (k))
 
 // Waves per SIMD the register allocator must leave room for (512 / WPS VGPRs per lane): the
 // knob that trades spills against resident workgroups per CU.  Compile-time only.
+#ifndef PQP_WPS_256_DENSE
+#define PQP_WPS_256_DENSE 4 // throughput variant of the C2 kernel (LDS: 4 x 40.9 KB fits the CU's 160 KB)
+#endif
 #ifndef PQP_WPS_256
 #define PQP_WPS_256 3
 #endif
@@ -56,6 +66,7 @@ launch_solve(pqp_batch* h)
 
 // SPEC = 1: no box constraints and a dense Hessian, both known at compile time
 int pqp_launch_solve_256_s1(pqp_batch* h);
+int pqp_launch_solve_256_s1_lat(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
@@ -63,6 +74,13 @@ int pqp_launch_solve_1024(pqp_batch* h, bool common);
 #if PQP_TU_HAS(1)
 int
 pqp_launch_solve_256_s1(pqp_batch* h)
+{
+  return launch_solve<256, PQP_WPS_256_DENSE, 1>(h);
+}
+#endif
+#if PQP_TU_HAS(7)
+int
+pqp_launch_solve_256_s1_lat(pqp_batch* h)
 {
   return launch_solve<256, PQP_WPS_256, 1>(h);
 }
@@ -252,7 +270,12 @@ pqp_launch_solve(pqp_batch* h)
                       h->dev.d.backend != PQP_BACKEND_PRIMAL_LDLT;
   switch (h->nt) {
     case 256:
-      return common ? pqp_launch_solve_256_s1(h) : pqp_launch_solve_256_s0(h);
+      if (!common)
+        return pqp_launch_solve_256_s0(h);
+      // more workgroups than three per CU can hold at once: the four-per-CU build; otherwise the
+      // launch is latency-bound and the build with the larger register budget is faster per QP
+      return (h->range_count > 3L * h->n_cu && 4 * h->lds_solve <= 160 * 1024) ? pqp_launch_solve_256_s1(h)
+                                                                                : pqp_launch_solve_256_s1_lat(h);
     case 512:
       return pqp_launch_solve_512(h, common);
     default:
