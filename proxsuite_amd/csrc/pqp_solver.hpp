@@ -1546,11 +1546,8 @@ struct Solver
       return;
     }
     bool done = false;
-#ifndef PQP_SCHUR_MB_S
-#define PQP_SCHUR_MB_S SCHUR_MB
-#endif
 #ifndef PQP_SCHUR_REG_ROWS
-#define PQP_SCHUR_REG_ROWS (16 * PQP_SCHUR_MB_S)
+#define PQP_SCHUR_REG_ROWS (16 * SCHUR_MB)
 #endif
     if constexpr (NT == 256 && PQP_SCHUR_REG_ROWS > 0) {
       if (rr > 0 && rr <= PQP_SCHUR_REG_ROWS) {
@@ -1570,7 +1567,7 @@ struct Solver
             return live ? v + ((i < ne) ? mu_eq : mu_in) : 1.0;
           return live ? v : 0.0;
         };
-        ldlt_inverse_reg<NT, PQP_SCHUR_MB_S>(load, P.WS(), nd, rr, L.dS(), L.top());
+        ldlt_inverse_reg<NT, SCHUR_MB>(load, P.WS(), nd, rr, L.dS(), L.top());
         bytes((long)rr * (rr + 1) * 8); // gather of the lower triangle + the lower triangle of W written
         toc(ST_CYC_S_GATHER);
         done = true;
