@@ -1,12 +1,13 @@
 // The kernels of libproxqp_hip.so and their launchers.  Compiled once per kernel family
-// (-DPQP_TU=1..7, objects built in parallel by proxsuite_amd/_build.py); PQP_TU undefined or 0
+// (-DPQP_TU=1..8, objects built in parallel by proxsuite_amd/_build.py); PQP_TU undefined or 0
 // compiles everything in one translation unit (the CPU emulator build of tests/emu does that).
 //   1  pqp_solve_kernel<256, 4, 1>    no box constraints, dense Hessian (the C2 kernel): 128 VGPRs per
 //                                     lane, FOUR workgroups per CU -- launches that fill the device
 //   7  pqp_solve_kernel<256, 3, 1>    the same solve with 168 VGPRs per lane, three workgroups per CU:
 //                                     lower latency per QP, used when the launch leaves CUs idle anyway
 //   2  pqp_solve_kernel<256, 3, 0>
-//   3  pqp_solve_kernel<512, ., .>
+//   3  pqp_solve_kernel<512, 2, .>    256 VGPRs, one workgroup per CU
+//   8  pqp_solve_kernel<512, 4, .>    128 VGPRs, two workgroups per CU: launches of more workgroups than CUs
 //   4  pqp_solve_kernel<1024, ., .>
 //   5  pqp_backward_kernel<.>
 //   6  pqp_setup_kernel<.>, pqp_order_kernel, the dispatchers
@@ -31,6 +32,9 @@
 #endif
 #ifndef PQP_WPS_512
 #define PQP_WPS_512 2
+#endif
+#ifndef PQP_WPS_512_DENSE
+#define PQP_WPS_512_DENSE 4
 #endif
 #ifndef PQP_WPS_1024
 #define PQP_WPS_1024 4
@@ -69,6 +73,7 @@ int pqp_launch_solve_256_s1(pqp_batch* h);
 int pqp_launch_solve_256_s1_lat(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
+int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
 
 #if PQP_TU_HAS(1)
@@ -97,6 +102,13 @@ int
 pqp_launch_solve_512(pqp_batch* h, bool common)
 {
   return common ? launch_solve<512, PQP_WPS_512, 1>(h) : launch_solve<512, PQP_WPS_512, 0>(h);
+}
+#endif
+#if PQP_TU_HAS(8)
+int
+pqp_launch_solve_512_dense(pqp_batch* h, bool common)
+{
+  return common ? launch_solve<512, PQP_WPS_512_DENSE, 1>(h) : launch_solve<512, PQP_WPS_512_DENSE, 0>(h);
 }
 #endif
 #if PQP_TU_HAS(4)
@@ -277,7 +289,9 @@ pqp_launch_solve(pqp_batch* h)
       return (h->range_count > 3L * h->n_cu && 4 * h->lds_solve <= 160 * 1024) ? pqp_launch_solve_256_s1(h)
                                                                                 : pqp_launch_solve_256_s1_lat(h);
     case 512:
-      return pqp_launch_solve_512(h, common);
+      // (same rule as for 256 threads: the smaller register budget only when it buys a second resident workgroup)
+      return (h->range_count > (long)h->n_cu && 2 * h->lds_solve <= 160 * 1024) ? pqp_launch_solve_512_dense(h, common)
+                                                                               : pqp_launch_solve_512(h, common);
     default:
       return pqp_launch_solve_1024(h, common);
   }
