@@ -366,6 +366,30 @@ def case_determinism(lib, randqp, n=20, ne=5, ni=8, B=6):
     assert np.array_equal(out[0], out[1])
 
 
+def case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk, box=False, dense_backend=0):
+    """A QP's result must not depend on how many QPs share its launch: device-filling launches take
+    the 128-VGPR builds of the solve kernels (four / two workgroups per CU), small ones the builds with
+    the larger register budget (csrc/pqp_kernels.hip) -- same arithmetic in the same order, so the
+    results are compared bit for bit."""
+    m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2)
+    kw = {}
+    if box:
+        rng = np.random.default_rng(3)
+        kw = dict(l_box=-1.0 - rng.random((B, n)), u_box=1.0 + rng.random((B, n)))
+    out = []
+    for step in (B, chunk):
+        b = N.Batch(B, n, ne, ni, box_constraints=box, dense_backend=dense_backend, lib=lib)
+        settings_all(b, eps_abs=EPS, eps_rel=0)
+        b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u, **kw)
+        for first in range(0, B, step):
+            b.solve(first, min(step, B - first))
+        out.append([a.copy() for a in b.results()[:3]] + [np.array([i.status for i in b.infos()])])
+        b.close()
+    for a, c in zip(out[0], out[1]):
+        assert np.array_equal(a, c)
+    return out[0]
+
+
 def case_backward(lib, oracle, randqp, n=10, ne=4, ni=7, B=6, with_dual_terms=True):
     """QPLayer backward (reference dense/compute_ECJ.hpp:29-189; test/src/dense_backward.cpp): the
     seven loss jacobians of a solved batch against the oracle's literal restatement, with loss

@@ -39,6 +39,14 @@ def test_random_batch(lib, oracle, randqp, shape):
     pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=8 if n < 100 else 4)
 
 
+@pytest.mark.parametrize("shape", [(30, 7, 9, 8, 2), (40, 5, 300, 3, 1)])
+def test_launch_size_invariance(lib, randqp, shape):
+    """the launcher's choice between the two register-budget builds of a solve kernel (by launch
+    size; the emulated device has one CU) must not change a result"""
+    n, ne, ni, B, chunk = shape
+    pc.case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk)
+
+
 @pytest.mark.parametrize("shape", [(120, 100, 100), (40, 5, 300), (130, 10, 20)])
 def test_matrix_core_fallback_paths(lib, oracle, randqp, shape):
     """shapes that leave the register-resident factorisations: a dual Schur block above 112 rows

@@ -91,6 +91,16 @@ def test_determinism(lib, randqp):
     pc.case_determinism(lib, randqp, 100, 50, 100, B=64)
 
 
+@pytest.mark.parametrize("shape", [(100, 50, 100, 1024, 256, False), (40, 5, 300, 320, 64, False),
+                                   (100, 200, 200, 320, 64, True)])
+def test_launch_size_invariance(lib, randqp, shape):
+    """1024 QPs in one launch (four workgroups per CU, pqp_solve_kernel<256,4,1>) against the same QPs in
+    launches of 256 (<256,3,1>); 320 QPs of two 512-thread shapes in one launch (<512,4,.>) against
+    launches of 64 (<512,2,.>), the boxed one on the PrimalLDLT engine: bit-identical."""
+    n, ne, ni, B, chunk, box = shape
+    pc.case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk, box=box)
+
+
 def test_full_size_c2_all_against_oracle(lib, oracle, randqp):
     """BASELINE.json configs[1]: 2048 random dense QPs, n=100 n_eq=50 n_in=100.  Every QP must
     reach SOLVED with unscaled KKT residuals <= 1e-9 (numpy), and EVERY solution is compared with
