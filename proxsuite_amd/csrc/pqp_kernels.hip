@@ -18,6 +18,11 @@
 #if PQP_TU == 1 && !defined(PQP_GEMV_DEEP_256)
 #define PQP_GEMV_DEEP_256 0
 #endif
+// the translation units whose kernels run at 128 VGPRs per lane keep 4 instead of 8 MFMA k-steps of
+// operand loads in flight in the Z / G build (+2 % at C2 and C4, profiles/r02_ab_compiler_flags.txt)
+#if (PQP_TU == 1 || PQP_TU == 4 || PQP_TU == 8) && !defined(PQP_ZG_DEPTH)
+#define PQP_ZG_DEPTH 4
+#endif
 #include "pqp_host.hpp"
 
 #define PQP_TU_HAS(k) (PQP_TU == 0 || PQP_TU == (k))

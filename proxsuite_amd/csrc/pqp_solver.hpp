@@ -34,7 +34,10 @@ namespace pqp {
 #define PQP_LIKELY(x) __builtin_expect(!!(x), 1)
 
 constexpr double MACHINE_EPS = 2.220446049250313e-16;
-constexpr int ZG_DEPTH = 8; // MFMA k-steps (of 4) whose operand loads are in flight together in build_ZG
+#ifndef PQP_ZG_DEPTH
+#define PQP_ZG_DEPTH 8
+#endif
+constexpr int ZG_DEPTH = PQP_ZG_DEPTH; // MFMA k-steps (of 4) whose operand loads are in flight together in build_ZG
 constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * SCHUR_MB rows
 // `top`: LDS scratch of the factorisation routines (ldlt_factor_mfma: 2 * 256 + 32 doubles;
 // ldlt_factor_reg: 4 * 16 * MB; ldlt_inverse_reg: 6 * 16 * MB)
