@@ -32,15 +32,6 @@
 #define PQP_CALL __forceinline__
 #endif
 
-#ifndef PQP_STREAM_LOADS
-#define PQP_STREAM_LOADS 0
-#endif
-#if PQP_STREAM_LOADS && !defined(PQP_EMULATED_MFMA)
-#define PQP_LDG(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define PQP_LDG(ptr) (*(ptr))
-#endif
-
 namespace pqp {
 
 typedef PQP_LDS double* lptr;
@@ -516,7 +507,7 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
             double m[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-              m[u] = PQP_LDG(p + u * step);
+              m[u] = p[u * step];
 #pragma unroll
             for (int u = 0; u < 16; u += 4) {
               a0 = fma(m[u], v[k + u * KS], a0);
@@ -625,11 +616,7 @@ load_pair(cgptr p)
 {
 #ifndef PQP_EMULATED_MFMA
   typedef double pqp_d2 __attribute__((ext_vector_type(2)));
-#if PQP_STREAM_LOADS
-  const pqp_d2 t = __builtin_nontemporal_load(reinterpret_cast<const PQP_GLOBAL pqp_d2*>(p));
-#else
   const pqp_d2 t = *reinterpret_cast<const PQP_GLOBAL pqp_d2*>(p);
-#endif
   return Pair{ t.x, t.y };
 #else
   return Pair{ p[0], p[1] };
@@ -698,7 +685,7 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
               m[u][c][0] = t.x;
               m[u][c][W - 1] = t.y;
             } else {
-              m[u][c][0] = PQP_LDG(row + off[c]);
+              m[u][c][0] = row[off[c]];
             }
           } else {
 #pragma unroll
