@@ -66,8 +66,14 @@ def hip_headers():
 
 # Register allocation of the one-kernel solver is the lever: sinking
 # instructions into the loops that use them and NOT hoisting loop invariants out of them cuts the
-# VGPR spills of the C2 kernel from 517 to 163 (+9 % QPs/s, profiles/r02_ab_compiler_flags.txt).
+# VGPR spills of the C2 kernel from 517 to 163 (+9 % QPs/s, profiles/r02_ab_compiler_flags.txt); without
+# loop strength reduction the mat-vec loops recompute their addresses from one index instead of
+# carrying a pointer per load in flight (128-VGPR kernel: 319 -> 206 spilled VGPRs, +4.5 % QPs/s).
 CODEGEN_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-machine-licm"]
+# per translation unit (kernel family, csrc/pqp_kernels.hip): measured on the workload each one serves --
+# C2 +4.3 %, C1 +3.4 %, C4 +2 % with -disable-lsr; the structured / boxed 256-thread kernel (C5: -17 %) and the
+# 512-thread kernels (dense-backend shape: -7 %) keep loop strength reduction
+TU_FLAGS = {1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-mllvm", "-disable-lsr"]}
 
 
 def hip_flags(extra_flags=()):
@@ -93,7 +99,8 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
     jobs = [([hipcc, *flags, "-c", str(CSRC / "pqp_capi.hip"), "-o", str(odir / "capi.o")], odir / "capi.o")]
     for k in tus:
         o = odir / ("kernels_%d.o" % k)
-        jobs.append(([hipcc, *flags, "-DPQP_TU=%d" % k, "-c", str(CSRC / "pqp_kernels.hip"), "-o", str(o)], o))
+        jobs.append(([hipcc, *flags, *TU_FLAGS.get(k, []), "-DPQP_TU=%d" % k, "-c", str(CSRC / "pqp_kernels.hip"),
+                      "-o", str(o)], o))
     todo = [j for j in jobs if force or extra_flags or not _newer(j[1], deps)]
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
         list(ex.map(lambda j: _run(j[0]), todo))
@@ -127,7 +134,8 @@ def build_hip_variants(force: bool = False):
         lib = VARIANT_DIR / ("libproxqp_hip_wps512_%d.so" % w)
         if force or not _newer(lib, deps):
             o3 = base / ("kernels_3_wps%d.o" % w)
-            _run([hipcc, *hip_flags(("-DPQP_WPS_512=%d" % w,)), "-DPQP_TU=3", "-c", str(CSRC / "pqp_kernels.hip"),
+            _run([hipcc, *hip_flags(("-DPQP_WPS_512=%d" % w,)), *TU_FLAGS.get(3, []), "-DPQP_TU=3", "-c",
+                  str(CSRC / "pqp_kernels.hip"),
                   "-o", str(o3)])
             objs = [base / "capi.o"] + [o3 if k == 3 else base / ("kernels_%d.o" % k) for k in KERNEL_TUS]
             _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)])
