@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 
 namespace pqo {
 
@@ -236,7 +237,10 @@ ruiz_scale_qp_in_place(QP& qp, double epsilon, isize max_iter)
           mean += colH[size_t(k)];
         mean /= double(n);
         gamma = 1 / std::max(1.0, mean);
-        break; // NB: gamma is not applied to a Dense H (ruiz.hpp:256-287)
+        // NB: gamma is NOT applied to a Dense H by the reference (ruiz.hpp:256-287 computes it and breaks;
+        // only the Diagonal case has `H *= gamma`, :301), although g (:304) and c (:307) take it and the
+        // non-executing path multiplies H by c (:505).  Restated as written.
+        break;
       }
       case PQP_HESSIAN_DIAGONAL: {
         double mx = 0;
@@ -1206,6 +1210,9 @@ global_primal_residual_infeasibility(QP& qp, double* ATdy, double* CTdz, double*
   for (isize k = 0; k < n; ++k)
     lower_bound_2 = std::max(lower_bound_2, std::fabs(ATdy[k] + CTdz[k]));
   res = lower_bound_2 <= upper_bound && lower_bound_1 <= -upper_bound;
+  if (std::getenv("PQO_TRACE_CERT"))
+    std::fprintf(stderr, "[oracle]   primal-inf cert: lb2 %.4e <= ub %.4e ? lb1 %.4e <= %.4e ? -> %d\n", lower_bound_2,
+                 upper_bound, lower_bound_1, -upper_bound, int(res));
   return res;
 }
 
@@ -1671,6 +1678,7 @@ qp_solve(QP& qp)
   double duality_gap = 0, rhs_duality_gap = 0;
   double scaled_eps = s.eps_abs;
 
+  static const bool trace = std::getenv("PQO_TRACE") != nullptr; // debugging aid of the test infrastructure
   for (std::int64_t iter = 0; iter < s.max_iter; ++iter) {
     global_primal_residual(qp, primal_feasibility_lhs, primal_feasibility_eq_rhs_0,
                            primal_feasibility_in_rhs_0, primal_feasibility_eq_lhs,
@@ -1696,6 +1704,25 @@ qp_solve(QP& qp)
                                       std::max(dual_feasibility_rhs_1, w.dual_feasibility_rhs_2));
     bool is_dual_feasible = dual_feasibility_lhs <= rhs_dua;
 
+    // solver.hpp:1469-1510 — `verbose` is not only printing: the reference unscales x, y, z, evaluates the
+    // objective, prints, and scales them back.  unscale followed by scale is the identity only up to
+    // rounding, so a verbose run perturbs the iterates in their last bits at every outer iteration
+    // (test/src/dense_qp_wrapper.cpp:7178 runs its closest-feasible family with verbose = true).
+    if (s.verbose) {
+      sc.unscale_primal(r.x.data());
+      sc.unscale_dual_eq(r.y.data());
+      sc.unscale_dual_in(r.z.data());
+      if (qp.box_constraints)
+        sc.unscale_box_dual_in(r.z.data() + n_in);
+      r.info.objValue = objective_value(qp);
+      if (qp.verbose_sink)
+        qp.verbose_sink(iter + 1, r.info);
+      sc.scale_primal(r.x.data());
+      sc.scale_dual_eq(r.y.data());
+      sc.scale_dual_in(r.z.data());
+      if (qp.box_constraints)
+        sc.scale_box_dual_in(r.z.data() + n_in);
+    }
     if (is_primal_feasible && is_dual_feasible) {
       if (s.check_duality_gap) {
         if (std::fabs(r.info.duality_gap) <= s.eps_duality_gap_abs + s.eps_duality_gap_rel * rhs_duality_gap) {
@@ -1814,6 +1841,10 @@ qp_solve(QP& qp)
       new_bcl_mu_in_inv = s.cold_reset_mu_in_inv;
       new_bcl_mu_eq_inv = s.cold_reset_mu_eq_inv;
     }
+    if (trace)
+      std::fprintf(stderr, "[oracle] ext %lld status %d iter %lld n_c %lld mu_in %.3e->%.3e pri %.6e->%.6e dua %.6e->%.6e scaled_eps %.3e eta_ext %.3e eta_in %.3e\n",
+                   (long long)iter, int(r.info.status), (long long)r.info.iter, (long long)w.n_c, r.info.mu_in, new_bcl_mu_in,
+                   primal_feasibility_lhs, primal_feasibility_lhs_new, dual_feasibility_lhs, dual_feasibility_lhs_new, scaled_eps, bcl_eta_ext, bcl_eta_in);
     if (r.info.mu_in != new_bcl_mu_in || r.info.mu_eq != new_bcl_mu_eq) {
       ++r.info.mu_updates;
       mu_update(qp, new_bcl_mu_eq, new_bcl_mu_in);

@@ -122,6 +122,10 @@ struct QP
   isize n_solves = 0, n_residuals = 0, n_ls_evals = 0, n_inserted = 0, n_deleted = 0,
         n_refactorize = 0;
 
+  // settings.verbose: called once per outer iteration with the unscaled-iterate statistics the reference
+  // prints (solver.hpp:1469-1499); null = the round trip of the iterates happens, nothing is printed
+  void (*verbose_sink)(long long outer_iteration, const pqp_info& info) = nullptr;
+
   QP(isize dim, isize n_eq, isize n_in, bool box, int hessian, int backend);
 
   // wrapper.hpp:354-498 / 520-703.  Null pointer == nullopt; NaN == nullopt.
