@@ -3074,9 +3074,17 @@ struct Solver
     vload(L.x(), P.x(), n);
     vload(L.y(), P.y(), ne);
     vload(L.z(), P.z(), nc);
-    for (int i = threadIdx.x; i < nc; i += NT) {
-      L.aflags()[i] = 0;
-      L.slot_of()[i] = -1;
+    {
+      // active_set_up / active_set_low live as long as the QP object in the reference: neither
+      // Workspace::cleanup (workspace.hpp:330-377) nor init / update touch them, so the duality-gap
+      // terms of the first residual evaluation (utils.hpp:545-559) see the flags the LAST Newton step of
+      // the previous solve (or compute_backward) left.  They are parked in the high bits of the
+      // persistent slot list (bits 16-17 of act[i]; zero for a new object).
+      const PQP_GLOBAL int* ga = P.act();
+      for (int i = threadIdx.x; i < nc; i += NT) {
+        L.aflags()[i] = (ga[i] >> 16) & 3;
+        L.slot_of()[i] = -1;
+      }
     }
     __syncthreads();
 
@@ -3184,7 +3192,7 @@ struct Solver
       {
         const PQP_GLOBAL int* ga = P.act();
         for (int j = threadIdx.x; j < n_slots; j += NT) {
-          const int i = ga[j];
+          const int i = (ga[j] & 0xffff) - 1;
           L.act()[j] = (i >= 0) ? i : 0; // a hole keeps a valid row index; no slot_of points at it
           if (i >= 0)
             L.slot_of()[i] = j;
@@ -3197,7 +3205,7 @@ struct Solver
     if (do_aset_from_z || do_eq_guess) {
       if (do_aset_from_z) {
         for (int i = threadIdx.x; i < nc; i += NT)
-          L.aflags()[i] = (L.z()[i] != 0) ? 4 : 0;
+          L.aflags()[i] = (L.aflags()[i] & 3) | ((L.z()[i] != 0) ? 4 : 0); // only active_inequalities is rewritten (solver.hpp:1231-1238)
       }
       linear_step(do_eq_guess ? 1 : 2, 1.0);
     }
@@ -3524,11 +3532,11 @@ struct Solver
     if (pm())
       vstore(P.dF(), L.dF(), n); // D of P_J, beside its inverse factor in the WL buffer
     {
-      // the slots of the Schur factor kept for WARM_START_WITH_PREVIOUS_RESULT: constraint id of a
-      // live slot, -1 for a hole
+      // the slots of the Schur factor kept for WARM_START_WITH_PREVIOUS_RESULT: 1 + constraint id of a
+      // live slot, 0 for a hole (low 16 bits); the persistent up / low flags of constraint i in bits 16-17
       PQP_GLOBAL int* ga = P.act();
       for (int i = threadIdx.x; i < nc; i += NT)
-        ga[i] = (i < n_slots && slot_live(ne + i)) ? L.act()[i] : -1;
+        ga[i] = (((i < n_slots && slot_live(ne + i)) ? L.act()[i] : -1) + 1) | ((L.aflags()[i] & 3) << 16);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -3689,6 +3697,13 @@ struct Solver
         ou[i] = (L.aflags()[i] & 1) ? -dzu[i] : 0.0;
         ol[i] = (L.aflags()[i] & 2) ? -dzu[i] : 0.0;
       }
+    }
+    {
+      // compute_backward rewrites work.active_set_up / active_set_low (compute_ECJ.hpp:48-57); the next
+      // forward solve starts from them (see solve())
+      PQP_GLOBAL int* ga = P.act();
+      for (int i = threadIdx.x; i < ni; i += NT)
+        ga[i] = (ga[i] & 0xffff) | ((L.aflags()[i] & 3) << 16);
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -1,19 +1,25 @@
-"""Generates tests/golden/maros_meszaros_small.npz from the reference's own fixtures
+"""Generates the Maros-Meszaros fixtures from the reference's own data files
 (/root/reference/test/data/maros_meszaros_data/*.mat, loaded as in
 test/include/maros_meszaros.hpp:121-140: keys P,q,A,l,u; equality rows are l==u).
 
-Only the small problems (n <= 150, rows <= 320) are kept so the fixture stays a few
-hundred KB; tests/test_oracle_maros_meszaros.py additionally runs the full n<=1000 set
-when /root/reference is present.  Run:  python tests/golden/make_maros_meszaros_fixtures.py
+The reference test (test/src/dense_maros_meszaros.cpp:97) runs every problem with n <= 1000 and
+n_eq + n_in <= 1000: 62 problems.  They are committed in two files so that the GPU box, which has no
+/root/reference, runs all of them:
+  maros_meszaros_small.npz   n <= 150 and rows <= 320 (33 problems), dense arrays "<name>/<P|q|A|l|u>"
+  maros_meszaros_medium.npz  the other 29, P and A as COO triplets "<name>/<P|A>_<row|col|val|shape>"
+Run:  python tests/golden/make_maros_meszaros_fixtures.py
 """
 import glob
 import os
 
 import numpy as np
 import scipy.io as sio
+import scipy.sparse as sp
 
 SRC = "/root/reference/test/data/maros_meszaros_data"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "maros_meszaros_small.npz")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "maros_meszaros_small.npz")
+OUT_MEDIUM = os.path.join(HERE, "maros_meszaros_medium.npz")
 
 
 def load(path):
@@ -26,23 +32,59 @@ def load(path):
     return P, q, A, l, u
 
 
-def main():
+def load_medium(path=OUT_MEDIUM, only=None):
+    """-> {name: (P, q, A, l, u)} with dense P and A rebuilt from the triplets"""
+    d = np.load(path)
     out = {}
-    names = []
+    for name in [str(s) for s in d["names"]]:
+        if only is not None and name != only:
+            continue
+        mats = []
+        for k in "PA":
+            shape = tuple(int(v) for v in d["%s/%s_shape" % (name, k)])
+            m = np.zeros(shape)
+            m[d["%s/%s_row" % (name, k)], d["%s/%s_col" % (name, k)]] = d["%s/%s_val" % (name, k)]
+            mats.append(m)
+        out[name] = (mats[0], d[name + "/q"], mats[1], d[name + "/l"], d[name + "/u"])
+    return out
+
+
+def main():
+    small, medium = {}, {}
+    names_small, names_medium = [], []
     for f in sorted(glob.glob(os.path.join(SRC, "*.mat"))):
         r = load(f)
         if r is None:
             continue
         P, q, A, l, u = r
-        if P.shape[0] > 150 or A.shape[0] > 320:
-            continue
         name = os.path.basename(f)[:-4]
-        names.append(name)
-        for k, v in zip("PqAlu", (P, q, A, l, u)):
-            out["%s/%s" % (name, k)] = v
-    out["names"] = np.array(names)
-    np.savez_compressed(OUT, **out)
-    print("wrote", OUT, len(names), "problems", os.path.getsize(OUT), "bytes")
+        if P.shape[0] <= 150 and A.shape[0] <= 320:
+            names_small.append(name)
+            for k, v in zip("PqAlu", (P, q, A, l, u)):
+                small["%s/%s" % (name, k)] = v
+        else:
+            names_medium.append(name)
+            for k, m in (("P", P), ("A", A)):
+                c = sp.coo_matrix(m)
+                medium["%s/%s_row" % (name, k)] = c.row.astype(np.int32)
+                medium["%s/%s_col" % (name, k)] = c.col.astype(np.int32)
+                medium["%s/%s_val" % (name, k)] = c.data
+                medium["%s/%s_shape" % (name, k)] = np.array(m.shape, dtype=np.int64)
+            for k, v in zip("qlu", (q, l, u)):
+                medium["%s/%s" % (name, k)] = v
+    small["names"] = np.array(names_small)
+    medium["names"] = np.array(names_medium)
+    np.savez_compressed(OUT, **small)
+    np.savez_compressed(OUT_MEDIUM, **medium)
+    print("wrote", OUT, len(names_small), "problems", os.path.getsize(OUT), "bytes")
+    print("wrote", OUT_MEDIUM, len(names_medium), "problems", os.path.getsize(OUT_MEDIUM), "bytes")
+    rt = load_medium()
+    for f in sorted(glob.glob(os.path.join(SRC, "*.mat"))):
+        name = os.path.basename(f)[:-4]
+        if name in rt:
+            P, q, A, l, u = load(f)
+            assert np.array_equal(P, rt[name][0]) and np.array_equal(A, rt[name][2]) and np.array_equal(u, rt[name][4])
+    print("round trip ok:", [(n, rt[n][0].shape[0], rt[n][2].shape[0]) for n in names_medium])
 
 
 if __name__ == "__main__":

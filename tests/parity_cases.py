@@ -4,8 +4,11 @@ include/proxqp_hip.h and compares with the CPU oracle on the same seeded inputs.
 
 Tolerances: unscaled KKT residuals <= eps_abs = 1e-9 is the hard gate (the
 reference's own acceptance test, test/src/dense_qp_with_eq_and_in.cpp:46-56); (x, y, z) must
-agree with the oracle to 1e-7 * (1 + |ref|_inf) -- iteration paths may differ in rounding
-(hard part 4) so traces are not compared, solutions are.
+agree with the oracle to XYZ_TOL * (1 + |ref|_inf) = 1e-10 (observed: 1e-13 on random QPs); the
+counters of Results::info (iter, iter_ext, mu_updates, rho_updates, status) must be EQUAL and
+objValue / pri_res / dua_res / mu / rho close (INFO_*): the device runs the reference's iteration,
+only its linear algebra engine differs, so the iterates follow the oracle's to rounding.  Cases on
+ill-conditioned data (Maros-Meszaros, degenerate families) state their own, looser, numbers.
 """
 import numpy as np
 
@@ -13,7 +16,9 @@ from proxsuite_amd import _native as N
 from proxsuite_amd._ctypes_defs import HessianType, InitialGuess, QPSolverOutput
 
 EPS = 1e-9
-XYZ_TOL = 1e-7
+XYZ_TOL = 1e-10
+INFO_REL = 1e-9   # objValue, mu_eq, mu_in, rho: relative
+INFO_RES = 1e-11  # pri_res, dua_res, duality_gap: absolute, plus 1e-6 relative (they are differences at the rounding floor)
 
 
 def kkt_numpy(H, g, A, b, Cm, l, u, x, y, z, l_box=None, u_box=None):
@@ -42,10 +47,32 @@ def kkt(oracle, m, i, x, y, z, l_box=None, u_box=None):
                      x, y, z, l_box, u_box)
 
 
-def close(a, ref):
+def close(a, ref, tol=None):
     if ref.size == 0:
         return True
-    return float(np.max(np.abs(a - ref))) <= XYZ_TOL * (1 + float(np.max(np.abs(ref))))
+    return float(np.max(np.abs(a - ref))) <= (XYZ_TOL if tol is None else tol) * (1 + float(np.max(np.abs(ref))))
+
+
+def info_close(dev, ref, counters=True, residuals=True):
+    """Results::info of the device against the oracle's (reference results.hpp:28-76): the integer
+    counters and the status are equal, the proximal parameters and the objective agree to INFO_REL, the
+    residual norms to INFO_RES.  Returns a description of the first mismatch, or None."""
+    if dev.status != ref.status:
+        return "status %d != %d" % (dev.status, ref.status)
+    if counters:
+        for k in ("iter", "iter_ext", "mu_updates", "rho_updates"):
+            if getattr(dev, k) != getattr(ref, k):
+                return "%s %d != %d" % (k, getattr(dev, k), getattr(ref, k))
+    for k in ("mu_eq", "mu_in", "rho", "objValue"):
+        a, r = getattr(dev, k), getattr(ref, k)
+        if abs(a - r) > INFO_REL * (1 + abs(r)):
+            return "%s %.17g != %.17g" % (k, a, r)
+    if residuals:
+        for k in ("pri_res", "dua_res", "duality_gap"):
+            a, r = getattr(dev, k), getattr(ref, k)
+            if abs(a - r) > INFO_RES + 1e-6 * abs(r):
+                return "%s %.6e != %.6e" % (k, a, r)
+    return None
 
 
 def settings_all(b, **kw):
@@ -79,14 +106,15 @@ def case_random_batch(lib, oracle, randqp, n, ne, ni, B, guess=InitialGuess.NO_I
         pri, dua = kkt(oracle, m, i, x[i], y[i], z[i])
         assert pri <= EPS and dua <= EPS, (i, pri, dua)
     if compare:
-        # compare == True: the first 16 QPs; compare == "all": every QP of the batch, the oracle
-        # running under its solve_in_parallel (reference parallel/qp_solve.hpp:17-39)
-        idx = range(B) if compare == "all" else range(min(B, 16))
+        # EVERY QP of the batch, the oracle running under its solve_in_parallel (reference
+        # parallel/qp_solve.hpp:17-39); an integer `compare` limits the comparison to the first ones
+        idx = range(B) if compare is True or compare == "all" else range(min(B, int(compare)))
         qs = oracle_solve_many(oracle, [(m.H[i], m.g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i]) for i in idx],
                                n, ne, ni, guess)
         for i, q in zip(idx, qs):
             assert close(x[i], q.results.x) and close(y[i], q.results.y) and close(z[i], q.results.z), i
-            assert info[i].status == q.results.info.status, i
+            bad = info_close(info[i], q.results.info)
+            assert bad is None, (i, bad)
     b.close()
     return x, y, z, info
 
@@ -153,7 +181,8 @@ def case_state_machine(lib, oracle, randqp, guess):
             assert pri <= EPS and dua <= EPS, (i, pri, dua)
             r = qs[i].results
             assert close(x[i], r.x) and close(y[i], r.y) and close(z[i], r.z), i
-            assert info[i].status == r.info.status
+            bad = info_close(info[i], r.info)
+            assert bad is None, (i, bad)
 
     b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
     for i, q in enumerate(qs):
@@ -257,7 +286,9 @@ def case_box_constraints(lib, oracle, randqp, seeds=20, hessian=HessianType.Dens
         q.settings.eps_rel = 0
         q.init(H[s], g[s], A[s], bb[s], Cm[s], l[s], u[s], lb[s], ub[s])
         q.solve()
-        assert close(x[s], q.results.x) and close(z[s], q.results.z), s
+        assert close(x[s], q.results.x) and close(y[s], q.results.y) and close(z[s], q.results.z), s
+        bad = info_close(info[s], q.results.info)
+        assert bad is None, (s, bad)
     b.close()
 
 
@@ -273,6 +304,16 @@ def case_families(lib, oracle, randqp, dim):
         x, y, z, se, si, info = b.results(0)
         pri, dua = kkt_numpy(m.H, m.g, m.A, m.b, m.C, m.l, m.u, x, y, z)
         assert pri <= EPS and dua <= EPS, (pri, dua, info.status)
+        # against the oracle: x and the Info counters (the multipliers of the degenerate / not strongly
+        # convex families are not unique in exact arithmetic, but the iteration is the same one)
+        q = oracle.QP(n, ne, ni, hessian_type=hessian)
+        q.settings.eps_abs, q.settings.eps_rel = EPS, 0
+        q.init(m.H, m.g, m.A if ne else None, m.b if ne else None, m.C if ni else None,
+               m.l if ni else None, m.u if ni else None)
+        q.solve()
+        assert close(x, q.results.x, 1e-8), np.max(np.abs(x - q.results.x))
+        bad = info_close(info, q.results.info)
+        assert bad is None, bad
         b.close()
 
     randqp.set_seed(1)
@@ -465,11 +506,11 @@ def case_c5(lib, oracle, randqp, B, sample, box, dim=200):
     hess = HessianType.Diagonal
     if box:
         b = N.Batch(B, dim, 0, 0, box_constraints=True, hessian_type=int(hess), lib=lib)
-        settings_all(b, eps_abs=EPS, eps_rel=0)
+        settings_all(b, eps_abs=EPS, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS))
         b.init(-1, H, g, None, None, None, None, None, l, u)
     else:
         b = N.Batch(B, dim, 0, dim, hessian_type=int(hess), lib=lib)
-        settings_all(b, eps_abs=EPS, eps_rel=0)
+        settings_all(b, eps_abs=EPS, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS))
         b.init(-1, H, g, None, None, Cm, l, u)
     b.solve()
     x, y, z, se, si, info = b.results()
@@ -490,7 +531,8 @@ def case_c5(lib, oracle, randqp, B, sample, box, dim=200):
                                dim, 0, dim, hessian_type=hess)
     for i, q in zip(idx, qs):
         assert close(x[i], q.results.x) and close(z[i], q.results.z), i
-        assert info[i].status == q.results.info.status, i
+        bad = info_close(info[i], q.results.info)
+        assert bad is None, (i, bad)
     b.close()
     return x, z
 
@@ -612,14 +654,11 @@ def case_closest_feasible(lib, oracle, randqp, seeds, max_oracle_iter_ext=None):
                 # hangs on residuals at the rounding floor.  Same point, either label: x is compared.
                 assert close(x[j], r.x), (pis, i)
                 continue
-            if pis and r.info.status == QPSolverOutput.PROXQP_MAX_ITER_REACHED:
-                # (seed 14, see tests/test_oracle_known_answers.py: a feasible instance on which the restated
-                # algorithm cycles through cold restarts; a cycle of that kind is chaotic in the last bits,
-                # and the device -- different summation order -- may leave it.  If it does, its answer
-                # must pass the reference test's acceptance lines, checked below.)
-                assert info[j].status in done + (QPSolverOutput.PROXQP_MAX_ITER_REACHED,), (pis, i, info[j].status)
-            else:
-                assert info[j].status == r.info.status, (pis, i, info[j].status, r.info.status)
+            # (seed 14 with the option on ends MAX_ITER_REACHED on both sides: a fixed point of the BCL rule at
+            # the mu floors, derived without the oracle in tests/test_oracle_known_answers.py::
+            # test_seed14_is_a_fixed_point_of_the_reference_bcl_rule -- not a rounding tie, so the device must
+            # land in it as well)
+            assert info[j].status == r.info.status, (pis, i, info[j].status, r.info.status)
             if not pis:
                 assert info[j].iter_ext == r.info.iter_ext, (pis, i)
             if info[j].status == QPSolverOutput.PROXQP_SOLVED and r.info.status == QPSolverOutput.PROXQP_SOLVED and not (pis and r.info.iter_ext > 1000):
@@ -693,6 +732,8 @@ def case_primal_ldlt(lib, oracle, randqp, dim, B, seed0=1):
         pri, dua = kkt_numpy(H[i], g[i], A[i], bb[i], Cm[i], l[i], u[i], x[i], y[i], z[i], lb[i], ub[i])
         assert pri <= EPS and dua <= EPS, (i, pri, dua)
         assert close(x[i], qs[i].results.x), i
+        bad = info_close(info[i], qs[i].results.info)
+        assert bad is None, (i, bad)
     assert solved >= (3 * B) // 4, solved
     # automatic choice picks this engine at this shape (reference dense/wrapper.hpp:81-113)
     b2 = N.Batch(1, dim, ne, ni, box_constraints=True, lib=lib)

@@ -3,6 +3,7 @@ include/proxqp_hip.h (proxsuite_amd/csrc/libproxqp_hip.so), against the CPU orac
 seeded inputs, the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
 size-independent properties (KKT residuals on the unscaled model, run-to-run determinism)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -81,6 +82,20 @@ def test_maros_meszaros_small(lib):
     d = np.load(gold)
     for name in [str(s) for s in d["names"]]:
         pc.case_maros_meszaros(lib, *(d["%s/%s" % (name, k)] for k in "PqAlu"))
+
+
+def _medium_names():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maros_meszaros_medium.npz"))
+    return [str(s) for s in d["names"]]
+
+
+@pytest.mark.parametrize("name", _medium_names())
+def test_maros_meszaros_medium(lib, name):
+    """the other 29 problems of reference test/src/dense_maros_meszaros.cpp:97 (n up to 760, up to 856
+    constraint rows): the 512- and 1024-thread kernels on ill-conditioned real-world data"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_maros_meszaros_fixtures as mm
+    pc.case_maros_meszaros(lib, *mm.load_medium(only=name)[name])
 
 
 def test_errors(lib):

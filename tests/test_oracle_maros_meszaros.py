@@ -53,15 +53,20 @@ def test_maros_meszaros_small(oracle, name):
     _check(oracle, *(d["%s/%s" % (name, k)] for k in "PqAlu"))
 
 
-@pytest.mark.slow
-@pytest.mark.skipif(not os.path.isdir("/root/reference/test/data/maros_meszaros_data"),
-                    reason="reference fixtures not on this box")
-def test_maros_meszaros_medium_from_reference():
-    """A few of the larger problems straight from the reference tree (authoring box only)."""
-    import scipy.io as sio
-    from oracle import oracle as O
-    for name in ("PRIMAL1", "QRECIPE", "QSC205", "QPCBOEI2", "QE226"):
-        m = sio.loadmat("/root/reference/test/data/maros_meszaros_data/%s.mat" % name)
-        dense = lambda a: a.toarray() if hasattr(a, "toarray") else np.asarray(a)
-        _check(O, dense(m["P"]).astype(float), np.asarray(m["q"], float).ravel(), dense(m["A"]).astype(float),
-               np.asarray(m["l"], float).ravel(), np.asarray(m["u"], float).ravel())
+def _medium():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_maros_meszaros_fixtures as mm
+    return mm
+
+
+def _medium_names():
+    d = np.load(os.path.join(os.path.dirname(GOLD), "maros_meszaros_medium.npz"))
+    return [str(s) for s in d["names"]]
+
+
+@pytest.mark.parametrize("name", _medium_names())
+def test_maros_meszaros_medium(oracle, name):
+    """the other 29 problems the reference test runs (n <= 1000 and n_eq + n_in <= 1000,
+    test/src/dense_maros_meszaros.cpp:97), from the committed triplet fixture"""
+    _check(oracle, *_medium().load_medium(only=name)[name])
