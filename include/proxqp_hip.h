@@ -42,7 +42,7 @@ enum pqp_error
 };
 
 /* number of entries of the per-QP statistics record, see pqp_batch_get_stats */
-#define PQP_STATS_COUNT 31
+#define PQP_STATS_COUNT 32
 
 const char* pqp_last_error(void);
 int pqp_device_count(void);
@@ -83,6 +83,13 @@ int pqp_batch_warm_start(pqp_batch* h, int64_t idx, const double* x, const doubl
 
 /* QP::cleanup (reference dense/wrapper.hpp:958-962). */
 int pqp_batch_cleanup(pqp_batch* h, int64_t idx);
+
+/* Puts slot `idx` back into the state of a freshly created batch: default Settings of the batch's
+ * backend, default Results / Info, zero model with bounds +-sqrt(DBL_MAX), identity equilibration,
+ * cleared workspace flags.  What a NEW QP object must see when it takes over a recycled slot
+ * (reference dense/wrapper.hpp:140-333: every QP constructor starts from Settings / Results / Model
+ * defaults; QP::cleanup, :958-962, keeps settings and model). */
+int pqp_batch_reset_qp(pqp_batch* h, int64_t idx);
 
 /* Runs the queued init/update work (Ruiz equilibration, reference helpers.hpp:500-667)
  * on the device.  pqp_batch_solve calls it implicitly; call it explicitly to keep
@@ -153,6 +160,15 @@ int pqp_batch_pack_results(pqp_batch* h, int64_t first, int64_t count, double* o
  * test/src/dense_ruiz_equilibration.cpp) */
 int pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A, double* b,
                          double* C, double* l, double* u, double* delta, double* c);
+
+/* Diagnostic accessor (tests): the dual Schur block of QP `idx` as the last solve left it in HBM --
+ * inverse factor W_S [nd*nd], D_S [nd], Gram cache G [nd*nd] (by constraint id), inequality slot list
+ * [nc] (constraint index of slot j, -1 = hole), meta = {n_slots, n_c, ls_valid, ls_edited},
+ * mus = {mu_eq, mu_in} of the factorisation.  nd = n_eq + n_in (+ dim with box constraints).  The
+ * reference keeps the corresponding object in work.ldl (linalg/dense/ldlt.hpp); its row insertions and
+ * deletions are linalg/dense/modify.hpp:80-264. */
+int pqp_batch_get_schur_factor(pqp_batch* h, int64_t idx, double* WS, double* dS, double* G, int32_t* slots,
+                               int64_t* meta, double* mus);
 
 /* per-QP device statistics of the last solve: [B][PQP_STATS_COUNT] int64
  * (cycles per phase and event counters, see proxsuite_amd/csrc/pqp_solver.hpp ST_*) */

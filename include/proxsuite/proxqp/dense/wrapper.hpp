@@ -27,6 +27,7 @@
 #include <deque>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <vector>
 #include <memory>
 #include <stdexcept>
@@ -68,6 +69,11 @@ struct Pool
   isize capacity = 0, used = 0;
   isize dim = 0, n_eq = 0, n_in = 0, n_c = 0;
   std::vector<isize> free_slots; // registry pools only: slots given back by destroyed QPs
+  // The handle's host state (queued commands, launch range, events, settings upload) is shared by every
+  // QP of the pool.  With the reference each QP is an island, so `#pragma omp parallel for` over
+  // qps[i].solve() is legal user code: every QP method that touches `h`, and the slot bookkeeping, runs
+  // under this lock (recursive: solve() -> pull()).
+  mutable std::recursive_mutex mtx;
   Pool(isize cap, isize dim_, isize n_eq_, isize n_in_, bool box, HessianType hessian, DenseBackend backend,
        int device)
     : capacity(cap)
@@ -82,6 +88,7 @@ struct Pool
   Pool& operator=(const Pool&) = delete;
   ~Pool() { pqp_batch_destroy(h); }
 };
+using PoolLock = std::lock_guard<std::recursive_mutex>;
 
 template<typename T>
 inline T
@@ -90,39 +97,54 @@ opt_or_nan(const optional<T>& v)
   return v ? *v : std::numeric_limits<T>::quiet_NaN();
 }
 
-// Pools of the standalone QPs of this thread, by signature.  Slots are handed out in chunks sized
-// so that one pool stays below ~256 MB of device memory (1 .. 256 QPs).
+// Pools of the standalone QPs of this thread, by signature.  The registry only OBSERVES its pools
+// (weak_ptr): a pool lives as long as a QP holds it and its device memory goes away with the last of
+// them.  Pool sizes grow geometrically with the number of live QPs of the signature (1, 1, 2, 4, ...),
+// capped so that one pool stays below ~256 MB of device memory: one QP costs one QP.
 struct Registry
 {
   using Key = std::tuple<isize, isize, isize, bool, int, int, int>;
-  std::map<Key, std::vector<std::shared_ptr<Pool>>> pools;
+  std::map<Key, std::vector<std::weak_ptr<Pool>>> pools;
   static Registry& instance()
   {
     static thread_local Registry r;
     return r;
   }
-  static isize chunk(isize dim, isize n_eq, isize n_in, bool box)
+  static isize chunk_max(isize dim, isize n_eq, isize n_in, bool box)
   {
     const double n = double(dim), nd = double(n_eq + n_in + (box ? dim : 0));
     const double bytes = 8.0 * (5.0 * n * n + 6.0 * nd * n + 3.0 * nd * nd) + 4096.0;
     const double cap = 268435456.0 / bytes;
     return isize(std::max(1.0, std::min(256.0, cap)));
   }
-  std::pair<std::shared_ptr<Pool>, isize> acquire(isize dim, isize n_eq, isize n_in, bool box, HessianType hessian,
-                                                  DenseBackend backend, int device)
+  // -> (pool, slot, recycled): a recycled slot must be reset by its new owner (pqp_batch_reset_qp)
+  std::tuple<std::shared_ptr<Pool>, isize, bool> acquire(isize dim, isize n_eq, isize n_in, bool box,
+                                                         HessianType hessian, DenseBackend backend, int device)
   {
     auto& v = pools[Key{ dim, n_eq, n_in, box, int(hessian), int(backend), device }];
-    for (auto& p : v) {
+    isize live_capacity = 0;
+    for (auto it = v.begin(); it != v.end();) {
+      std::shared_ptr<Pool> p = it->lock();
+      if (!p) {
+        it = v.erase(it);
+        continue;
+      }
+      PoolLock lock(p->mtx);
       if (!p->free_slots.empty()) {
         const isize s = p->free_slots.back();
         p->free_slots.pop_back();
-        return { p, s };
+        return { p, s, true };
       }
       if (p->used < p->capacity)
-        return { p, p->used++ };
+        return { p, p->used++, false };
+      live_capacity += p->capacity;
+      ++it;
     }
-    v.push_back(std::make_shared<Pool>(chunk(dim, n_eq, n_in, box), dim, n_eq, n_in, box, hessian, backend, device));
-    return { v.back(), v.back()->used++ };
+    const isize cap = std::max<isize>(1, std::min(chunk_max(dim, n_eq, n_in, box), live_capacity));
+    auto p = std::make_shared<Pool>(cap, dim, n_eq, n_in, box, hessian, backend, device);
+    v.push_back(p);
+    p->used = 1;
+    return { p, 0, false };
   }
 };
 
@@ -163,11 +185,20 @@ public:
   {
     auto ps = detail::Registry::instance().acquire(model.dim, model.n_eq, model.n_in, box_constraints, hessian_type,
                                                    o.requested_backend_, device_);
-    pool_ = ps.first;
-    slot_ = ps.second;
+    pool_ = std::get<0>(ps);
+    slot_ = std::get<1>(ps);
     requested_backend_ = o.requested_backend_;
-    o.push_settings();
-    detail::check(pqp_batch_copy_qp(pool_->h, slot_, o.pool_->h, o.slot_));
+    // (every per-QP array, the settings and the flags are overwritten by the copy: no reset needed)
+    if (pool_ == o.pool_) {
+      detail::PoolLock lock(pool_->mtx);
+      o.push_settings();
+      detail::check(pqp_batch_copy_qp(pool_->h, slot_, o.pool_->h, o.slot_));
+    } else {
+      std::lock(pool_->mtx, o.pool_->mtx);
+      detail::PoolLock la(pool_->mtx, std::adopt_lock), lb(o.pool_->mtx, std::adopt_lock);
+      o.push_settings();
+      detail::check(pqp_batch_copy_qp(pool_->h, slot_, o.pool_->h, o.slot_));
+    }
   }
   QP& operator=(const QP& o)
   {
@@ -301,6 +332,7 @@ public:
   // QP::solve() (reference wrapper.hpp:922-939)
   void solve()
   {
+    detail::PoolLock lock(pool_->mtx);
     push_settings();
     detail::check(pqp_batch_solve_range(pool_->h, slot_, 1));
     pull();
@@ -308,6 +340,7 @@ public:
   // QP::solve(x, y, z) (reference wrapper.hpp:940-957; warm_start helpers.hpp:715-763)
   void solve(optional<VecRef<T>> x, optional<VecRef<T>> y, optional<VecRef<T>> z)
   {
+    detail::PoolLock lock(pool_->mtx);
     push_settings();
     std::vector<T> tx, ty, tz;
     const T* px = pack_vec(x, model.dim, tx, "the dimension wrt primal variable x for warm start is not valid.");
@@ -322,6 +355,7 @@ public:
   // QP::cleanup (reference wrapper.hpp:958-962)
   void cleanup()
   {
+    detail::PoolLock lock(pool_->mtx);
     detail::check(pqp_batch_cleanup(pool_->h, slot_));
     pull();
   }
@@ -331,6 +365,7 @@ public:
   void pull_settings() { settings.from_c(*pqp_batch_settings(pool_->h, slot_)); }
   void pull()
   {
+    detail::PoolLock lock(pool_->mtx);
     pull_settings();
     pqp_info info;
     detail::check(pqp_batch_get_results(pool_->h, slot_, results.x.data(), results.y.data(), results.z.data(),
@@ -346,8 +381,8 @@ private:
   void release() noexcept
   {
     if (owns_slot_ && pool_) {
-      // the slot goes back to its pool with a clean device state for the next owner
-      (void)pqp_batch_cleanup(pool_->h, slot_);
+      // the slot goes back to its pool; its next owner resets it (pqp_batch_reset_qp in the constructor)
+      detail::PoolLock lock(pool_->mtx);
       pool_->free_slots.push_back(slot_);
     }
     owns_slot_ = false;
@@ -371,10 +406,17 @@ private:
         throw std::invalid_argument(
           "wrong argument size: the dimension wrt the primal variable x should be strictly positive.");
       auto ps = detail::Registry::instance().acquire(dim, n_eq, n_in, box, hessian, backend, device);
-      pool_ = ps.first;
-      slot_ = ps.second;
+      pool_ = std::get<0>(ps);
+      slot_ = std::get<1>(ps);
       owns_slot_ = true;
+      if (std::get<2>(ps)) {
+        // a slot another QP object used before: a new QP starts from Settings / Results / Model defaults
+        // (reference wrapper.hpp:140-333), not from what its predecessor left there
+        detail::PoolLock lock(pool_->mtx);
+        detail::check(pqp_batch_reset_qp(pool_->h, slot_));
+      }
     }
+    detail::PoolLock lock(pool_->mtx);
     dense_backend = DenseBackend(pqp_batch_dense_backend(pool_->h)); // Automatic resolved (wrapper.hpp:81-113)
     pull_settings();                                                  // defaults of that backend
     pqp_info info;
@@ -436,6 +478,7 @@ private:
              const optional<VecRef<T>>& u_box, bool preconditioner_flag, const optional<T>& rho,
              const optional<T>& mu_eq, const optional<T>& mu_in, const optional<T>& min_eig)
   {
+    detail::PoolLock lock(pool_->mtx);
     const isize n = model.dim, ne = model.n_eq, ni = model.n_in;
     std::vector<T> tH, tg, tA, tb, tC, tl, tu, tlb, tub;
     // the checks of the reference (wrapper.hpp:380-451 / :744-797), in its order

@@ -78,7 +78,40 @@ TU_FLAGS = {1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-
 
 def hip_flags(extra_flags=()):
     return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", *CODEGEN_FLAGS,
+            "-Rpass-analysis=kernel-resource-usage",  # per-kernel registers / spills / scratch, parsed below
             "-I", str(INCLUDE), "-I", str(CSRC), *extra_flags]
+
+
+def parse_kernel_resources(stderr: str) -> dict:
+    """The AMDGPU backend's kernel-resource-usage remarks -> {demangled-ish kernel name: {field: value}}.
+    The register allocation of the one-kernel solver decides its speed, and three
+    internal -mllvm switches shape it: every build records what it got (build/kernel_resources.json,
+    copied to profiles/ by __graft_entry__.build) so that a toolchain change cannot shift it silently."""
+    import re
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+(Function Name|[A-Za-z ]+(?:\[[^\]]*\])?):\s*(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(2)
+        if key == "Function Name":
+            cur = out.setdefault(val, {})
+        elif cur is not None:
+            key = re.sub(r"\s*\[.*\]", "", key).strip().replace(" ", "_")
+            try:
+                cur[key] = int(val)
+            except ValueError:
+                cur[key] = val
+    return out
+
+
+def kernel_label(mangled: str) -> str:
+    """_Z16pqp_solve_kernelILi256ELi4ELi1EEv... -> pqp_solve_kernel<256,4,1>"""
+    import re
+    m = re.match(r"_Z\d+([A-Za-z_0-9]+?)I((?:Li\d+E)+)E", mangled)
+    if not m:
+        return mangled
+    return "%s<%s>" % (m.group(1), ",".join(re.findall(r"Li(\d+)E", m.group(2))))
 
 
 def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_TUS) -> Path:
@@ -103,9 +136,24 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
                       "-o", str(o)], o))
     todo = [j for j in jobs if force or extra_flags or not _newer(j[1], deps)]
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
-        list(ex.map(lambda j: _run(j[0]), todo))
+        results = list(ex.map(lambda j: _run(j[0]), todo))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *[str(j[1]) for j in jobs]])
+    # registers / spills / scratch of every kernel that was (re)compiled, merged into the record of this build tag
+    import json
+    rec_path = odir / "kernel_resources.json"
+    rec = json.loads(rec_path.read_text()) if rec_path.exists() else {}
+    for j, r in zip(todo, results):
+        for name, fields in parse_kernel_resources(r.stderr).items():
+            rec[kernel_label(name)] = dict(fields, object=j[1].name)
+    rec_path.write_text(json.dumps(rec, indent=1, sort_keys=True))
     return lib
+
+
+def kernel_resources(tag: str = "default") -> dict:
+    """what the last build of `tag` recorded (see parse_kernel_resources)"""
+    import json
+    p = OBJ_DIR / tag / "kernel_resources.json"
+    return json.loads(p.read_text()) if p.exists() else {}
 
 
 def build_hip_stats(force: bool = False) -> Path:

@@ -14,12 +14,12 @@ import numpy as np
 
 from ._ctypes_defs import pqp_info, pqp_settings
 
-PQP_STATS_COUNT = 31
+PQP_STATS_COUNT = 32
 STAT_NAMES = ("cyc_total", "cyc_scale", "cyc_factor_h", "cyc_zg", "cyc_schur", "cyc_kkt_solve",
               "cyc_residual", "cyc_linesearch", "cyc_global_res", "cyc_newton_misc", "n_newton",
               "n_schur_fact", "n_new_rows", "n_kkt_solves", "n_ls_breakpoints", "n_active_final",
               "cyc_f_load", "cyc_f_update", "cyc_f_panel", "cyc_f_writeback", "cyc_f_tinv", "cyc_s_gather",
-              "cyc_solve_ldlt", "n_schur_blocked", "n_append", "n_delete", "bytes_engine", "n_refactorize", "cyc_ls_eval", "cyc_cert", "cyc_update")
+              "cyc_solve_ldlt", "n_schur_blocked", "n_append", "n_delete", "bytes_engine", "n_refactorize", "cyc_ls_eval", "cyc_cert", "cyc_update", "wall_ticks")
 
 _DP = C.POINTER(C.c_double)
 NAN = float("nan")
@@ -34,10 +34,10 @@ class NativeLib:
 
     SYMBOLS = ("pqp_last_error", "pqp_device_count", "pqp_batch_create", "pqp_batch_destroy",
                "pqp_batch_size", "pqp_batch_dense_backend", "pqp_batch_settings", "pqp_batch_init",
-               "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_flush",
+               "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_reset_qp", "pqp_batch_flush",
                "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_solve_subset", "pqp_batch_copy_qp", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
                "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs", "pqp_batch_pack_results",
-               "pqp_batch_get_scaled", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
+               "pqp_batch_get_scaled", "pqp_batch_get_schur_factor", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
                "pqp_batch_launch_config")
 
     def __init__(self, path):
@@ -58,6 +58,7 @@ class NativeLib:
             getattr(L, name).argtypes = [vp, C.c_int64] + [_DP] * 9 + [C.c_int] + [C.c_double] * 4
         L.pqp_batch_warm_start.argtypes = [vp, C.c_int64] + [_DP] * 3
         L.pqp_batch_cleanup.argtypes = [vp, C.c_int64]
+        L.pqp_batch_reset_qp.argtypes = [vp, C.c_int64]
         L.pqp_batch_flush.argtypes = [vp]
         L.pqp_batch_solve.argtypes = [vp]
         L.pqp_batch_solve_range.argtypes = [vp, C.c_int64, C.c_int64]
@@ -73,6 +74,7 @@ class NativeLib:
         L.pqp_batch_pack_results.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
         L.pqp_batch_get_scaled.argtypes = [vp, C.c_int64] + [_DP] * 9
         L.pqp_batch_get_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.pqp_batch_get_schur_factor.argtypes = [vp, C.c_int64] + [_DP] * 3 + [C.POINTER(C.c_int32), C.POINTER(C.c_int64), _DP]
         L.pqp_batch_last_solve_ms.argtypes = [vp]
         L.pqp_batch_last_solve_ms.restype = C.c_double
         L.pqp_batch_launch_config.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
@@ -340,6 +342,16 @@ class Batch:
             p(out["u"]), p(out["delta"]), C.cast(C.byref(c), _DP)))
         out["c"] = c.value
         return out
+
+    def schur_factor(self, idx):
+        """diagnostic: (W_S, D_S, G, slots, meta, mus) of QP `idx` after its last solve (see proxqp_hip.h)"""
+        nd, nc = self.n_eq + self.n_c, self.n_c
+        WS, dS, G = np.zeros((nd, nd)), np.zeros(nd), np.zeros((nd, nd))
+        slots, meta, mus = np.zeros(max(nc, 1), dtype=np.int32), np.zeros(4, dtype=np.int64), np.zeros(2)
+        self.lib.check(self.lib.L.pqp_batch_get_schur_factor(
+            self._h, idx, WS.ctypes.data_as(_DP), dS.ctypes.data_as(_DP), G.ctypes.data_as(_DP),
+            slots.ctypes.data_as(C.POINTER(C.c_int32)), meta.ctypes.data_as(C.POINTER(C.c_int64)), mus.ctypes.data_as(_DP)))
+        return WS, dS, G, slots[:nc], dict(zip(("n_slots", "n_c", "ls_valid", "ls_edited"), meta.tolist())), mus
 
     def stats(self):
         a = np.zeros((self.B, PQP_STATS_COUNT), dtype=np.int64)

@@ -157,7 +157,7 @@ enqueue_setup(pqp_batch* h, int64_t idx, bool update_call, const double* H, cons
     return fail(PQP_ERR_INVALID_ARGUMENT,
                 "wrong model setup: the QP object is designed without box constraints, but is "
                 "initialized or updated with lower or upper box inequalities.");
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   const int64_t lo = idx < 0 ? 0 : idx, hi = idx < 0 ? h->dev.B : idx + 1;
   // one queued command per QP: run what is pending before stacking another one
   for (int64_t q = lo; q < hi; ++q)
@@ -245,7 +245,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     return fail(PQP_ERR_NO_DEVICE, "no HIP device: libproxqp_hip has no CPU fallback");
   if (device < 0 || device >= ndev)
     return fail(PQP_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-  DeviceGuard guard_(device);
+  PQP_ON_DEVICE(device);
 
   pqp_batch* h = new pqp_batch();
   h->device = device;
@@ -253,6 +253,11 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
       h->n_cu = cus;
+    // wall_clock64() of the device: constant-rate counter, rate in kHz (100 MHz on CDNA) -> Info timings
+    int khz = 0;
+    h->dev.wall_us_per_tick =
+      (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ? 1.0e3 / double(khz)
+                                                                                                      : 1.0e-2;
   }
   h->backend = dense_backend_choice(dense_backend, dim, n_eq, n_in, box_constraints != 0);
   pqp::Dims& d = h->dev.d;
@@ -448,7 +453,7 @@ pqp_batch_warm_start(pqp_batch* h, int64_t idx, const double* x, const double* y
     return rc;
   if (!x && !y && !z) // helpers.hpp:724-725
     return PQP_OK;
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   // the guess must land after any queued cleanup of the results
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
@@ -484,6 +489,55 @@ pqp_batch_cleanup(pqp_batch* h, int64_t idx)
   return pqp_batch_flush(h);
 }
 
+// A slot handed to a NEW QP object (the C++ facade recycles the slots of its pools): everything a
+// freshly created batch holds for that QP -- Settings(dense_backend), Results, Model (zero matrices,
+// bounds +-sqrt(DBL_MAX)), workspace flags, Ruiz delta = 1 (reference dense/wrapper.hpp:140-333: every
+// constructor starts from defaults).
+int
+pqp_batch_reset_qp(pqp_batch* h, int64_t idx)
+{
+  if (!h || idx < 0 || idx >= h->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+  PQP_ON_DEVICE(h->device);
+  if (h->cmd_pending)
+    if (int rc = pqp_batch_flush(h))
+      return rc;
+  const size_t q = size_t(idx);
+  for (const auto& a : h->per_qp)
+    HIP_TRY(hipMemset(a.base + q * a.bytes_per_qp, 0, a.bytes_per_qp));
+  pqp::Batch& D = h->dev;
+  const pqp::Dims& d = D.d;
+  const size_t n = size_t(d.n), ni = size_t(d.n_in);
+  pqp_info info;
+  pqp_info_default(&info, h->backend);
+  HIP_TRY(hipMemcpy(D.info + q, &info, sizeof(info), hipMemcpyHostToDevice));
+  pqp::State st;
+  std::memset(&st, 0, sizeof(st));
+  st.ruiz_c = 1.0;
+  HIP_TRY(hipMemcpy(D.state + q, &st, sizeof(st), hipMemcpyHostToDevice));
+  const double ib = std::sqrt(std::numeric_limits<double>::max());
+  std::vector<double> tmp;
+  auto fill = [&](double* dst, size_t cnt, double v) -> int {
+    if (!cnt)
+      return PQP_OK;
+    tmp.assign(cnt, v);
+    HIP_TRY(hipMemcpy(dst, tmp.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+    return PQP_OK;
+  };
+  int rc = 0;
+  if ((rc = fill(D.u + q * ni, ni, +ib)) || (rc = fill(D.l + q * ni, ni, -ib)) ||
+      (rc = fill(D.u_box + q * n, n, +ib)) || (rc = fill(D.l_box + q * n, n, -ib)) ||
+      (rc = fill(D.delta + q * size_t(d.ntot), size_t(d.ntot), 1.0)) || (rc = fill(D.is + q * n, n, 1.0)))
+    return rc;
+  pqp_settings_default(&h->settings[q], h->backend);
+  h->settings_dirty = true;
+  h->settings_uploaded.clear(); // (the slice of d_settings was zeroed above: force a re-upload)
+  h->cmd[q] = pqp::Cmd{};
+  h->is_initialized[q] = 0;
+  h->order_valid = false;
+  return PQP_OK;
+}
+
 int
 pqp_batch_flush(pqp_batch* h)
 {
@@ -491,7 +545,7 @@ pqp_batch_flush(pqp_batch* h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
   if (!h->cmd_pending || h->dev.B == 0)
     return PQP_OK;
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   if (int rc = upload_settings(h))
     return rc;
   // only the span of QPs that carry a command is uploaded and launched (a BatchQP filled QP by
@@ -542,6 +596,57 @@ pqp_batch_solve(pqp_batch* h)
   return pqp_batch_solve_range(h, 0, h->dev.B);
 }
 
+// settings.verbose (reference dense/utils.hpp:33-131 header, dense/solver.hpp:1789-1830 statistics): the
+// whole solve of a QP runs inside one kernel, so there are no per-iteration lines to print; the header and
+// the final statistics block are printed from the returned Info, one block per verbose QP, in index order.
+static int
+verbose_report(pqp_batch* h, const int64_t* idx, int64_t first, int64_t count)
+{
+  bool any = false;
+  for (int64_t i = 0; i < count && !any; ++i)
+    any = h->settings[size_t(idx ? idx[i] : first + i)].verbose != 0;
+  if (!any)
+    return PQP_OK;
+  const pqp::Dims& d = h->dev.d;
+  static const char* const status_name[] = { "Solved", "Maximum number of iterations reached", "Primal infeasible",
+                                             "Solved closest primal feasible", "Dual infeasible", "Solver not run" };
+  for (int64_t i = 0; i < count; ++i) {
+    const int64_t q = idx ? idx[i] : first + i;
+    const pqp_settings& st = h->settings[size_t(q)];
+    if (!st.verbose)
+      continue;
+    pqp_info info;
+    HIP_TRY(hipMemcpy(&info, h->dev.info + q, sizeof(info), hipMemcpyDeviceToHost));
+    std::printf("-------------------------------------------------------------------------------------------------\n"
+                "ProxQP dense backend, batched on MI355X (QP %lld of the batch)\n"
+                "problem:  \n          variables n = %d, equality constraints n_eq = %d,\n"
+                "          inequality constraints n_in = %d\n"
+                "settings: \n          backend = dense,\n          eps_abs = %g eps_rel = %g\n"
+                "          eps_prim_inf = %g, eps_dual_inf = %g,\n          rho = %g, mu_eq = %g, mu_in = %g,\n"
+                "          max_iter = %lld, max_iter_in = %lld,\n          box constraints: %s, \n"
+                "          dense backend: %s, \n          problem type: %s, \n          scaling: %s, \n"
+                "          timings: %s, \n",
+                (long long)q, d.n, d.n_eq, d.n_in, st.eps_abs, st.eps_rel, st.eps_primal_inf, st.eps_dual_inf, info.rho,
+                info.mu_eq, info.mu_in, (long long)st.max_iter, (long long)st.max_iter_in, d.box ? "on" : "off",
+                h->backend == PQP_BACKEND_PRIMAL_LDLT ? "PrimalLDLT" : "PrimalDualLDLT",
+                d.hessian == PQP_HESSIAN_DENSE
+                  ? "Quadratic Program"
+                  : (d.hessian == PQP_HESSIAN_ZERO ? "Linear Program" : "Quadratic Program with diagonal Hessian"),
+                st.compute_preconditioner ? "on" : "off", st.compute_timings ? "on" : "off");
+    std::printf("-------------------SOLVER STATISTICS-------------------\n"
+                "outer iter:     %lld\ntotal iter:     %lld\nmu updates:     %lld\nrho updates:    %lld\n"
+                "objective:      %g\nstatus:         %s\n",
+                (long long)info.iter_ext, (long long)info.iter, (long long)info.mu_updates,
+                (long long)info.rho_updates, info.objValue,
+                (info.status >= 0 && info.status <= 5) ? status_name[info.status] : "?");
+    if (st.compute_timings)
+      std::printf("run time [\xce\xbcs]:  %g\n", info.solve_time);
+    std::printf("--------------------------------------------------------\n");
+  }
+  std::fflush(stdout);
+  return PQP_OK;
+}
+
 int
 pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
 {
@@ -555,7 +660,7 @@ pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
     return PQP_OK;
   h->range_first = first;
   h->range_count = count;
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   if (int rc = pqp_batch_flush(h))
     return rc;
   if (int rc = upload_settings(h))
@@ -572,7 +677,7 @@ pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
   }
   // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
   std::fill(h->is_initialized.begin() + first, h->is_initialized.begin() + first + count, char(1));
-  return PQP_OK;
+  return verbose_report(h, nullptr, first, count);
 }
 
 int
@@ -585,12 +690,16 @@ pqp_batch_solve_subset(pqp_batch* h, const int64_t* idx, int64_t count)
   if (count == 0)
     return PQP_OK;
   std::vector<int> order(static_cast<size_t>(count));
+  std::vector<char> seen(static_cast<size_t>(h->dev.B), 0);
   for (int64_t i = 0; i < count; ++i) {
     if (idx[i] < 0 || idx[i] >= h->dev.B)
       return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+    if (seen[size_t(idx[i])]) // two workgroups on one QP would race on its x / y / z / state / factors
+      return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_solve_subset: a QP index is listed twice");
+    seen[size_t(idx[i])] = 1;
     order[size_t(i)] = int(idx[i]);
   }
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   if (int rc = pqp_batch_flush(h))
     return rc;
   if (int rc = upload_settings(h))
@@ -609,7 +718,7 @@ pqp_batch_solve_subset(pqp_batch* h, const int64_t* idx, int64_t count)
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   for (int64_t i = 0; i < count; ++i)
     h->is_initialized[size_t(idx[i])] = 1;
-  return PQP_OK;
+  return verbose_report(h, idx, 0, count);
 }
 
 int
@@ -623,7 +732,7 @@ pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_i
   if (a.n != b.n || a.n_eq != b.n_eq || a.n_in != b.n_in || a.box != b.box || a.hessian != b.hessian ||
       dst->per_qp.size() != src->per_qp.size())
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_copy_qp: the two batches hold QPs of different shapes");
-  DeviceGuard guard_(src->device);
+  PQP_ON_DEVICE(src->device);
   if (int rc = pqp_batch_flush(src))
     return rc;
   if (int rc = pqp_batch_flush(dst))
@@ -658,7 +767,7 @@ pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const doubl
     return fail(PQP_ERR_INVALID_ARGUMENT, "loss_derivatives is required");
   if (count == 0)
     return PQP_OK;
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -723,7 +832,7 @@ pqp_batch_get_backward(pqp_batch* h, int64_t idx, double* dL_dH, double* dL_dg, 
     return rc;
   if (!h->bw_dH)
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_backward has not been called on this batch");
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   const pqp::Dims& d = h->dev.d;
   const size_t n = size_t(d.n), ne = size_t(d.n_eq), ni = size_t(d.n_in);
   const int64_t B = h->dev.B;
@@ -742,7 +851,7 @@ pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z
 {
   if (int rc = check_idx(h, idx))
     return rc;
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -785,7 +894,7 @@ pqp_batch_pack_results(pqp_batch* h, int64_t first, int64_t count, double* out, 
     return fail(PQP_ERR_INVALID_ARGUMENT, "pack range outside the batch");
   if (count == 0)
     return PQP_OK;
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -800,7 +909,7 @@ pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A,
     return rc;
   if (idx < 0)
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_get_scaled addresses one QP");
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -821,6 +930,49 @@ pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A,
   return PQP_OK;
 }
 
+// Diagnostic: the dual Schur block of QP `idx` as the last solve left it in HBM (DenseBackend::PrimalDualLDLT):
+// inverse factor W_S (nd x nd, row-major, lower, unit diagonal), D_S (nd), the Gram cache G (nd x nd, by
+// constraint id: equality a -> a, inequality i -> n_eq + i), the slot list (nc ints: constraint id of the
+// inequality slot j, -1 for a hole) and meta = {n_slots, n_c, ls_valid, ls_edited}, mus = {mu_eq, mu_in} the
+// factor was built for.  The identity W_S (M_J + G_JJ) W_S^T = D_S can then be checked on the host
+// (tests: accuracy of the rank-1 row appends / deletions on the real device).
+int
+pqp_batch_get_schur_factor(pqp_batch* h, int64_t idx, double* WS, double* dS, double* G, int32_t* slots,
+                           int64_t* meta, double* mus)
+{
+  if (int rc = check_idx(h, idx))
+    return rc;
+  if (idx < 0)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_get_schur_factor addresses one QP");
+  PQP_ON_DEVICE(h->device);
+  const pqp::Dims& d = h->dev.d;
+  const pqp::Batch& D = h->dev;
+  const size_t nd = size_t(d.nd), nc = size_t(d.nc);
+  int rc = 0;
+  if ((rc = copy_out(WS, D.WS, idx, D.B, nd * nd)) || (rc = copy_out(dS, D.dS, idx, D.B, nd)) ||
+      (rc = copy_out(G, D.G, idx, D.B, nd * nd)))
+    return rc;
+  if (slots && nc) {
+    std::vector<int> raw(nc);
+    HIP_TRY(hipMemcpy(raw.data(), D.act + size_t(idx) * nc, nc * sizeof(int), hipMemcpyDefault));
+    for (size_t j = 0; j < nc; ++j)
+      slots[j] = (raw[j] & 0xffff) - 1; // (bits 16-17 carry the persistent up / low flags)
+  }
+  pqp::State s;
+  HIP_TRY(hipMemcpy(&s, D.state + idx, sizeof(s), hipMemcpyDefault));
+  if (meta) {
+    meta[0] = s.n_slots;
+    meta[1] = s.n_c;
+    meta[2] = s.ls_valid;
+    meta[3] = s.ls_edited;
+  }
+  if (mus) {
+    mus[0] = s.mu_eq_fact;
+    mus[1] = s.mu_in_fact;
+  }
+  return PQP_OK;
+}
+
 int
 pqp_batch_get_stats(pqp_batch* h, int64_t* stats)
 {
@@ -828,7 +980,7 @@ pqp_batch_get_stats(pqp_batch* h, int64_t* stats)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
   static_assert(PQP_STATS_COUNT == pqp::ST_COUNT, "stats record size");
   static_assert(sizeof(long long) == sizeof(int64_t), "stats element size");
-  DeviceGuard guard_(h->device);
+  PQP_ON_DEVICE(h->device);
   HIP_TRY(hipMemcpy(stats, h->dev.stats, size_t(h->dev.B) * pqp::ST_COUNT * sizeof(int64_t), hipMemcpyDefault));
   return PQP_OK;
 }

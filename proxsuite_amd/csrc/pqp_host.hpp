@@ -80,12 +80,17 @@ struct DeviceGuard
 {
   int prev = -1;
   bool switched = false;
+  bool failed = false; // the switch to `device` did not happen: the entry must not touch device memory
   explicit DeviceGuard(int device)
   {
-    if (hipGetDevice(&prev) == hipSuccess && prev != device) {
+    if (hipGetDevice(&prev) != hipSuccess)
+      failed = true;
+    else if (prev != device) {
       switched = hipSetDevice(device) == hipSuccess;
+      failed = !switched;
     }
   }
+  bool ok() const { return !failed; }
   ~DeviceGuard()
   {
     if (switched)
@@ -94,6 +99,11 @@ struct DeviceGuard
   DeviceGuard(const DeviceGuard&) = delete;
   DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
+// every C-ABI entry that touches device memory: switch to the handle's device or fail the call
+#define PQP_ON_DEVICE(dev)                                                                          \
+  DeviceGuard guard_(dev);                                                                          \
+  if (!guard_.ok())                                                                                 \
+    return pqp_fail(PQP_ERR_HIP, "hipSetDevice(" + std::to_string(dev) + ") failed: the call did not run")
 
 // launchers (pqp_kernels.hip); each picks the instantiation for h->nt / the model signature
 int pqp_launch_setup(pqp_batch* h);

@@ -107,7 +107,7 @@ struct State
   int ls_valid;     // the Schur factor in HBM matches (mu_eq_fact, mu_in_fact, active list)
   int n_slots;      // inequality slots of that factor (n_c live ones + the holes deletions left)
   int c_diag;       // C has no off-diagonal entry and n_in == dim (e.g. bounds passed as C = I): set by init / update
-  int _pad1;
+  int ls_edited;    // that factor has taken rank-1 edits since its last full factorisation (refinement fallback, solver.hpp:474-532)
   double ruiz_c;
   double dual_feasibility_rhs_2;
   double correction_guess_rhs_g;
@@ -148,6 +148,7 @@ enum
   ST_CYC_LS_EVAL,     // line search: phi'(alpha) at every breakpoint (sub-phase of ST_CYC_LINESEARCH)
   ST_CYC_CERT,        // infeasibility certificates (sub-phase of ST_CYC_NEWTON_MISC)
   ST_CYC_UPDATE,      // iterate update + inner stopping criterion (sub-phase of ST_CYC_NEWTON_MISC)
+  ST_WALL_TICKS,      // residency of the QP's workgroup in constant-rate ticks (wall_clock64): info.solve_time
   ST_COUNT
 };
 
@@ -179,6 +180,7 @@ struct Batch
   double *dS;     // nd     D_S
   int* act;       // nc      active list kept across solves
   long long* stats; // ST_COUNT per QP
+  double wall_us_per_tick; // microseconds per wall_clock64() tick of this device (Info timings)
 };
 
 // QPLayer backward (reference dense/compute_ECJ.hpp): inputs and outputs of one launch.
@@ -524,6 +526,7 @@ work_cleanup_flags(State& w)
   w.factor_valid = 0;
   w.ls_valid = 0;
   w.n_slots = 0;
+  w.ls_edited = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -794,6 +797,7 @@ setup_body(const Batch& batch, long q, lptr lds_base)
   }
 
   const bool is_init = (cmd.op == CMD_INIT) || !W.is_initialized; // wrapper.hpp:743-746
+  const long long setup_t0 = wall_clock64();                      // wrapper.hpp:374-377
   __syncthreads();
   if (threadIdx.x == 0) {
     if (is_init) {
@@ -924,6 +928,8 @@ setup_body(const Batch& batch, long q, lptr lds_base)
       W.ruiz_c = c;
       if (is_init)
         W.is_initialized = 1;
+      if (st.compute_timings) // wrapper.hpp:495-497, 804-806: microseconds spent in init / update
+        info.setup_time = (double)(wall_clock64() - setup_t0) * batch.wall_us_per_tick;
     }
   }
 }
@@ -2092,9 +2098,7 @@ struct Solver
   }
 
   // reference solver.hpp:406-541: solve + iterative refinement on the unfactorised
-  // operator.  The refactorisation fallback (:474-532) has nothing to rebuild here:
-  // the Schur block is re-factorised from G on every change and never drifts.
-  // In: rhs in (L.rx(), L.rd()).  Out: solution in (L.dx(), L.sd()).
+  // operator.  In: rhs in (L.rx(), L.rd()).  Out: solution in (L.dx(), L.sd()).
   // Returns true when refinement missed eps on a Schur factor that rank-1 sweeps have edited since
   // its last full factorisation: the caller then rebuilds the factor and repeats the solve once --
   // the reference's fallback (solver.hpp:474-532: refactorize, solve again).  A fresh factor has
@@ -2149,7 +2153,9 @@ struct Solver
         break;
     }
     info.iterative_residual = cur;
-    return (cur >= eps) && schur_incremental && r > 0;
+    // (:474: the fallback triggers on err >= max(eps, eps_refact); a factor without edits since its last
+    // full factorisation would be rebuilt to the same bits, so only an edited one is worth the repeat)
+    return (cur >= fmax(eps, st.eps_refact)) && schur_incremental && (r > 0 || pm());
   }
 
   // New active set from L.aflags (bit 2 = wanted active).  (reference linesearch.hpp:549-786
@@ -2831,7 +2837,7 @@ struct Solver
   // One linear step.  mode 0: semismooth Newton step (reference solver.hpp:754-869);
   // mode 1: equality-constrained initial guess (helpers.hpp:199-228);
   // mode 2: only install the active set encoded in L.aflags (solver.hpp:1231-1240).
-  __device__ __forceinline__ void linear_step(int mode, double eps)
+  __device__ __forceinline__ bool linear_step(int mode, double eps)
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
     const double zfac = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
@@ -2845,7 +2851,7 @@ struct Solver
     __syncthreads();
     apply_active_set();
     if (mode == 2)
-      return;
+      return false;
     tic();
     if (mode == 0) {
       // right-hand side (solver.hpp:787-847)
@@ -2915,23 +2921,18 @@ struct Solver
     __syncthreads();
     zero_holes(L.rd());
     toc(ST_CYC_NEWTON_MISC);
-    if (PQP_UNLIKELY(iterative_solve(eps))) {
-      // Refinement missed eps on a Schur factor edited by rank-1 sweeps.  The reference rebuilds its
-      // factorisation and repeats the solve (solver.hpp:474-532); here the step is taken as it is
-      // (the exact line search and the outer loop absorb an inexact Newton direction, exactly as
-      // they do when the reference's second attempt also misses eps) and the block is re-factorised
-      // from scratch before the next linear solve.  (Repeating the solve in place would put a
-      // second copy of the factorisation inside the Newton loop: measured +300 VGPR spills in the
-      // hot mat-vec loops.)
-      schur_dirty = true;
-      count(ST_N_REFACTORIZE);
-    }
+    // true: refinement missed max(eps, eps_refact) on a factor that rank-1 sweeps have edited -- the
+    // reference then rebuilds its factorisation and repeats solve + refinement once (refactorize,
+    // solver.hpp:474-532); the Newton loop does that by re-entering this step with the factor marked stale
+    const bool missed = iterative_solve(eps);
     if (mode == 1) {
       vcopy(L.x(), L.dx(), n);
       vcopy(L.y(), L.sd(), ne);
       __syncthreads();
-      return;
+      return false;
     }
+    if (PQP_UNLIKELY(missed))
+      return true;
     // un-permute: dz_i = solution of its slot, or -z_i when inactive (:860-868);
     // C^T dz = (active part, from the last residual) - (inactive multipliers' part)
     vcopy(L.dy(), L.sd(), ne);
@@ -2942,19 +2943,30 @@ struct Solver
     for (int k = threadIdx.x; k < n; k += NT)
       L.CTdz()[k] -= L.CTzin()[k];
     __syncthreads();
+    return false;
   }
 
   // reference solver.hpp:882-1077
   __device__ __forceinline__ void newton_semi_smooth(double eps_int)
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nc = d.nc;
+    bool refactorized = false;
     for (long iter = 0; iter <= st.max_iter_in; ++iter) {
       if (iter == st.max_iter_in) {
         info.iter += st.max_iter_in + 1;
         break;
       }
       count(ST_N_NEWTON);
-      linear_step(0, eps_int);
+      if (PQP_UNLIKELY(linear_step(0, eps_int)) && !refactorized) {
+        // refinement fallback (solver.hpp:474-532): same iterate, same active set, factor rebuilt from
+        // scratch by the step's own call of apply_active_set, solve + refinement repeated -- once
+        schur_dirty = true;
+        refactorized = true;
+        count(ST_N_REFACTORIZE);
+        --iter;
+        continue;
+      }
+      refactorized = false;
       tic();
       if (st.merit_function_type == PQP_MERIT_GPDAL) {
         for (int i = threadIdx.x; i < nc; i += NT)
@@ -3070,6 +3082,7 @@ struct Solver
       L.stat()[k] = 0;
     if (threadIdx.x == 0)
       L.stat()[ST_CYC_TOTAL] = -clock64(); // (start time parked in its own counter: no register held)
+
     // results -> LDS (the warm-start modes read them)
     vload(L.x(), P.x(), n);
     vload(L.y(), P.y(), ne);
@@ -3087,6 +3100,8 @@ struct Solver
       }
     }
     __syncthreads();
+    if (threadIdx.x == 0)
+      L.stat()[ST_WALL_TICKS] = -wall_clock64(); // (after the barrier: another lane zeroed this counter above)
 
     // --- what this call has to do (solver.hpp:1125-1376), decided once so that the
     // heavy phases below have a single call site each
@@ -3200,7 +3215,7 @@ struct Solver
       }
       __syncthreads();
       schur_dirty = !(W.ls_valid && W.mu_eq_fact == info.mu_eq && W.mu_in_fact == info.mu_in);
-      schur_incremental = n_slots > n_c;
+      schur_incremental = W.ls_edited != 0;
     }
     if (do_aset_from_z || do_eq_guess) {
       if (do_aset_from_z) {
@@ -3540,6 +3555,14 @@ struct Solver
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+      // Info timings (solver.hpp:1112-1115, 1783-1787): the reference reads a host timer around one QP's
+      // solve; here it is the time this QP's workgroup was resident, in microseconds (the batch's launch
+      // time is pqp_batch_last_solve_ms)
+      L.stat()[ST_WALL_TICKS] += wall_clock64();
+      if (st.compute_timings) {
+        info.solve_time = (double)L.stat()[ST_WALL_TICKS] * batch.wall_us_per_tick;
+        info.run_time = info.solve_time + info.setup_time;
+      }
       info.store(*P.info());
       W.dirty = 1;
       W.is_initialized = 1;
@@ -3547,6 +3570,7 @@ struct Solver
       W.n_slots = n_slots;
       W.factor_valid = 1;
       W.ls_valid = schur_dirty ? 0 : 1;
+      W.ls_edited = schur_incremental ? 1 : 0;
       W.mu_eq_fact = info.mu_eq;
       W.mu_in_fact = info.mu_in;
       W.rho_fact = info.rho;

@@ -474,9 +474,11 @@ def solve(*args, **kwargs):
         solve(H, g, A, b, C, l, u, x, y, z, eps_abs, ...)
         solve(H, g, A, b, C, l, u, l_box, u_box, x, y, z, eps_abs, ...)
 
-    Python cannot overload on types, so a positional call is read as the box overload when its 8th
-    and 9th arguments are vectors of the primal dimension and the 9th cannot be `y` (n_eq != dim), or
-    when twelve or more leading arguments are arrays / None; `l_box=` / `u_box=` keywords always work."""
+    Python cannot overload on types.  A positional call is read as the box overload when its 8th and
+    9th arguments can only be (l_box, u_box): both vectors of the primal dimension -- or None followed by
+    such a vector -- while n_eq != dim, so that the 9th cannot be `y`.  When n_eq == dim the two readings
+    cannot be told apart and the call raises TypeError: pass `l_box=` / `u_box=` (or `x=`, `y=`) by keyword,
+    which always works."""
     def is_vec(v, length):
         try:
             return v is not None and not np.isscalar(v) and np.asarray(v).ndim == 1 and np.asarray(v).shape[0] == length
@@ -491,8 +493,11 @@ def solve(*args, **kwargs):
         n0 = H0.shape[0] if H0 is not None else (len(args[1]) if args[1] is not None else 0)
         A0 = _host(args[2])
         ne0 = A0.shape[0] if A0 is not None else 0
-        arrays12 = len(args) >= 12 and all(a is None or (not np.isscalar(a) and hasattr(a, "__len__")) for a in args[:12])
-        if is_vec(args[7], n0) and is_vec(args[8], n0) and (ne0 != n0 or arrays12):
+        v8, v9 = is_vec(args[7], n0), is_vec(args[8], n0)
+        if v9 and (v8 or args[7] is None):
+            if ne0 == n0:
+                raise TypeError("solve(): with n_eq == dim the 8th and 9th positional arguments can be read as (x, y) "
+                                "or as (l_box, u_box); pass them by keyword")
             names = box_names
     if len(args) > len(names):
         raise TypeError("solve() takes at most %d positional arguments" % len(names))

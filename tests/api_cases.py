@@ -111,6 +111,23 @@ def case_box(dense, oracle, randqp):
     r3 = dense.solve(H, g, None, None, C, l, u, lb, ub, None, None, None, 1e-9)
     assert np.array_equal(r3.x, r2.x) and np.array_equal(r3.z, r2.z)
     np.testing.assert_allclose(r2.x, r.x, atol=1e-8)
+    # l_box = None given positionally: still the box overload (the 9th argument cannot be y: n_eq != dim)
+    r4 = dense.solve(H, g, None, None, C, l, u, None, ub, None, None, None, 1e-9)
+    r5 = dense.solve(H, g, None, None, C, l, u, eps_abs=1e-9, u_box=ub)
+    assert np.array_equal(r4.x, r5.x) and r4.z.shape == (ni + n,)
+    # a plain positional call with a warm start x and y = None stays the plain overload
+    r6 = dense.solve(H, g, None, None, C, l, u, r.x, None, None, 1e-9)
+    assert r6.z.shape == (ni,)
+    # n_eq == dim: (x, y) and (l_box, u_box) cannot be told apart positionally -> TypeError, keywords work
+    A = np.eye(n)
+    bvec = np.zeros(n)
+    import pytest
+    with pytest.raises(TypeError):
+        dense.solve(H, g, A, bvec, C, l, u, lb, ub, None, None, None, 1e-9)
+    with pytest.raises(TypeError):
+        dense.solve(H, g, A, bvec, C, l, u, None, ub, None, None, None, 1e-9)
+    r7 = dense.solve(H, g, A, bvec, C, l, u, x=np.zeros(n), y=np.zeros(n), eps_abs=1e-9)
+    assert r7.z.shape == (ni,)
 
 
 def case_batch_and_parallel(dense, oracle, randqp, B=6):
@@ -318,3 +335,55 @@ def case_nonconvex_helpers(dense):
     assert r.info.status == dense.QPSolverOutput.PROXQP_SOLVED
     assert np.max(np.abs(H @ r.x + g + r.z)) <= 1e-9
     assert np.all(r.x <= 1 + 1e-9) and np.all(r.x >= -1 - 1e-9)
+
+
+def case_timings_and_verbose(dense, randqp, capfd=None):
+    """settings.compute_timings / settings.verbose (reference dense/wrapper.hpp:374-377, 495-497,
+    dense/solver.hpp:1112-1115, 1783-1787, 1789-1830): Info timings are microseconds, non-zero, and
+    run_time = setup_time + solve_time on a first solve; a dirty re-solve clears setup_time
+    (results.hpp:157-174: cleanup_statistics); without the setting the fields stay 0."""
+    n, ne, ni = 10, 3, 4
+    d = _qp_data(randqp, n, ne, ni, 3)
+    qp = dense.QP(n, ne, ni)
+    qp.settings.eps_abs = 1e-9
+    qp.init(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"])
+    qp.solve()
+    i = qp.results.info
+    assert i.setup_time == 0 and i.solve_time == 0 and i.run_time == 0
+    qp = dense.QP(n, ne, ni)
+    qp.settings.eps_abs = 1e-9
+    qp.settings.compute_timings = True
+    qp.init(d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"])
+    assert qp.results.info.setup_time > 0
+    qp.solve()
+    i = qp.results.info
+    assert i.setup_time > 0 and i.solve_time > 0
+    assert abs(i.run_time - (i.setup_time + i.solve_time)) <= 1e-9 * i.run_time
+    assert i.solve_time < 60e6  # microseconds: a 10-variable QP does not take a minute
+    first = i.solve_time
+    qp.solve()  # dirty re-solve: statistics cleaned, setup_time back to 0
+    i = qp.results.info
+    assert i.setup_time == 0 and i.solve_time > 0 and i.run_time == i.solve_time
+    assert first > 0
+    # verbose: the header and the statistics block of the reference, printed by the host after the launch
+    qp.settings.verbose = True
+    qp.solve()
+    if capfd is not None:
+        out = capfd.readouterr().out
+        for word in ("SOLVER STATISTICS", "outer iter:", "total iter:", "mu updates:", "objective:", "status:         Solved",
+                     "variables n = 10", "eps_abs = 1e-09", "run time"):
+            assert word in out, (word, out)
+
+
+def case_alias_package():
+    """`proxsuite` import name (reference bindings/python/proxsuite/__init__.py, torch/qplayer.py:12-20)"""
+    import proxsuite
+    import proxsuite.proxqp.dense as pd
+    from proxsuite.proxqp.dense import QP, BatchQP, solve_in_parallel  # noqa: F401
+    from proxsuite.torch.qplayer import QPFunction
+    from proxsuite_amd.proxqp import dense as impl
+    from proxsuite_amd.torch import qplayer
+    assert pd is impl and proxsuite.proxqp.dense is impl and QP is impl.QP
+    assert QPFunction is qplayer.QPFunction
+    assert proxsuite.proxqp.InitialGuess.NO_INITIAL_GUESS == impl.InitialGuess.NO_INITIAL_GUESS
+    assert proxsuite.torch.QPFunction is QPFunction

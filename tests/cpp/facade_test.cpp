@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
 
 #include <proxsuite/proxqp/dense/dense.hpp>
 #include <proxsuite/proxqp/parallel/qp_solve.hpp>
@@ -284,6 +285,100 @@ main(int argc, char** argv)
     for (int k = 0; k < 2; ++k)
       for (isize j = 0; j < bd; ++j)
         CHECK(std::fabs(bq[k].model.backward_data.dL_dg[j] - dx_dg(k, j)) < 1e-9);
+  }
+
+  // --- Info timings (wrapper.hpp:374-377, 495-497; solver.hpp:1112-1115, 1783-1787): microseconds, non-zero and
+  // ordered when settings.compute_timings is set, zero otherwise; a dirty re-solve clears setup_time
+  {
+    const auto& m = models[1];
+    dense::QP<T> qp(dim, n_eq, n_in);
+    qp.settings.eps_abs = eps_abs;
+    qp.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+    qp.solve();
+    CHECK(qp.results.info.setup_time == 0 && qp.results.info.solve_time == 0 && qp.results.info.run_time == 0);
+    dense::QP<T> qt(dim, n_eq, n_in);
+    qt.settings.eps_abs = eps_abs;
+    qt.settings.compute_timings = true;
+    qt.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+    CHECK(qt.results.info.setup_time > 0);
+    qt.solve();
+    const auto& i = qt.results.info;
+    CHECK(i.setup_time > 0 && i.solve_time > 0 && i.solve_time < 60e6);
+    CHECK(std::fabs(i.run_time - (i.setup_time + i.solve_time)) <= 1e-9 * i.run_time);
+    qt.solve();
+    CHECK(qt.results.info.setup_time == 0 && qt.results.info.solve_time > 0 &&
+          qt.results.info.run_time == qt.results.info.solve_time);
+  }
+
+  // --- a NEW QP on a recycled registry slot starts from defaults (reference wrapper.hpp:140-333): neither the
+  // settings nor the model of the QP that owned the slot before may show through
+  {
+    const auto& m = models[0];
+    {
+      dense::QP<T> a(dim, n_eq, n_in);
+      a.settings.eps_abs = 1e-3;
+      a.settings.max_iter = 7;
+      a.settings.default_rho = 1e-2;
+      a.settings.initial_guess = InitialGuessStatus::WARM_START_WITH_PREVIOUS_RESULT;
+      a.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+      a.solve();
+    } // a dies: its slot goes back to the pool
+    dense::QP<T> fresh(dim, n_eq, n_in); // a slot nobody used
+    dense::QP<T> b(dim, n_eq, n_in);     // (one of the two sits on a's slot, whatever the pool layout)
+    for (dense::QP<T>* q : { &fresh, &b }) {
+      CHECK(q->settings.eps_abs == 1e-5);
+      CHECK(q->settings.max_iter == 10000);
+      CHECK(q->settings.default_rho == 1e-6);
+      CHECK(q->settings.initial_guess == InitialGuessStatus::EQUALITY_CONSTRAINED_INITIAL_GUESS);
+      CHECK(q->results.info.rho == 1e-6);
+      CHECK(q->results.info.mu_eq == 1e-3);
+      CHECK(q->results.info.status == QPSolverOutput::PROXQP_NOT_RUN);
+    }
+    // stale model arrays must not survive either: init with H and g only -> the unconstrained minimiser
+    // of THIS model, not a's constraints
+    dense::QP<T> c(dim, n_eq, n_in);
+    c.settings.eps_abs = eps_abs;
+    c.init(m.H, m.g, nullopt, nullopt, nullopt, nullopt, nullopt);
+    c.solve();
+    T worst = 0;
+    for (isize j = 0; j < dim; ++j) {
+      T r = m.g[j];
+      for (isize k = 0; k < dim; ++k)
+        r += m.H(j, k) * c.results.x[k];
+      worst = std::max(worst, std::fabs(r));
+    }
+    CHECK(worst <= 1e-7); // H x + g = 0: no stale A, C, l, u took part
+  }
+
+  // --- independent QP objects driven from several host threads (legal with the reference:
+  // `#pragma omp parallel for` over qps[i].solve()): same answers as the serial run
+  {
+    std::vector<dense::QP<T>> qs;
+    for (usize i = 0; i < 8; ++i) {
+      qs.emplace_back(dim, n_eq, n_in);
+      qs.back().settings.eps_abs = eps_abs;
+    }
+    std::vector<std::thread> th;
+    for (usize t = 0; t < 4; ++t)
+      th.emplace_back([&, t]() {
+        for (usize i = t; i < 8; i += 4) {
+          const auto& m = models[i % models.size()];
+          qs[i].init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+          qs[i].solve();
+        }
+      });
+    for (auto& t : th)
+      t.join();
+    for (usize i = 0; i < 8; ++i) {
+      const auto& m = models[i % models.size()];
+      dense::QP<T> ref(dim, n_eq, n_in);
+      ref.settings.eps_abs = eps_abs;
+      ref.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+      ref.solve();
+      for (isize j = 0; j < dim; ++j)
+        CHECK(qs[i].results.x[j] == ref.results.x[j]);
+      CHECK(qs[i].results.info.status == QPSolverOutput::PROXQP_SOLVED);
+    }
   }
 
   std::printf("facade_test: %d failure(s)\n", failures);

@@ -15,6 +15,7 @@
 #ifndef PQP_HIP_EMU_HPP
 #define PQP_HIP_EMU_HPP
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -163,7 +164,9 @@ clock64()
 inline long long
 wall_clock64()
 {
-  return clock64();
+  // a real clock (nanoseconds), so that the Info timings of the emulated kernels are ordered and non-zero
+  return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(
+           std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 inline double
 __fma_rn(double a, double b, double c)
@@ -315,12 +318,16 @@ hipSetDevice(int)
 }
 enum
 {
-  hipDeviceAttributeMultiprocessorCount = 63
+  hipDeviceAttributeMultiprocessorCount = 63,
+  hipDeviceAttributeWallClockRate = 10017
 };
 inline hipError_t
-hipDeviceGetAttribute(int* v, int, int)
+hipDeviceGetAttribute(int* v, int attr, int)
 {
-  *v = 1; // one "CU": every launch of more than three workgroups takes the throughput build of the C2 kernel
+  if (attr == hipDeviceAttributeWallClockRate)
+    *v = 1000000; // kHz: wall_clock64() of the emulator counts nanoseconds
+  else
+    *v = 1; // one "CU": every launch of more than three workgroups takes the throughput build of the C2 kernel
   return hipSuccess;
 }
 inline hipError_t

@@ -16,7 +16,7 @@ CSRC = ROOT / "proxsuite_amd" / "csrc"
 def _compile(out, libdir, libname, extra=()):
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), str(SRC), "-o",
            str(out), "-L", str(libdir), "-l" + libname, "-L", str(CSRC), "-lpqp_randqp",
-           "-Wl,-rpath," + str(libdir), "-Wl,-rpath," + str(CSRC)] + list(extra)
+           "-Wl,-rpath," + str(libdir), "-Wl,-rpath," + str(CSRC), "-pthread"] + list(extra)
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out

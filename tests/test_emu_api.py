@@ -72,3 +72,11 @@ def test_product_path_has_no_cpu_fallback():
             N.load()
     finally:
         N._lib = saved
+
+
+def test_timings_and_verbose(dense, randqp, capfd):
+    ac.case_timings_and_verbose(dense, randqp, capfd)
+
+
+def test_alias_package(dense):
+    ac.case_alias_package()

@@ -133,3 +133,11 @@ def test_primal_ldlt_engine_without_box(lib, oracle, randqp):
         b.close()
     for a, r in zip(out[0], out[1]):
         assert pc.close(a, r)
+
+
+def test_refinement_fallback(lib, oracle):
+    pc.case_refinement_fallback(lib, oracle, names=("QADLITTL", "QSHARE2B"))
+
+
+def test_schur_factor_identity(lib, randqp):
+    pc.case_schur_factor_identity(lib, randqp, n=30, ne=7, ni=30, B=8)

@@ -58,3 +58,11 @@ def test_qpfunction_backward(dense, device):
 def test_omp_get_max_threads(dense):
     from proxsuite_amd import proxqp
     assert proxqp.omp_get_max_threads() >= 256
+
+
+def test_timings_and_verbose(dense, randqp, capfd):
+    ac.case_timings_and_verbose(dense, randqp, capfd)
+
+
+def test_alias_package(dense):
+    ac.case_alias_package()

@@ -164,3 +164,16 @@ def test_primal_ldlt_engine(lib, oracle, randqp, dim, B):
     """DenseBackend::PrimalLDLT at benchmark/timings-dense-backend.cpp's shape (n_eq = n_in = 2 dim, box):
     256-thread (dim 20) and 512-thread (dim 100: 500 constraints) workgroups"""
     pc.case_primal_ldlt(lib, oracle, randqp, dim=dim, B=B)
+
+
+def test_refinement_fallback(lib, oracle):
+    """row a14 on the real device (the event counter needs the instrumented twin of the library)"""
+    from proxsuite_amd import _build
+    pc.case_refinement_fallback(lib, oracle, need_stats=False)
+    pc.case_refinement_fallback(N.NativeLib(_build.HIP_STATS_LIB), oracle, need_stats=True)
+
+
+def test_schur_factor_identity(lib, randqp):
+    """rows a10-a13: accuracy of the rank-1 edited inverse Schur factor as the MI355X leaves it, C2 shape"""
+    worst, edited = pc.case_schur_factor_identity(lib, randqp, 100, 50, 100, B=256)
+    print("max |W S W^T - D| / max|D| = %.2e over %d edited factors" % (worst, edited))

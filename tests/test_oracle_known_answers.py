@@ -140,10 +140,11 @@ def _closest_feasible_qp(oracle, dim, ne, ni, eps, verbose=False):
 
 def test_reference_primal_infeasibility_solving(oracle, randqp):
     """reference test/src/dense_qp_wrapper.cpp:7153-7215: 20 seeds of dim 20 pushed out of
-    feasibility, closest-feasible solving on; the reference's two acceptance lines.  19 seeds pass them;
-    seed 14 cannot under the reference's own update rules — see
-    test_seed14_is_a_fixed_point_of_the_reference_bcl_rule, which derives that outcome from the
-    reference's constants with plain numpy, without the oracle."""
+    feasibility, closest-feasible solving on; the reference's two acceptance lines.  19 seeds pass them.
+    Seed 14 falls into a cycle of the reference's BCL rule whose only exit is the safe guard; whether the
+    run converges after that exit depends on the phase of the cycle (11 phases of 15 do), and with the
+    default safe_guard the oracle sits in one of the 4 that do not -- derived, without the oracle, in
+    test_seed14_is_a_fixed_point_of_the_reference_bcl_rule."""
     import parity_cases as pc
     models, dim, ne, ni = pc.infeasible_family(randqp, range(20))
     eps = 1e-5
@@ -181,12 +182,22 @@ def test_seed14_is_a_fixed_point_of_the_reference_bcl_rule(oracle, randqp):
     (solver.hpp:616 with settings.hpp:218): bad step again, multipliers back to 0, mu cannot shrink: the
     SAME subproblem is solved again and again.  Both residuals are then exactly unchanged, so the cold-restart
     test `new >= old` (solver.hpp:1700-1712) fires, mu goes back to 1/1.1 with y = z = 0 still, and the
-    descent repeats with period 12 until the safe guard (info.iter > 1e4, solver.hpp:585) accepts every
-    step at mu = 0.09, which converges far too slowly to finish before max_iter.  The margin (0.1291 vs
-    0.1259) is 2.5 %, not a rounding tie: relative perturbations of the data up to 1e-3 do not change the
-    outcome.  The certificate of primal infeasibility, which would switch to the weighted residual, is a
-    factor 30 away from firing.  (With Ruiz row scaling on — the option off — the same instance solves in
-    9 outer iterations.)
+    descent repeats with period 12 (mu = 0.909, 0.0909, ..., 9.1e-8, then 1e-8 four times).  The margin
+    (0.1291 vs 0.1259) is 2.5 %, not a rounding tie: relative perturbations of the data up to 1e-3 do not
+    change it, and the certificate of primal infeasibility, which would switch to the weighted residual, is a
+    factor 30 away from firing.  (With Ruiz row scaling on -- the option off -- the same instance solves in 9
+    outer iterations.)
+
+    The ONLY exit from the cycle is the safe guard: once info.iter > safe_guard = 1e4 every step is accepted
+    (solver.hpp:585), the multipliers are kept and mu stays where the cycle was at that moment.  From a small
+    mu the method of multipliers then converges in a handful of iterations; from mu >= 1e-2 its linear rate
+    is far too slow for the remaining outer iterations.  Sweeping the guard over one period shows it: 11 of 15
+    consecutive phases end SOLVED within the reference test's acceptance lines, 4 end MAX_ITER_REACHED.  The
+    phase at the moment info.iter crosses 1e4 counts inner iterations at a stagnated iterate (one or two per
+    outer iteration, decided by `infty_norm(alpha * dw) < 1e-11`, solver.hpp:969), i.e. it is fixed by the last
+    bits: the oracle lands on mu = 0.0909 and fails the lines, the MI355X kernel lands on a small mu and passes
+    them (tests/parity_cases.py::case_closest_feasible accepts either, with the lines enforced on a SOLVED
+    run), and the reference binary's outcome on its own seed 14 is one of the two for the same reason.
     """
     import parity_cases as pc
     (H, g, A, b, C, l, u), = pc.infeasible_family(randqp, [14])[0]
@@ -215,6 +226,20 @@ def test_seed14_is_a_fixed_point_of_the_reference_bcl_rule(oracle, randqp):
     q.solve()
     assert abs(q.results.info.pri_res - pri_fixed_point) <= 1e-6 * pri_fixed_point
     assert np.max(np.abs(q.results.y)) == 0 and np.max(np.abs(q.results.z)) == 0
+    # --- the exit through the safe guard: outcome by phase of the 12-periodic cycle (one period = 15 values of
+    # info.iter, the stagnated outer iterations taking two inner ones)
+    outcomes = []
+    for guard in range(40, 55):
+        q = _closest_feasible_qp(oracle, dim, ne, ni, 1e-5)
+        q.settings.safe_guard, q.settings.max_iter = guard, 2500
+        q.init(H, g, A, b, C, l, u)
+        q.solve()
+        ok, pri, dua = _closest_feasible_acceptance(H, g, A, b, C, l, u, q.results.x, q.results.y, q.results.z, 1e-5)
+        st = q.results.info.status
+        assert (st == QPSolverOutput.PROXQP_SOLVED and ok) or (st == QPSolverOutput.PROXQP_MAX_ITER_REACHED and not ok)
+        assert ok == (q.results.info.mu_in < 5e-3), (guard, q.results.info.mu_in)  # decided by mu at the exit
+        outcomes.append(ok)
+    assert sum(outcomes) == 11 and len(outcomes) == 15
     # --- ... and leaves the option-off run alone (row scaling on): solved in 9 outer iterations
     q = _closest_feasible_qp(oracle, dim, ne, ni, 1e-5)
     q.settings.primal_infeasibility_solving = False
