@@ -282,10 +282,13 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     h->lpt = std::string(e) == "lpt";
   h->lds_solve = pqp::lds_bytes(d, h->nt);
   h->lds_setup = pqp::setup_lds_bytes(d, h->nt);
-  if (h->lds_solve > 160 * 1024) {
-    delete h;
-    return fail(PQP_ERR_UNSUPPORTED, "per-QP vector state exceeds the 160 KiB LDS of one CU");
-  }
+  // per-QP vector state beyond the 160 KiB of LDS of one CU (e.g. n = 760 with 837 constraint rows): the
+  // solver then runs with 1024 threads on a slice of HBM per workgroup (allocated below)
+  // (PQP_FORCE_HBM_VECTORS=1: any shape takes that path -- test hook: small problems through the large-shape kernel)
+  const char* force_hbm = std::getenv("PQP_FORCE_HBM_VECTORS");
+  const bool vectors_in_hbm = h->lds_solve > 160 * 1024 || (force_hbm && force_hbm[0] == '1');
+  if (vectors_in_hbm)
+    h->nt = 1024;
   const size_t B = size_t(batch_size), n = size_t(dim), ne = size_t(n_eq), ni = size_t(n_in),
                nc = size_t(d.nc), nd = size_t(d.nd);
   pqp::Batch& D = h->dev;
@@ -338,6 +341,14 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   ALLOC(D.dS, B * nd)
   ALLOC(D.act, B * nc)
   ALLOC(D.stats, B * size_t(pqp::ST_COUNT))
+  if (vectors_in_hbm) {
+    h->lds_solve = pqp::lds_bytes(d, h->nt);
+    h->lds_setup = pqp::setup_lds_bytes(d, h->nt);
+    if ((rc = dalloc(h, &h->vec_scratch, B * ((h->lds_solve + 7) / 8)))) {
+      pqp_batch_destroy(h);
+      return rc;
+    }
+  }
   ALLOC(h->d_order, B)
   ALLOC(h->d_settings, B)
   ALLOC(h->d_cmd, B)
@@ -760,6 +771,9 @@ pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const doubl
   const pqp::Dims& d = h->dev.d;
   if (first < 0 || count < 0 || first + count > h->dev.B)
     return fail(PQP_ERR_INVALID_ARGUMENT, "backward range outside the batch");
+  if (h->vec_scratch)
+    return fail(PQP_ERR_UNSUPPORTED, "compute_backward is not built for shapes whose per-QP vectors exceed the LDS of a "
+                                     "CU (n + constraint rows above ~1100): the forward solve is");
   if (d.box)
     return fail(PQP_ERR_UNSUPPORTED, "compute_backward is defined for QPs without box constraints "
                                      "(reference dense/compute_ECJ.hpp ignores them)");

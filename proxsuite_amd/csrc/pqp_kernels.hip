@@ -14,13 +14,23 @@
 #ifndef PQP_TU
 #define PQP_TU 0
 #endif
+//   9  pqp_solve_hbm_kernel<1024, .>  shapes whose per-QP vectors exceed the CU's 160 KiB of LDS: the
+//                                     SAME solver with its "LDS" pointers typed as global memory and
+//                                     carved out of a per-workgroup slice of an HBM scratch buffer (the
+//                                     workgroup barrier orders global accesses within a workgroup as it
+//                                     does LDS ones).  Slow per QP -- every vector access is an L1/L2 round
+//                                     trip -- but it removes the size ceiling below 1024 rows.
+#if PQP_TU == 9
+#define PQP_LDS __attribute__((address_space(1)))
+#define PQP_GLOBAL __attribute__((address_space(1)))
+#endif
 // 8 instead of 16 matrix loads in flight per lane in gemv for the 128-VGPR kernel (pqp_block.hpp)
 #if PQP_TU == 1 && !defined(PQP_GEMV_DEEP_256)
 #define PQP_GEMV_DEEP_256 0
 #endif
 // the translation units whose kernels run at 128 VGPRs per lane keep 4 instead of 8 MFMA k-steps of
 // operand loads in flight in the Z / G build (+2 % at C2 and C4, profiles/r02_ab_compiler_flags.txt)
-#if (PQP_TU == 1 || PQP_TU == 4 || PQP_TU == 8) && !defined(PQP_ZG_DEPTH)
+#if (PQP_TU == 1 || PQP_TU == 4 || PQP_TU == 8 || PQP_TU == 9) && !defined(PQP_ZG_DEPTH)
 #define PQP_ZG_DEPTH 4
 #endif
 #include "pqp_host.hpp"
@@ -80,6 +90,7 @@ int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
+int pqp_launch_solve_hbm(pqp_batch* h, bool common);
 
 #if PQP_TU_HAS(1)
 int
@@ -121,6 +132,36 @@ int
 pqp_launch_solve_1024(pqp_batch* h, bool common)
 {
   return common ? launch_solve<1024, PQP_WPS_1024, 1>(h) : launch_solve<1024, PQP_WPS_1024, 0>(h);
+}
+#endif
+
+#if PQP_TU == 9 || (PQP_TU == 0 && defined(PQP_EMULATED_MFMA))
+// (the single-translation-unit build exists for the CPU emulator only, where address spaces are plain
+// pointers: there the kernel below is the ordinary solver running on a heap slice)
+template<int NT, int WPS, int SPEC>
+__global__ __launch_bounds__(NT, WPS) void
+pqp_solve_hbm_kernel(pqp::Batch batch, long first, const int* __restrict__ order, double* scratch, long stride)
+{
+  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
+  pqp::solve_body<NT, SPEC>(batch, first + slot, (pqp::lptr)(scratch + (long)blockIdx.x * stride));
+}
+
+int
+pqp_launch_solve_hbm(pqp_batch* h, bool common)
+{
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
+  const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
+  const long stride = (long)((h->lds_solve + 7) / 8);
+  if (common)
+    hipLaunchKernelGGL((pqp_solve_hbm_kernel<1024, PQP_WPS_1024, 1>), dim3((unsigned)h->range_count), dim3(1024), 0,
+                       h->stream, h->dev, h->range_first, order, h->vec_scratch, stride);
+  else
+    hipLaunchKernelGGL((pqp_solve_hbm_kernel<1024, PQP_WPS_1024, 0>), dim3((unsigned)h->range_count), dim3(1024), 0,
+                       h->stream, h->dev, h->range_first, order, h->vec_scratch, stride);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  return PQP_OK;
 }
 #endif
 
@@ -285,6 +326,8 @@ pqp_launch_solve(pqp_batch* h)
   // SPEC = 1: no box constraints, dense Hessian, PrimalDualLDLT engine -- all known at compile time
   const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE &&
                       h->dev.d.backend != PQP_BACKEND_PRIMAL_LDLT;
+  if (h->vec_scratch) // per-QP vectors beyond the LDS of a CU: the solver runs on an HBM slice per workgroup
+    return pqp_launch_solve_hbm(h, common);
   switch (h->nt) {
     case 256:
       if (!common)

@@ -141,3 +141,11 @@ def test_refinement_fallback(lib, oracle):
 
 def test_schur_factor_identity(lib, randqp):
     pc.case_schur_factor_identity(lib, randqp, n=30, ne=7, ni=30, B=8)
+
+
+def test_vectors_in_hbm_path(lib, oracle, randqp, monkeypatch):
+    """shapes whose per-QP vectors exceed the 160 KiB of LDS run the solver on an HBM slice per workgroup
+    (pqp_solve_hbm_kernel, 1024 threads); PQP_FORCE_HBM_VECTORS sends a small batch down that path"""
+    monkeypatch.setenv("PQP_FORCE_HBM_VECTORS", "1")
+    pc.case_random_batch(lib, oracle, randqp, 30, 7, 9, B=2)
+    pc.case_box_constraints(lib, oracle, randqp, seeds=2)

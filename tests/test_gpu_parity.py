@@ -177,3 +177,11 @@ def test_schur_factor_identity(lib, randqp):
     """rows a10-a13: accuracy of the rank-1 edited inverse Schur factor as the MI355X leaves it, C2 shape"""
     worst, edited = pc.case_schur_factor_identity(lib, randqp, 100, 50, 100, B=256)
     print("max |W S W^T - D| / max|D| = %.2e over %d edited factors" % (worst, edited))
+
+
+def test_vectors_in_hbm_path(lib, oracle, randqp, monkeypatch):
+    """the large-shape kernel (per-QP vectors in HBM) on ordinary shapes, against the oracle"""
+    monkeypatch.setenv("PQP_FORCE_HBM_VECTORS", "1")
+    pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=64)
+    pc.case_random_batch(lib, oracle, randqp, 300, 40, 120, B=8)
+    pc.case_box_constraints(lib, oracle, randqp, seeds=8)
