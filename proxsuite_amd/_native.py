@@ -184,6 +184,19 @@ class Batch:
             raise IndexError(idx)
         return p.contents
 
+    def settings_table(self):
+        """All B settings records as ONE numpy structured array aliasing the handle's host memory (the records
+        are contiguous: `pqp_batch_settings(h, i)` is &settings[i]).  `tab["eps_abs"][:] = 1e-9` writes the field
+        of every QP at once -- what a per-QP Python loop costs milliseconds for at B = 2048."""
+        p = self.lib.L.pqp_batch_settings(self._h, 0)
+        arr = (pqp_settings * self.B).from_address(C.addressof(p.contents))
+        return np.frombuffer(arr, dtype=np.dtype(pqp_settings))
+
+    def set_all_settings(self, **fields):
+        tab = self.settings_table()
+        for k, v in fields.items():
+            tab[k][:] = v
+
     def _shapes(self, idx):
         pre = (self.B,) if idx < 0 else ()
         n, ne, ni = self.n, self.n_eq, self.n_in

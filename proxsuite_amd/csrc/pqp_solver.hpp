@@ -2612,35 +2612,11 @@ struct Solver
       s_dz2 += L.dz()[k] * L.dz()[k];
       s_dzz += L.dz()[k] * L.z()[k];
     }
-    // breakpoints (linesearch.hpp:378-391).  One thread per CONSTRAINT (nc <= NT by the choice of the
-    // workgroup size): a constraint has at most two breakpoints, and as rup <= si at most one of them is
-    // positive unless the iterate violates its lower bound -- so a thread's first live breakpoint is its
-    // `primary`, a second one its `secondary`, and the secondaries are only walked when some thread of
-    // the workgroup has one (their count rides in the reduction below).  The live lanes are then the
-    // first nc of the workgroup instead of being spread over 2 nc slots: at C2 two wavefronts instead of
-    // four walk the constraint list, at 200 box constraints one pass instead of two.
-    double my_alpha[2] = { -1.0, -1.0 };
-    double my_grad[2] = { 0.0, 0.0 };
-    int cnt = 0;
-    if ((int)threadIdx.x < nc) {
-      const int i = threadIdx.x;
-      const double cdx = L.Cdx()[i];
-      if (cdx != 0.) {
-        const double a_up = -L.rup()[i] / (cdx + MACHINE_EPS);
-        const double a_lo = -L.si()[i] / (cdx + MACHINE_EPS);
-        if (a_up > MACHINE_EPS)
-          my_alpha[cnt++] = a_up;
-        if (a_lo > MACHINE_EPS)
-          my_alpha[cnt++] = a_lo;
-      }
-    }
-    double n_secondary = (cnt == 2) ? 1.0 : 0.0;
     {
       // the ten coefficient sums in one barrier interval
-      double sv[11] = { s_dxHdx, s_adx2, s_dx2, s_e2, s_xHdx, s_errdx, s_adxres, s_eres, s_dz2, s_dzz, n_secondary };
+      double sv[10] = { s_dxHdx, s_adx2, s_dx2, s_e2, s_xHdx, s_errdx, s_adxres, s_eres, s_dz2, s_dzz };
       double mx[1] = { dwm };
-      R.template mixed<11, 1>(sv, mx);
-      n_secondary = sv[10];
+      R.template mixed<10, 1>(sv, mx);
       dw_max = mx[0];
       s_dxHdx = sv[0];
       s_adx2 = sv[1];
@@ -2660,26 +2636,35 @@ struct Solver
       a0 += info.mu_in * (1. - st.alpha_gpdal) * s_dz2;
       b0 += info.mu_in * (1. - st.alpha_gpdal) * s_dzz;
     }
-    // every breakpoint gets its own phi'(alpha) -- no sort, no sequential walk
+    // breakpoints (linesearch.hpp:378-391): every breakpoint gets its own thread and
+    // its own phi'(alpha) -- no sort, no sequential walk
     const double INF = __builtin_inf();
     sub_tic(ST_CYC_LS_EVAL);
     double first_pos_alpha = INF;
-    if (cnt > 0) {
-      double ai, bi;
-      ls_ineq_terms(my_alpha[0], ai, bi);
-      const double gr = (a0 + ai) * my_alpha[0] + (b0 + bi);
-      my_grad[0] = gr;
-      if (!(gr < 0))
-        first_pos_alpha = my_alpha[0];
-    }
-    if (PQP_UNLIKELY(n_secondary != 0.0)) { // uniform
-      if (cnt > 1) {
-        double ai, bi;
-        ls_ineq_terms(my_alpha[1], ai, bi);
-        const double gr = (a0 + ai) * my_alpha[1] + (b0 + bi);
-        my_grad[1] = gr;
-        if (!(gr < 0) && my_alpha[1] < first_pos_alpha)
-          first_pos_alpha = my_alpha[1];
+    double my_alpha[2] = { -1.0, -1.0 };
+    double my_grad[2] = { 0.0, 0.0 };
+    int cnt = 0;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      int t = threadIdx.x + rep * NT;
+      if (t < 2 * nc) {
+        int i = t >> 1;
+        double cdx = L.Cdx()[i];
+        double al = -1.0;
+        if (cdx != 0.) {
+          double num = (t & 1) ? L.si()[i] : L.rup()[i];
+          al = -num / (cdx + MACHINE_EPS);
+        }
+        if (al > MACHINE_EPS) {
+          double ai, bi;
+          ls_ineq_terms(al, ai, bi);
+          double gr = (a0 + ai) * al + (b0 + bi);
+          my_alpha[rep] = al;
+          my_grad[rep] = gr;
+          ++cnt;
+          if (!(gr < 0) && al < first_pos_alpha)
+            first_pos_alpha = al;
+        }
       }
     }
     count(ST_N_LS_BREAKPOINTS, cnt);

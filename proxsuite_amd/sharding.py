@@ -56,12 +56,16 @@ class ShardedBatch:
     def width(self):
         return self.n + self.n_eq + self.n_c + 2
 
-    def gather_device(self, group=None):
+    def gather_device(self, group=None, via_host=False):
         """The path's one collective, device-resident end to end: a device kernel packs
         (x, y, z, status, iter) of the local shard into one fp64 buffer on this rank's GPU
         (`pqp_batch_pack_results`), `all_gather_into_tensor` moves it over RCCL / xGMI, and the
         result -- a [world * per][width] ROCm tensor, shards padded to `per` rows -- stays on the
-        GPU.  No host copy, no numpy."""
+        GPU.  No host copy, no numpy.
+
+        `via_host=True` is the rehearsal form for a box with ONE GPU shared by all ranks (RCCL refuses two
+        ranks on one device): the same pack kernel, then the packed buffer crosses the process group on
+        the host (gloo) and the gathered batch goes back to the device."""
         import torch
         import torch.distributed as dist
         dev = torch.device("cuda", self.device)
@@ -70,6 +74,10 @@ class ShardedBatch:
         if self.local:
             with torch.cuda.device(dev):
                 self.batch.pack_results(buf, 0, self.local, stream=torch.cuda.current_stream(dev).cuda_stream)
+        if via_host:
+            host = torch.empty((self.world * per, self.width), dtype=torch.float64)
+            dist.all_gather_into_tensor(host, buf.cpu(), group=group)
+            return host.to(dev), per
         out = torch.empty((self.world * per, self.width), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(out, buf, group=group)
         return out, per

@@ -97,15 +97,11 @@ def _solve_batch(Q, p, A, b, G, l, u, eps, max_iter, infeasible):
     batch = _checkout(key)
     lease = _Lease(key, batch)
     rho = 5.0e-5
-    for i in range(nbatch):
-        st = batch.settings(i)
-        st.primal_infeasibility_solving = int(infeasible)
-        st.max_iter = max_iter
-        st.max_iter_in = 100
-        st.default_rho = rho
-        st.refactor_rho_threshold = rho  # no refactorization
-        st.eps_abs = eps
-        st.initial_guess = int(InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS)  # the default, restated for reused handles
+    # (one vectorised write per field over the handle's settings table: the per-QP Python loop cost ~5 ms at 2048 QPs)
+    batch.set_all_settings(primal_infeasibility_solving=int(infeasible), max_iter=max_iter, max_iter_in=100,
+                           default_rho=rho, refactor_rho_threshold=rho,  # no refactorization
+                           eps_abs=eps,
+                           initial_guess=int(InitialGuess.EQUALITY_CONSTRAINED_INITIAL_GUESS))  # (restated for reused handles)
     if dev.type == "cuda":
         # kernels go to the caller's stream; the model copies of init are blocking copies on the
         # null stream, which are ordered after torch's default stream -- only a side stream with
