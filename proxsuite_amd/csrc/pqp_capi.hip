@@ -280,6 +280,8 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   }
   if (const char* e = std::getenv("PQP_SCHEDULE"))
     h->lpt = std::string(e) == "lpt";
+  if (const char* e = std::getenv("PQP_SPLIT_SOLVE"))
+    h->split_solve = e[0] == '1';
   h->lds_solve = pqp::lds_bytes(d, h->nt);
   h->lds_setup = pqp::setup_lds_bytes(d, h->nt);
   // per-QP vector state beyond the 160 KiB of LDS of one CU (e.g. n = 760 with 837 constraint rows): the

@@ -52,6 +52,7 @@ struct pqp_batch
   float last_ms = 0.f;
   bool solve_in_flight = false; // ev1 recorded, elapsed time not read yet (asynchronous solves)
   hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
+  bool split_solve = false; // device-filling launches of the C2 kernel run as prepare + iterate kernels (PQP_SPLIT_SOLVE)
   double* vec_scratch = nullptr; // non-null: per-QP vectors live in HBM (B slices of lds_solve bytes), see pqp_kernels.hip TU 9
   long range_first = 0, range_count = 0;
   long setup_first = 0, setup_count = 0; // QPs with a queued init / update / cleanup command

@@ -979,7 +979,15 @@ schur_factor_blocked(cgptr G, gptr LS, gptr WS, int nd, int rr, int ne, double m
 // SPEC = 1 compiles the solver for the commonest signature -- no box constraints, dense Hessian --
 // with those two switches as compile-time constants (the box / diagonal / zero-Hessian branches and
 // the scalars that feed them disappear from the hot kernel); SPEC = 0 keeps them at run time.
-template<int NT, int SPEC = 0>
+// PART splits one solve over two kernels (pqp_kernels.hip: pqp_prepare_kernel / pqp_iterate_kernel):
+//   0  the whole of qp_solve in one kernel;
+//   1  only the model-dependent heavy work of the prologue -- re-application of the equilibration of a dirty
+//      re-solve, factorisation of the primal block, W = L^{-1}, Z and G (everything factor_primal_block leaves
+//      in HBM) -- decided by the same state machine, WITHOUT touching results, Info or the workspace flags;
+//   2  the rest: the same prologue logic with those phases skipped (D of the primal block reloaded from HBM),
+//      then the iteration.  Without the factorisation / matrix-core code inlined beside it, the iteration kernel
+//      spills half as many registers (profiles/r03_kernel_resources.json).
+template<int NT, int SPEC = 0, int PART = 0>
 struct Solver
 {
   __device__ __forceinline__ bool has_box() const { return SPEC == 1 ? false : (d.box != 0); }
@@ -3155,7 +3163,7 @@ struct Solver
       }
     }
     __syncthreads();
-    if (do_rescale) {
+    if (PART != 2 && do_rescale) {
       // re-apply the stored equilibration (solver.hpp:1192-1214); u, l unclamped
       tic();
       lptr S = L.rd(); // scratch of ntot doubles: rd, ed, sd, dS, t2 (4 nd + max(n, nd)) are free here
@@ -3184,7 +3192,12 @@ struct Solver
         L.stat()[ST_CYC_FACTOR_H] -= clock64();
 #endif
       tic();
-      factor_primal_block();
+      if constexpr (PART != 2) {
+        factor_primal_block();
+      } else {
+        vload(L.dF(), P.dF(), n); // (the prepare kernel of this launch left F, W, Z, G and D in HBM)
+        __syncthreads();
+      }
 #ifdef PQP_STATS
       if (threadIdx.x == 0)
         L.stat()[ST_CYC_FACTOR_H] += clock64();
@@ -3195,6 +3208,8 @@ struct Solver
       r = ne;
       schur_dirty = true;
     }
+    if constexpr (PART == 1)
+      return; // prepare kernel: nothing of the QP's state (results, Info, flags) has been written
     if (do_restore) {
       // WARM_START_WITH_PREVIOUS_RESULT on an unchanged model: reuse the block
       // factorisation the previous solve left in HBM (solver.hpp:1173-1187, 1343-1375)
@@ -3750,11 +3765,11 @@ backward_body(const Batch& batch, const BackwardArgs& bw, long slot, lptr lds_ba
   S.backward(bw, slot);
 }
 
-template<int NT, int SPEC>
+template<int NT, int SPEC, int PART = 0>
 __device__ __forceinline__ void
 solve_body(const Batch& batch, long q, lptr lds_base)
 {
-  Solver<NT, SPEC> S(batch, q, lds_base);
+  Solver<NT, SPEC, PART> S(batch, q, lds_base);
   S.solve();
 }
 
