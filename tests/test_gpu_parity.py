@@ -124,15 +124,16 @@ def test_full_size_c2_all_against_oracle(lib, oracle, randqp):
 
 
 def test_full_shape_c4_against_oracle(lib, oracle, randqp):
-    """BASELINE.json configs[3] at its real shape (512, 200, 400): 1024-thread workgroups."""
-    pc.case_c4_shape(lib, oracle, randqp, B=8)
+    """BASELINE.json configs[3] at its real shape (512, 200, 400): 1024-thread workgroups, 64 QPs, every one
+    against the oracle (solutions to 1e-10, Info counters equal)."""
+    pc.case_c4_shape(lib, oracle, randqp, B=64)
 
 
 @pytest.mark.parametrize("box", [False, True])
 def test_full_shape_c5_against_oracle(lib, oracle, randqp, box):
     """BASELINE.json configs[4] (n = 200, diagonal Hessian, 200 bound pairs) at a batch that fills
-    the GPU (768 = 3 workgroups x 256 CUs), both forms; 32 QPs against the oracle, all KKT-gated."""
-    pc.case_c5(lib, oracle, randqp, B=768, sample=32, box=box)
+    the GPU (768 = 3 workgroups x 256 CUs), both forms; every QP against the oracle and KKT-gated."""
+    pc.case_c5(lib, oracle, randqp, B=768, sample=768, box=box)
 
 
 def test_infeasibility_statuses(lib, oracle):
