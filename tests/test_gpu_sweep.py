@@ -1,0 +1,20 @@
+"""`-m gpu`: the randomised robustness sweep as a test (tests/parity_cases.py::case_random_sweep): random shapes x
+{box constraints, Dense / Diagonal Hessian, the three DenseBackend values} x {cold solve, update(g) + warm
+re-solve on the restored, edited Schur factor}.  0 failures; every SOLVED QP carries the oracle's Info
+counters; the infeasible instances whose two sides end with different non-SOLVED statuses stay a small
+fraction of the unsolved ones (measured: 16 of 660 over three seeds, profiles/r03_random_sweep.log)."""
+import pytest
+
+import parity_cases as pc
+from proxsuite_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_sweep(oracle, randqp, seed):
+    r = pc.case_random_sweep(N.load(), oracle, randqp, seed, 60)
+    assert r["failures"] == 0, r
+    assert r["info_mismatch"] == 0, r
+    assert r["solved"] >= 150, r
+    assert r["forks"] <= max(3, 0.08 * (r["unsolved_alike"] + r["forks"])), r
