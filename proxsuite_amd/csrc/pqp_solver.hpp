@@ -108,6 +108,8 @@ struct State
   int n_slots;      // inequality slots of that factor (n_c live ones + the holes deletions left)
   int c_diag;       // C has no off-diagonal entry and n_in == dim (e.g. bounds passed as C = I): set by init / update
   int ls_edited;    // that factor has taken rank-1 edits since its last full factorisation (refinement fallback, solver.hpp:474-532)
+  int scaled_valid; // H_s, A_s, C_s (both orientations) in HBM are the equilibrated model: written by init / update, read-only afterwards
+  int _pad2;
   double ruiz_c;
   double dual_feasibility_rhs_2;
   double correction_guess_rhs_g;
@@ -537,7 +539,7 @@ work_cleanup_flags(State& w)
 // ---------------------------------------------------------------------------
 template<int NT>
 __device__ PQP_CALL void
-write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool diag_only = false)
+write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool diag_only = false, bool matrices = true)
 {
   const QpRef P(batch, q);
   const Dims& d = batch.d;
@@ -546,7 +548,12 @@ write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool dia
   clptr Se = S + n;
   clptr Si = S + n + ne;
   clptr Sb = S + n + ne + ni;
-  if (diag_only) {
+  // matrices == false: only the equilibrated VECTORS are rewritten.  The scaled matrices are a function of
+  // (model, delta, c) alone, nothing ever modifies them between two set-ups, and a dirty re-solve re-applies the
+  // SAME stored equilibration (solver.hpp:1192-1214): the copies init / update left in HBM are already the
+  // bits this pass would write.  The vectors differ (the re-solve takes u, l unclamped).
+  if (!matrices) {
+  } else if (diag_only) {
     // diagonal structure (see Solver::dm): only the diagonals of H and C carry information; the
     // dense copies keep the zeros the init-time pass wrote, the compact ones feed the solver
     cgptr H = P.H();
@@ -926,6 +933,7 @@ setup_body(const Batch& batch, long q, lptr lds_base)
     if (threadIdx.x == 0) {
       W.correction_guess_rhs_g = m;
       W.ruiz_c = c;
+      W.scaled_valid = 1;
       if (is_init)
         W.is_initialized = 1;
       if (st.compute_timings) // wrapper.hpp:495-497, 804-806: microseconds spent in init / update
@@ -987,6 +995,12 @@ schur_factor_blocked(cgptr G, gptr LS, gptr WS, int nd, int rr, int ne, double m
 //   2  the rest: the same prologue logic with those phases skipped (D of the primal block reloaded from HBM),
 //      then the iteration.  Without the factorisation / matrix-core code inlined beside it, the iteration kernel
 //      spills half as many registers (profiles/r03_kernel_resources.json).
+#ifndef PQP_HESS_LOWER
+#define PQP_HESS_LOWER 0 // 1: 256-thread kernels take H_s v from the lower triangle of H_s only (symv_lower, half the bytes
+                         // of a pass).  Measured SLOWER in round 2 and again in round 3 (profiles/r03_ab_hess_lower.txt: C2 8.32
+                         // -> 8.55 ms, C1 1.33 -> 1.40 ms, 8192 QPs 299 k -> 294 k QPs/s): the triangular rows unbalance the
+                         // wavefronts and the masked FMAs cost more than the 40 KB they save.  Off.
+#endif
 template<int NT, int SPEC = 0, int PART = 0>
 struct Solver
 {
@@ -1135,12 +1149,17 @@ struct Solver
     const int v = L.act()[k < 0 ? 0 : k];
     return (k < 0) ? a : d.n_eq + v;
   }
-  // out = H_s v for the dense H_s.  (A lower-triangle-only variant of gemv_dual halves the
-  // bytes but measured SLOWER at C2: 1.00 M vs 0.87 M cycles per QP in the KKT residual; the
-  // triangular rows unbalance the wavefronts and the plain gemv keeps 16 loads per lane in flight.)
+  // out = H_s v for the dense H_s (PQP_HESS_LOWER selects the triangle-only pass, see above)
+  // elements of H_s one hess_mv pass reads (engine byte counter)
+  __device__ __forceinline__ long hess_pass_elems() const
+  {
+    return (NT == 256 && PQP_HESS_LOWER) ? (long)d.n * (d.n + 1) / 2 : (long)d.n * d.n;
+  }
   __device__ __forceinline__ void hess_mv(clptr v, lptr out)
   {
-    if constexpr (NT == 256) // column sums of the symmetric H_s = H_s v, with 16-byte loads
+    if constexpr (NT == 256 && PQP_HESS_LOWER) // the lower triangle of the symmetric H_s only: half the bytes of a pass
+      symv_lower<NT>(P.Hs(), d.n, d.n, v, out, L.part());
+    else if constexpr (NT == 256) // column sums of the symmetric H_s = H_s v, with 16-byte loads
       gemv_dual<NT, true, false, false>(P.Hs(), d.n, d.n, d.n, v, v, out, out, L.part());
     else
       mv(P.Hs(), d.n, d.n, d.n, v, out);
@@ -2099,7 +2118,7 @@ struct Solver
     zero_holes(L.ed());
     {
       const long mats = (NT == 256) ? 1 : 2; // one pass over A_s / C_s, or A_s and its transpose
-      bytes((((hess() == PQP_HESSIAN_DENSE) ? (long)n * n : (long)n) +
+      bytes((((hess() == PQP_HESSIAN_DENSE) ? hess_pass_elems() : (long)n) +
              (dm() ? (long)ni : mats * ((long)ne * n + (long)ni * n))) * 8);
     }
     return nrm;
@@ -2444,7 +2463,7 @@ struct Solver
         L.t1()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? (dm() ? hd[k] : Hs[(long)k * n + k]) * L.x()[k] : 0.0;
     }
     const bool have_products = aty_fresh; // A^T y, C^T z left by global_primal_residual
-    bytes(((hess() == PQP_HESSIAN_DENSE ? (long)n * n : (long)n) + (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
+    bytes(((hess() == PQP_HESSIAN_DENSE ? hess_pass_elems() : (long)n) + (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
     if (!have_products) {
       if (ne > 0)
         mv(P.As(), n, ne, n, L.y(), L.t2());
@@ -3169,9 +3188,11 @@ struct Solver
       lptr S = L.rd(); // scratch of ntot doubles: rd, ed, sd, dS, t2 (4 nd + max(n, nd)) are free here
       vload(S, P.delta(), d.ntot);
       __syncthreads();
-      write_scaled<NT>(batch, q, S, ruiz_c, false, dm());
+      const bool rewrite_matrices = W.scaled_valid == 0; // (never after an init / update: see write_scaled)
+      write_scaled<NT>(batch, q, S, ruiz_c, false, dm(), rewrite_matrices);
       // H, A, C read; H_s, A_s, A_s^T, C_s, C_s^T written (diagonal structure: the two diagonals)
-      bytes(dm() ? ((long)n * 3 + (long)ni * 3) * 8 : ((long)n * n * 2 + 3L * ne * n + 3L * ni * n) * 8);
+      if (rewrite_matrices)
+        bytes(dm() ? ((long)n * 3 + (long)ni * 3) * 8 : ((long)n * n * 2 + 3L * ne * n + 3L * ni * n) * 8);
       toc(ST_CYC_SCALE);
     }
     vload(L.gs(), P.gs(), n);
