@@ -1040,6 +1040,7 @@ struct Solver
   bool schur_dirty;       // the factor does not describe (active set, mu): re-factorise
   bool schur_incremental; // rows were appended / deleted since the last full factorisation
   bool aty_fresh; // L.ATdy / L.CTdz hold A^T y, C^T z of the current iterate (see global_primal_residual)
+  bool iterate_zero; // x = y = z = 0 exactly (NO_INITIAL_GUESS before the first Newton loop): A x, C x, H x, A^T y, C^T z are zero vectors
   UD ruiz_c;
   UD dual_feasibility_rhs_2;
   bool nonfinite;
@@ -1061,6 +1062,7 @@ struct Solver
     schur_dirty = true;
     schur_incremental = false;
     diag_mode = false;
+    iterate_zero = false;
   }
   __device__ __forceinline__ void set_diag_mode(const State& W)
   {
@@ -2354,6 +2356,14 @@ struct Solver
       }
       aty_fresh = true;
       __syncthreads();
+    } else if (iterate_zero) {
+      // (the products of a zero iterate: no pass over A_s / C_s)
+      vzero(L.se(), ne);
+      vzero(L.rup(), ni);
+      vzero(L.ATdy(), n);
+      vzero(L.CTdz(), n);
+      aty_fresh = true;
+      __syncthreads();
     } else if constexpr (NT == 256) {
       // one pass over A_s and C_s: the row sums are A x / C x; the column sums A^T y / C^T z are
       // what global_dual_residual needs at this same iterate, parked in the Newton by-product
@@ -2409,7 +2419,8 @@ struct Solver
         m_in0 = fmax(m_in0, fabs(L.x()[k]));      // utils.hpp:230-231
       }
     }
-    bytes(dm() ? (long)ni * 8 : ((long)ne * n + (long)ni * n) * 8);
+    if (!iterate_zero)
+      bytes(dm() ? (long)ni * 8 : ((long)ne * n + (long)ni * n) * 8);
     {
       double none[1] = { 0.0 };
       double mv[4] = { m_eq0, m_in0, m_eql, m_inl };
@@ -2454,7 +2465,9 @@ struct Solver
     double xHx = 0, gx = 0;
     // H x -> t1, A^T y -> ATdy-free scratch (t2), C^T z -> CTzin-free... use t1/t2/zfull? keep
     // three distinct n-vectors: t1, t2 and ex (free outside the Newton loop)
-    if (hess() == PQP_HESSIAN_DENSE) {
+    if (iterate_zero) {
+      vzero(L.t1(), n); // H 0
+    } else if (hess() == PQP_HESSIAN_DENSE) {
       hess_mv(L.x(), L.t1());
     } else {
       cgptr Hs = P.Hs();
@@ -2463,7 +2476,8 @@ struct Solver
         L.t1()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? (dm() ? hd[k] : Hs[(long)k * n + k]) * L.x()[k] : 0.0;
     }
     const bool have_products = aty_fresh; // A^T y, C^T z left by global_primal_residual
-    bytes(((hess() == PQP_HESSIAN_DENSE ? hess_pass_elems() : (long)n) + (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
+    bytes(((iterate_zero ? 0L : (hess() == PQP_HESSIAN_DENSE ? hess_pass_elems() : (long)n)) +
+           (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
     if (!have_products) {
       if (ne > 0)
         mv(P.As(), n, ne, n, L.y(), L.t2());
@@ -3289,6 +3303,17 @@ struct Solver
     // they leave behind) still describe the current iterate.
     bool gpr_fresh = false, gdr_fresh = false;
     aty_fresh = false;
+    {
+      // an all-zero iterate (NO_INITIAL_GUESS: the first residual evaluations) needs no pass over H_s, A_s, C_s
+      double mz = 0;
+      for (int k = threadIdx.x; k < n; k += NT)
+        mz = fmax(mz, fabs(L.x()[k]));
+      for (int k = threadIdx.x; k < ne; k += NT)
+        mz = fmax(mz, fabs(L.y()[k]));
+      for (int k = threadIdx.x; k < nc; k += NT)
+        mz = fmax(mz, fabs(L.z()[k]));
+      iterate_zero = !dm() && R.max(mz) == 0.0;
+    }
     UD pl_cache = 0, dl_cache = 0;
     while (!done) {
       tic();
@@ -3416,6 +3441,7 @@ struct Solver
           info.rho_updates = uni((long)pk[k++]);
         }
 #undef PQP_PARKED
+        iterate_zero = false;
         gpr_fresh = false; // x, y, z moved; the shifted rup / si were consumed
         gdr_fresh = false;
         aty_fresh = false; // (and the Newton loop reused the vectors they were parked in)
