@@ -39,6 +39,7 @@ compute_backward(QP<T>& solved_qp, VecRef<T> loss_derivative, T eps = 1.E-4, T r
       tmp[usize(i)] = loss_derivative[i];
     p = tmp.data();
   }
+  detail::PoolLock lock(solved_qp.pool()->mtx); // (the pool's handle is shared with the other QPs of the pool)
   solved_qp.push_settings();
   detail::check(pqp_batch_backward_range(solved_qp.pool()->h, solved_qp.slot(), 1, p, eps, rho_new, mu_new));
   detail::pull_backward(solved_qp);

@@ -26,6 +26,7 @@ solve_in_parallel(BatchQP<T>& qps, const optional<usize> /*num_threads*/ = nullo
     const detail::Pool& p = *e.pool;
     if (p.used == 0)
       continue;
+    detail::PoolLock lock(p.mtx); // (another thread may be driving a standalone QP of this pool)
     for (isize idx : e.members)
       qps[idx].push_settings();
     detail::check(pqp_batch_solve_range(p.h, 0, p.used));
@@ -65,6 +66,7 @@ solve_in_parallel(std::vector<QP<T>>& qps, const optional<usize> /*num_threads*/
     groups[qps[i].pool().get()].push_back(i);
   for (auto& kv : groups) {
     const detail::Pool& p = *kv.first;
+    detail::PoolLock lock(p.mtx);
     std::vector<int64_t> idx;
     idx.reserve(kv.second.size());
     for (usize i : kv.second) {
@@ -109,6 +111,7 @@ qp_solve_backward_in_parallel(optional<const usize> /*num_threads*/, BatchQP<T>&
     const detail::Pool& p = *e.pool;
     if (p.used == 0)
       continue;
+    detail::PoolLock lock(p.mtx);
     const usize ntot = usize(p.dim + p.n_eq + p.n_in);
     std::vector<T> ld(usize(p.used) * ntot);
     for (usize s = 0; s < e.members.size(); ++s) {
