@@ -594,12 +594,18 @@ gemv(cgptr M, int ld, int K, int J, clptr v, lptr out, lptr part, cliptr rowmap,
 // rows per step, each lane keeps the 8 column accumulators of its 16-column stripes; columns
 // beyond 128 are handled in further blocks of 128.  Row sums close with four DPP row shifts
 // inside the 16-lane group, column sums with two across the groups and an LDS pass across the
-// wavefronts.  `part`: gemv_dual_part_len() doubles of LDS.  v, w must not alias the outputs.
-// Two barriers with COLS, one otherwise.  (The column pass is a template flag and not a null
+// wavefronts, block of 128 columns by block.  `part`: gemv_dual_part_len() doubles of LDS.  v, w must not alias
+// the outputs.  Two barriers per column block with COLS, one in all otherwise.  (The column pass is a template flag and not a null
 // test of w: LDS offset 0 is a valid address -- the first vector of the carve-up lives there.)
 // ---------------------------------------------------------------------------
 __host__ __device__ inline int
 gemv_dual_part_len(int nt, int n)
+{
+  return (nt / WAVE) * (n < 128 ? n : 128);
+}
+// (symv_lower keeps its partial column sums of ALL column blocks until one closing pass)
+__host__ __device__ inline int
+symv_lower_part_len(int nt, int n)
 {
   return (nt / WAVE) * n;
 }
@@ -726,6 +732,8 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
       }
     }
     if (COLS) {
+      // the column sums of this block meet across the wavefronts (the scratch is reused by the next block)
+      const int bw = (n - c0 < 128) ? (n - c0) : 128;
 #pragma unroll
       for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -733,23 +741,23 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
           double a = acc[c][e];
           a += __shfl_xor(a, 16);
           a += __shfl_xor(a, 32);
-          const int col = c0 + 16 * W * c + W * s + e;
-          if (g == 0 && col < n)
-            part[wid * n + col] = a;
+          const int cb = 16 * W * c + W * s + e;
+          if (g == 0 && cb < bw)
+            part[wid * bw + cb] = a;
         }
+      __syncthreads();
+      for (int j = threadIdx.x; j < bw; j += NT) {
+        double a = part[j];
+#pragma unroll
+        for (int q = 1; q < NW; ++q)
+          a += part[q * bw + j];
+        colout[c0 + j] = (epi == EPI_COL_SUBDIV) ? (ea[c0 + j] - a) / eb[c0 + j] : a;
+      }
+      if (c0 + 128 < n)
+        __syncthreads();
     }
   }
   __syncthreads();
-  if (COLS) {
-    for (int j = threadIdx.x; j < n; j += NT) {
-      double a = part[j];
-#pragma unroll
-      for (int q = 1; q < NW; ++q)
-        a += part[q * n + j];
-      colout[j] = (epi == EPI_COL_SUBDIV) ? (ea[j] - a) / eb[j] : a;
-    }
-    __syncthreads();
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -758,7 +766,7 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
 // sums over the triangle including the diagonal plus the column sums over the strict triangle, in ONE pass with
 // the lane layout of gemv_dual (16 lanes share a row, W doubles per lane and load).  A 16 W-column stripe of a
 // row step is loaded only if some row of that wavefront's step reaches it (wave-uniform test); elements beyond the
-// diagonal inside a loaded stripe are masked.  `part`: gemv_dual_part_len() doubles.  v must not alias out.
+// diagonal inside a loaded stripe are masked.  `part`: symv_lower_part_len() doubles.  v must not alias out.
 // ---------------------------------------------------------------------------
 template<int NT, int W>
 __device__ __forceinline__ void

@@ -278,12 +278,29 @@ struct Lds
   __device__ __forceinline__ liptr chg() const { return ints(3 * nc + nd + nt / WAVE + 16); }
 };
 
-// `part`: cross-wavefront scratch of gemv, and of gemv_dual where that routine is used (the
-// 256-thread kernels: NW * n doubles; the wider workgroups keep the gemv pair)
+#ifndef PQP_HESS_LOWER
+#define PQP_HESS_LOWER 0 // 1: 256-thread kernels take H_s v from the lower triangle of H_s only (symv_lower, half the bytes
+                         // of a pass).  Measured SLOWER in round 2 and again in round 3 (profiles/r03_ab_hess_lower.txt: C2 8.32
+                         // -> 8.55 ms, C1 1.33 -> 1.40 ms, 8192 QPs 299 k -> 294 k QPs/s): the triangular rows unbalance the
+                         // wavefronts and the masked FMAs cost more than the 40 KB they save.  Off.
+#endif
+// One pass over A_s / C_s per product pair (gemv_dual) in the kernels of every width; 0 keeps the gemv pair over
+// the matrix and its transposed copy in the 512- / 1024-thread kernels (A/B switch).
+#ifndef PQP_DUAL_WIDE
+#define PQP_DUAL_WIDE 1
+#endif
+__host__ __device__ constexpr bool
+dual_pass(int nt)
+{
+  return nt == 256 || PQP_DUAL_WIDE;
+}
+
+// `part`: cross-wavefront scratch of gemv and of gemv_dual (NW * min(n, 128) doubles)
 __host__ __device__ inline int
 part_doubles(int nt, int tmax, int n)
 {
-  const int a = gemv_part_len(nt, tmax), b = (nt == 256) ? gemv_dual_part_len(nt, n) : 0;
+  const int a = gemv_part_len(nt, tmax);
+  const int b = !dual_pass(nt) ? 0 : (nt == 256 && PQP_HESS_LOWER) ? symv_lower_part_len(nt, n) : gemv_dual_part_len(nt, n);
   return a > b ? a : b;
 }
 
@@ -995,12 +1012,6 @@ schur_factor_blocked(cgptr G, gptr LS, gptr WS, int nd, int rr, int ne, double m
 //   2  the rest: the same prologue logic with those phases skipped (D of the primal block reloaded from HBM),
 //      then the iteration.  Without the factorisation / matrix-core code inlined beside it, the iteration kernel
 //      spills half as many registers (profiles/r03_kernel_resources.json).
-#ifndef PQP_HESS_LOWER
-#define PQP_HESS_LOWER 0 // 1: 256-thread kernels take H_s v from the lower triangle of H_s only (symv_lower, half the bytes
-                         // of a pass).  Measured SLOWER in round 2 and again in round 3 (profiles/r03_ab_hess_lower.txt: C2 8.32
-                         // -> 8.55 ms, C1 1.33 -> 1.40 ms, 8192 QPs 299 k -> 294 k QPs/s): the triangular rows unbalance the
-                         // wavefronts and the masked FMAs cost more than the 40 KB they save.  Off.
-#endif
 template<int NT, int SPEC = 0, int PART = 0>
 struct Solver
 {
@@ -1161,7 +1172,7 @@ struct Solver
   {
     if constexpr (NT == 256 && PQP_HESS_LOWER) // the lower triangle of the symmetric H_s only: half the bytes of a pass
       symv_lower<NT>(P.Hs(), d.n, d.n, v, out, L.part());
-    else if constexpr (NT == 256) // column sums of the symmetric H_s = H_s v, with 16-byte loads
+    else if constexpr (dual_pass(NT)) // column sums of the symmetric H_s = H_s v, with 16-byte loads
       gemv_dual<NT, true, false, false>(P.Hs(), d.n, d.n, d.n, v, v, out, out, L.part());
     else
       mv(P.Hs(), d.n, d.n, d.n, v, out);
@@ -2024,7 +2035,7 @@ struct Solver
       schur_apply(bd);
       toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
-      if constexpr (NT == 256) {
+      if constexpr (dual_pass(NT)) {
         // t1 <- (t1 - Z_J^T dvec) / D in the epilogue of the column sums
         gemv_dual<NT, true, true, false>(P.Zr(), n, rr, n, bd, bd, L.t1(), L.t1(), L.part(), L.act(), d.n_eq,
                                          EPI_COL_SUBDIV, L.t1(), L.dF());
@@ -2061,7 +2072,7 @@ struct Solver
         L.Hdx()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? (dm() ? hd[k] : Hs[(long)k * n + k]) * L.dx()[k] : 0.0;
     }
     if (ne > 0) {
-      if constexpr (NT == 256) {
+      if constexpr (dual_pass(NT)) {
         // A is read ONCE: row sums give A dx, column sums A^T dy
         gemv_dual<NT>(P.As(), n, ne, n, L.dx(), L.sd(), L.Adx(), L.ATdy(), L.part());
       } else {
@@ -2079,7 +2090,7 @@ struct Solver
         L.CTdz()[k] = ck * L.zfull()[k];
       }
     } else if (ni > 0) {
-      if constexpr (NT == 256) {
+      if constexpr (dual_pass(NT)) {
         gemv_dual<NT>(P.Cs(), n, ni, n, L.dx(), L.zfull(), L.Cdx(), L.CTdz(), L.part());
       } else {
         mv(P.Cs(), n, ni, n, L.zfull(), L.CTdz());
@@ -2119,7 +2130,7 @@ struct Solver
     const double nrm = R.max(m);
     zero_holes(L.ed());
     {
-      const long mats = (NT == 256) ? 1 : 2; // one pass over A_s / C_s, or A_s and its transpose
+      const long mats = dual_pass(NT) ? 1 : 2; // one pass over A_s / C_s, or A_s and its transpose
       bytes((((hess() == PQP_HESSIAN_DENSE) ? hess_pass_elems() : (long)n) +
              (dm() ? (long)ni : mats * ((long)ne * n + (long)ni * n))) * 8);
     }
@@ -2364,7 +2375,7 @@ struct Solver
       vzero(L.CTdz(), n);
       aty_fresh = true;
       __syncthreads();
-    } else if constexpr (NT == 256) {
+    } else if constexpr (dual_pass(NT)) {
       // one pass over A_s and C_s: the row sums are A x / C x; the column sums A^T y / C^T z are
       // what global_dual_residual needs at this same iterate, parked in the Newton by-product
       // vectors (idle between Newton loops) and flagged by `aty_fresh`
