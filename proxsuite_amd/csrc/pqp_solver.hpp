@@ -38,6 +38,15 @@ constexpr double MACHINE_EPS = 2.220446049250313e-16;
 #define PQP_ZG_DEPTH 8
 #endif
 constexpr int ZG_DEPTH = PQP_ZG_DEPTH; // MFMA k-steps (of 4) whose operand loads are in flight together in build_ZG
+// 512- / 1024-thread kernels: build_ZG works on 2 x 2 tiles per wavefront (four operand tiles feed four products: a
+// third less operand traffic than the 1 x 2 units of the 256-thread kernels, whose matrices mostly sit in L2)
+#ifndef PQP_ZG_BLOCK2
+#define PQP_ZG_BLOCK2 1
+#endif
+#ifndef PQP_ZG2_DEPTH
+#define PQP_ZG2_DEPTH 4
+#endif
+constexpr int ZG2_DEPTH = PQP_ZG2_DEPTH;
 constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * SCHUR_MB rows
 // `top`: LDS scratch of the factorisation routines (ldlt_factor_mfma: 2 * 256 + 32 doubles;
 // ldlt_factor_reg: 4 * 16 * MB; ldlt_inverse_reg: 6 * 16 * MB)
@@ -1278,6 +1287,85 @@ struct Solver
       // work unit = one 16-row block of Z times TWO adjacent 16-column blocks: the W operand is
       // loaded once for both, and every batch keeps 3 * ZG_DEPTH loads in flight per lane
       const int KT = (n + 15) / 16, CT = (nb + 15) / 16, CP = (CT + 1) / 2;
+      if constexpr (NT >= 512 && PQP_ZG_BLOCK2) {
+        // 2 x 2: two 16-row blocks of Z (k) times two 16-column blocks (c)
+        const int KP = (KT + 1) / 2;
+        for (int t = w; t < KP * CP; t += NWV) {
+          const int kp = t / CP, cp = t - kp * CP;
+          int k0[2], k[2], kc[2];
+          bool k_ok[2];
+          int c0[2], c[2];
+          bool c_ok[2];
+          cgptr bbase[2];
+          long bld[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            k0[h] = (2 * kp + h) * 16;
+            k[h] = k0[h] + lr;
+            k_ok[h] = k[h] < n;
+            kc[h] = k_ok[h] ? k[h] : n - 1;
+            c0[h] = (2 * cp + h) * 16;
+            c[h] = c0[h] + lr;
+            c_ok[h] = c[h] < nb;
+            const bool is_eq = c[h] < ne;
+            bbase[h] = is_eq ? (ATs + c[h]) : (CTs + (c_ok[h] ? c[h] - ne : 0));
+            bld[h] = is_eq ? ne : ni;
+          }
+          pqp_d4 acc1[2][2], acc2[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              acc1[h][g] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+              acc2[h][g] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+            }
+          // W[k][j] = 0 for j > k (the zeros of WU's lower triangle are stored): one range for both row blocks
+          const int jend = (k0[1] + 16 < n) ? (k0[1] + 16) : n;
+          for (int j0 = 0; j0 < jend; j0 += 4 * ZG2_DEPTH) {
+            double a[2][ZG2_DEPTH], b[2][ZG2_DEPTH];
+#pragma unroll
+            for (int u = 0; u < ZG2_DEPTH; ++u) {
+              const int j = j0 + 4 * u + lk;
+              const int jc = (j < n) ? j : n - 1;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                a[h][u] = WU[(long)jc * n + kc[h]];
+                b[h][u] = bbase[h][(long)jc * bld[h]];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < ZG2_DEPTH; ++u) {
+              const int j = j0 + 4 * u + lk;
+              double av[2], bv[2];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                av[h] = (j < n && k_ok[h]) ? a[h][u] : 0.0;
+                bv[h] = (j < n && c_ok[h]) ? b[h][u] : 0.0;
+              }
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                  acc1[h][g] = mfma_f64_16x16x4(av[h], bv[g], acc1[h][g]);
+                  acc2[h][g] = mfma_f64_16x16x4(bv[g], av[h], acc2[h][g]);
+                }
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) {
+                const int kr = k0[h] + lk + 4 * rr;
+                if (kr < n && c_ok[g])
+                  Zc[(long)kr * nd + c[g]] = acc1[h][g][rr];
+                const int cr = c0[g] + lk + 4 * rr;
+                if (cr < nb && k_ok[h])
+                  Zr[(long)cr * n + k[h]] = acc2[h][g][rr];
+              }
+        }
+      } else
       for (int t = w; t < KT * CP; t += NWV) {
         const int kt = t / CP, cp = t - kt * CP;
         const int k0 = kt * 16;
@@ -1379,6 +1467,105 @@ struct Solver
       // work unit = block row ct of G times TWO adjacent block columns dt, dt+1 <= ct (lower
       // tiles; each off-diagonal tile also yields its mirror from the swapped operands)
       const int DT = (nd + 15) / 16;
+      if constexpr (NT >= 512 && PQP_ZG_BLOCK2) {
+        // 2 x 2: block rows (2 sc, 2 sc + 1) of G times block columns (2 sd, 2 sd + 1), sd <= sc; on the diagonal
+        // of this coarser grid the tile above G's diagonal is the mirror of the one below and is skipped
+        const int ST = (DT + 1) / 2;
+        const int units2 = ST * (ST + 1) / 2;
+        for (int t = w; t < units2; t += NWV) {
+          int sc = 0, sd = t;
+          while (sd >= sc + 1) {
+            sd -= sc + 1;
+            ++sc;
+          }
+          int c0[2], c[2], cc[2], d0[2], dcol[2], dcc[2];
+          bool c_ok[2], d_ok[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            c0[h] = (2 * sc + h) * 16;
+            c[h] = c0[h] + lr;
+            c_ok[h] = c[h] < nd;
+            cc[h] = c_ok[h] ? c[h] : nd - 1;
+            d0[h] = (2 * sd + h) * 16;
+            dcol[h] = d0[h] + lr;
+            d_ok[h] = dcol[h] < nd;
+            dcc[h] = d_ok[h] ? dcol[h] : nd - 1;
+          }
+          const bool diag2 = (sc == sd);
+          pqp_d4 acc1[2][2], acc2[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              acc1[h][g] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+              acc2[h][g] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+            }
+          for (int k0 = 0; k0 < n; k0 += 4 * ZG2_DEPTH) {
+            double za[2][ZG2_DEPTH], zb[2][ZG2_DEPTH], sv[ZG2_DEPTH];
+#pragma unroll
+            for (int u = 0; u < ZG2_DEPTH; ++u) {
+              const int k = k0 + 4 * u + lk;
+              const int kc = (k < n) ? k : n - 1;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                za[h][u] = Zcc[(long)kc * nd + cc[h]];
+                zb[h][u] = Zcc[(long)kc * nd + dcc[h]];
+              }
+              sv[u] = L.t1()[kc];
+            }
+#pragma unroll
+            for (int u = 0; u < ZG2_DEPTH; ++u) {
+              const int k = k0 + 4 * u + lk;
+              double av[2], bv[2];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                av[h] = (k < n && c_ok[h]) ? za[h][u] * sv[u] : 0.0;
+                bv[h] = (k < n && d_ok[h]) ? zb[h][u] : 0.0;
+              }
+              // (1, 0) and, off the coarse diagonal, (0, 0) (0, 1) (1, 1): tile and mirror
+              acc1[1][0] = mfma_f64_16x16x4(av[1], bv[0], acc1[1][0]);
+              acc2[1][0] = mfma_f64_16x16x4(bv[0], av[1], acc2[1][0]);
+              acc1[0][0] = mfma_f64_16x16x4(av[0], bv[0], acc1[0][0]);
+              acc1[1][1] = mfma_f64_16x16x4(av[1], bv[1], acc1[1][1]);
+              if (!diag2) {
+                acc2[0][0] = mfma_f64_16x16x4(bv[0], av[0], acc2[0][0]);
+                acc2[1][1] = mfma_f64_16x16x4(bv[1], av[1], acc2[1][1]);
+                acc1[0][1] = mfma_f64_16x16x4(av[0], bv[1], acc1[0][1]);
+                acc2[0][1] = mfma_f64_16x16x4(bv[1], av[0], acc2[0][1]);
+              }
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int ct = 2 * sc + h, dt = 2 * sd + g;
+              if (dt > ct || ct >= DT || dt >= DT)
+                continue; // above G's diagonal (coarse diagonal only) or past the last block
+              if (dt != ct) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                  const int cr = c0[h] + lk + 4 * rr;
+                  if (cr < nd && d_ok[g])
+                    G[(long)cr * nd + dcol[g]] = acc1[h][g][rr];
+                  const int dr = d0[g] + lk + 4 * rr;
+                  if (dr < nd && c_ok[h])
+                    G[(long)dr * nd + c[h]] = acc2[h][g][rr];
+                }
+              } else {
+                // diagonal tile: keep G exactly symmetric (lower part + its mirror)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                  const int cr = c0[h] + lk + 4 * rr;
+                  if (cr < nd && d_ok[g] && cr >= dcol[g]) {
+                    G[(long)cr * nd + dcol[g]] = acc1[h][g][rr];
+                    G[(long)dcol[g] * nd + cr] = acc1[h][g][rr];
+                  }
+                }
+              }
+            }
+        }
+      } else {
       int units = 0;
       for (int ct = 0; ct < DT; ++ct)
         units += ct / 2 + 1;
@@ -1458,6 +1645,7 @@ struct Solver
             }
           }
         }
+      }
       }
     }
     count(ST_N_NEW_ROWS, nd);
