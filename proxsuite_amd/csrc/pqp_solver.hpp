@@ -144,10 +144,10 @@ enum
   ST_N_KKT_SOLVES,
   ST_N_LS_BREAKPOINTS,
   ST_N_ACTIVE_FINAL,
-  ST_CYC_F_LOAD, // ldlt_factor of the Schur block: panel load
-  ST_CYC_F_UPDATE,
+  ST_CYC_F_LOAD,      // blocked Schur factorisation: gather of S = M_J + G_JJ
+  ST_CYC_F_UPDATE,    //   its LDL^T on the matrix cores
   ST_CYC_F_PANEL,
-  ST_CYC_F_WRITEBACK,
+  ST_CYC_F_WRITEBACK, //   the row-wise inverse W_S
   ST_CYC_F_TINV,
   ST_CYC_S_GATHER,
   ST_CYC_SOLVE_LDLT,
@@ -970,12 +970,11 @@ setup_body(const Batch& batch, long q, lptr lds_base)
 
 // Dual Schur blocks beyond the register-resident path (more than 16 * SCHUR_MB rows, or a
 // workgroup that is not 16 x 16): S = M_J + G_JJ is gathered into LS (slot -> constraint id in
-// `sid`, -1 for a hole = identity row), factorised there on the matrix cores in the FULL layout,
-// and inverted row-wise into W_S.
+// `sid`, -1 for a hole = identity row) here; the caller factorises it there on the matrix cores in the
+// FULL layout (ldlt_factor_mfma) and inverts it row-wise into W_S (tri_inverse_mfma_rows).
 template<int NT>
 __device__ __forceinline__ void
-schur_factor_blocked(cgptr G, gptr LS, gptr WS, int nd, int rr, int ne, double mu_eq, double mu_in, cliptr sid,
-                     lptr dS, lptr top)
+schur_gather_blocked(cgptr G, gptr LS, int nd, int rr, int ne, double mu_eq, double mu_in, cliptr sid)
 {
   // gathered loads are batched 8 deep ahead of the stores (G and LS are distinct buffers, but
   // the compiler cannot know and would serialise load/store pairs)
@@ -1003,8 +1002,6 @@ schur_factor_blocked(cgptr G, gptr LS, gptr WS, int nd, int rr, int ne, double m
         LS[dst[u]] = v[u];
   }
   __syncthreads();
-  ldlt_factor_mfma<NT, true>(LS, nd, rr, dS, top);
-  tri_inverse_mfma_rows<NT, false>(LS, nd, rr, WS, WS);
 }
 
 // ===========================================================================
@@ -1815,9 +1812,14 @@ struct Solver
       for (int a = threadIdx.x; a < rr; a += NT)
         sid[a] = slot_live(a) ? cid_of_slot(a) : -1;
       __syncthreads();
-      schur_factor_blocked<NT>(G, P.LS(), P.WS(), nd, rr, ne, mu_eq, mu_in, sid, L.dS(), L.top());
-      bytes((long)rr * rr * 8 * 4);
+      // (three stages, billed apart in the stats build: gather / factorisation / inverse)
+      schur_gather_blocked<NT>(G, P.LS(), nd, rr, ne, mu_eq, mu_in, sid);
+      toc(ST_CYC_F_LOAD);
+      ldlt_factor_mfma<NT, true>(P.LS(), nd, rr, L.dS(), L.top());
       toc(ST_CYC_F_UPDATE);
+      tri_inverse_mfma_rows<NT, false>(P.LS(), nd, rr, P.WS(), P.WS());
+      bytes((long)rr * rr * 8 * 4);
+      toc(ST_CYC_F_WRITEBACK);
       count(ST_N_SCHUR_BLOCKED);
     }
     debug_check_factor("factor_schur");
