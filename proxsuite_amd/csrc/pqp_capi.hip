@@ -192,6 +192,9 @@ enqueue_setup(pqp_batch* h, int64_t idx, bool update_call, const double* H, cons
     c.mu_in = mu_in;
     c.min_eig = me;
     h->cmd[size_t(q)] = c;
+    if (h->cmd_settings.size() != h->settings.size())
+      h->cmd_settings = h->settings;
+    h->cmd_settings[size_t(q)] = st;
     if (is_init) {
       h->is_initialized[size_t(q)] = 1;
     } else {
@@ -571,11 +574,27 @@ pqp_batch_flush(pqp_batch* h)
     }
   if (lo < hi) {
     HIP_TRY(hipMemcpy(h->d_cmd + lo, h->cmd.data() + lo, (hi - lo) * sizeof(pqp::Cmd), hipMemcpyHostToDevice));
+    // init / update run under the settings of the moment they were called
+    bool stale = false;
+    if (h->cmd_settings.size() == h->settings.size()) {
+      std::vector<pqp_settings> snap(h->settings.begin() + long(lo), h->settings.begin() + long(hi));
+      for (size_t q = lo; q < hi; ++q)
+        if ((h->cmd[q].op == pqp::CMD_INIT || h->cmd[q].op == pqp::CMD_UPDATE) &&
+            std::memcmp(&h->cmd_settings[q], &h->settings[q], sizeof(pqp_settings)) != 0) {
+          snap[q - lo] = h->cmd_settings[q];
+          stale = true;
+        }
+      if (stale)
+        HIP_TRY(hipMemcpy(h->d_settings + lo, snap.data(), (hi - lo) * sizeof(pqp_settings), hipMemcpyHostToDevice));
+    }
     h->setup_first = long(lo);
     h->setup_count = long(hi - lo);
     if (int rc = pqp_launch_setup(h))
       return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (stale) // back to the live settings for the solve
+      HIP_TRY(hipMemcpy(h->d_settings + lo, h->settings.data() + lo, (hi - lo) * sizeof(pqp_settings),
+                        hipMemcpyHostToDevice));
     for (size_t q = lo; q < hi; ++q)
       h->cmd[q].op = pqp::CMD_NONE;
   }

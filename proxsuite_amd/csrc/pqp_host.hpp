@@ -41,6 +41,10 @@ struct pqp_batch
   size_t lds_solve = 0, lds_setup = 0;
   std::vector<pqp_settings> settings;
   std::vector<pqp_settings> settings_uploaded; // what the device holds
+  // Settings of a QP at the moment its pending init / update was queued: setup() reads the settings of THAT moment
+  // in the reference (helpers.hpp:522-572 resets results by the initial_guess current at the call), so the deferred
+  // setup kernel is given this snapshot and not what the user wrote into the settings afterwards.
+  std::vector<pqp_settings> cmd_settings;
   std::vector<pqp::Cmd> cmd;
   std::vector<char> is_initialized;
   bool settings_dirty = true;

@@ -169,6 +169,29 @@ main(int argc, char** argv)
     CHECK(qp.results.x[0] == 0);
   }
 
+  // --- dense_qp_wrapper.cpp:5052-5242: an update runs under the settings of the moment it is called.  Under the
+  // default option it resets the results (helpers.hpp:522-531), so switching to WARM_START_WITH_PREVIOUS_RESULT
+  // afterwards does not bring the old solution back: the next solve iterates again
+  {
+    dense::Model<T> m = models[1];
+    dense::QP<T> qp(dim, n_eq, n_in);
+    qp.settings.eps_abs = eps_abs;
+    qp.settings.eps_rel = 0;
+    qp.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u, true, T(1e-7));
+    qp.solve();
+    CHECK(qp.results.info.iter > 0);
+    qp.update(nullopt, nullopt, nullopt, nullopt, nullopt, nullopt, nullopt, true, T(1e-6));
+    qp.settings.initial_guess = InitialGuessStatus::WARM_START_WITH_PREVIOUS_RESULT;
+    CHECK(std::fabs(qp.settings.default_rho - 1e-6) <= 1e-9 && std::fabs(qp.results.info.rho - 1e-6) <= 1e-9);
+    qp.solve();
+    CHECK(qp.results.info.iter > 0);
+    T pri, dua;
+    residuals(m, qp.results, pri, dua);
+    CHECK(pri <= eps_abs && dua <= eps_abs);
+    qp.solve(); // and now the previous result IS the solution
+    CHECK(qp.results.info.iter == 0);
+  }
+
   // --- one-shot solve (dense_qp_solve.cpp)
   {
     const auto& m = models[1];

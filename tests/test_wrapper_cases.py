@@ -1,0 +1,74 @@
+"""The reference's dense wrapper test cases (test/src/dense_qp_wrapper.cpp, tests/wrapper_cases.py restates them
+one by one) on the oracle -- the restatement must meet the reference's own acceptance lines -- and on the device
+engine behind the Python facade: CPU SIMT emulator build here (`-m "not gpu"`), the real library on the GPU box
+(`-m gpu`), each compared with the oracle's run of the same case solve by solve."""
+import os
+import sys
+
+import pytest
+
+import wrapper_cases as wc
+from proxsuite_amd import _native as N
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+NAMES = sorted(wc.CASES)
+
+
+def oracle_side(oracle, randqp):
+    return wc.Side(oracle.QP, oracle.kkt_residuals, randqp, "oracle")
+
+
+def device_side(dense, oracle, randqp, name):
+    return wc.Side(dense.QP, oracle.kkt_residuals, randqp, name)
+
+
+def _scaling_oracle(q):
+    s = q.scaled()
+    return s["delta"], s["c"]
+
+
+def _scaling_device(q):
+    s = q._pool.batch.scaled(q._slot)
+    return s["delta"], s["c"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_meets_reference_acceptance(oracle, randqp, name):
+    S = oracle_side(oracle, randqp)
+    S.scaling = _scaling_oracle
+    wc.CASES[name](S)
+    assert S.trace
+
+
+@pytest.fixture(scope="module")
+def emu_dense():
+    import build as emu_build
+    saved = N._lib
+    N._lib = N.NativeLib(emu_build.build())
+    from proxsuite_amd.proxqp import dense as d
+    yield d
+    N._lib = saved
+
+
+def _device_against_oracle(dense, oracle, randqp, name, label):
+    ref = oracle_side(oracle, randqp)
+    ref.scaling = _scaling_oracle
+    wc.CASES[name](ref)
+    dev = device_side(dense, oracle, randqp, label)
+    dev.scaling = _scaling_device
+    wc.CASES[name](dev)
+    wc.compare_traces(dev.trace, ref.trace)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_emulated_device_matches_oracle(emu_dense, oracle, randqp, name):
+    _device_against_oracle(emu_dense, oracle, randqp, name, "device (emulator)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_matches_oracle(oracle, randqp, name):
+    from proxsuite_amd.proxqp import dense
+    N.load()  # the real library or a loud failure
+    _device_against_oracle(dense, oracle, randqp, name, "device")

@@ -1,0 +1,671 @@
+"""The solver-flow test cases of the reference's dense wrapper suite (test/src/dense_qp_wrapper.cpp), restated
+one by one: same problem generator and seed, same sequence of init / solve / update / settings changes, same
+acceptance lines (primal and dual residual of the UNSCALED problem <= eps_abs, plus the exact-value checks on
+rho / mu_eq / mu_eq_inv the reference makes).  Each case is a function `case(S)`; `S` is a `Side`: either the
+oracle (tests pin the restatement against the reference's own known answers) or the device engine behind the
+Python facade (emulator build on CPU, the real library on the GPU box).  A side records every checked solve
+(x, y, z, iteration counts), so that a device run can also be compared with the oracle run step by step.
+
+Test infrastructure.  The random helpers below continue the generator stream exactly where the reference's
+tests do (utils::rand::vector_rand, sparse_matrix_rand_not_compressed, ...: random_qp_problems.hpp:150-364).
+"""
+import numpy as np
+
+NO_GUESS, EQ_GUESS, WS_PREV, WARM, COLD_PREV = 0, 1, 2, 3, 4
+PRIMAL_LDLT = 2
+EPS = 1e-9
+
+
+class M:
+    """plain model record (reference dense::Model), numpy arrays"""
+
+    def __init__(self, m):
+        self.H, self.g, self.A, self.b, self.C, self.l, self.u = (np.array(getattr(m, k), dtype=np.float64)
+                                                                   for k in ("H", "g", "A", "b", "C", "l", "u"))
+
+    def args(self):
+        return self.H, self.g, self.A, self.b, self.C, self.l, self.u
+
+
+class Side:
+    def __init__(self, make_qp, kkt, randqp, name):
+        self.make_qp, self.kkt, self.R, self.name = make_qp, kkt, randqp, name
+        self.trace = []
+
+    # -- generator stream (random_qp_problems.hpp:150-161, 308-364)
+    def vector_rand(self, n):
+        return np.array([self.R.normal_rand() for _ in range(n)])
+
+    def sparse_matrix_rand_not_compressed(self, rows, cols, p):
+        a = np.zeros((rows, cols))
+        for i in range(rows):
+            for j in range(cols):
+                if self.R.uniform_rand() < p:
+                    a[i, j] = self.R.normal_rand()
+        return a
+
+    def sparse_positive_definite_rand_not_compressed(self, n, rho, p):
+        h = np.zeros((n, n))
+        for i in range(n):
+            for j in range(n):
+                if self.R.uniform_rand() < p / 2:
+                    h[i, j] = self.R.normal_rand()
+        h = (h + h.T) * 0.5
+        h[np.diag_indices(n)] += rho + abs(np.linalg.eigvalsh(h).min())
+        return h
+
+    def model(self, dim=10, n_eq=None, n_in=None, sparsity=0.15, seed=1):
+        if seed is not None:
+            self.R.set_seed(seed)
+        n_eq = dim // 4 if n_eq is None else n_eq
+        n_in = dim // 4 if n_in is None else n_in
+        return M(self.R.dense_strongly_convex_qp(dim, n_eq, n_in, sparsity, 1e-2)), dim, n_eq, n_in
+
+    def qp(self, dim, n_eq, n_in, guess=None, eps=EPS, **kw):
+        q = self.make_qp(dim, n_eq, n_in, **kw)
+        q.settings.eps_abs = eps
+        q.settings.eps_rel = 0
+        if guess is not None:
+            q.settings.initial_guess = guess
+        return q
+
+    def check(self, q, m, eps=EPS, l_box=None, u_box=None):
+        """the reference's two acceptance lines on the unscaled problem"""
+        r = q.results
+        x, y, z = np.array(r.x), np.array(r.y), np.array(r.z)
+        pri, dua = self.kkt(m.H, m.g, m.A, m.b, m.C, m.l, m.u, x, y, z, l_box, u_box)
+        self.trace.append(dict(x=x, y=y, z=z, iter=int(r.info.iter), iter_ext=int(r.info.iter_ext),
+                               status=int(r.info.status), rho=float(r.info.rho), mu_eq=float(r.info.mu_eq),
+                               mu_in=float(r.info.mu_in)))
+        assert pri <= eps, "%s: primal residual %.3e > %.1e" % (self.name, pri, eps)
+        assert dua <= eps, "%s: dual residual %.3e > %.1e" % (self.name, dua, eps)
+
+
+def _init_solve_check(S, q, m, **kw):
+    q.init(*m.args(), **kw)
+    q.solve()
+    S.check(q, m)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# dense_qp_wrapper.cpp:16-162  empty equality constraints given three ways
+def case_empty_equality(S):
+    m, dim, n_eq, n_in = S.model(n_eq=0)
+    q = S.qp(dim, 0, n_in)
+    q.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u)  # A of size (0, 10)
+    q.solve()
+    S.check(q, m)
+    q2 = S.qp(dim, 0, n_in)
+    q2.init(m.H, m.g, np.zeros((0, 0)), np.zeros(0), m.C, m.l, m.u)  # A of size (0, 0)
+    q2.solve()
+    S.check(q2, m)
+    q3 = S.qp(dim, 0, n_in)
+    q3.init(m.H, m.g, None, None, m.C, m.l, m.u)  # nullopt
+    q3.solve()
+    S.check(q3, m)
+
+
+def _update_case(mutate):
+    """dense_qp_wrapper.cpp:163-1108: solve, change part of the model, update, solve; a fresh QP object on the
+    updated model must pass too"""
+
+    def case(S):
+        m, dim, n_eq, n_in = S.model()
+        q = S.qp(dim, n_eq, n_in)
+        _init_solve_check(S, q, m)
+        upd = mutate(S, m, dim, n_eq, n_in)
+        q.update(**upd)
+        q.solve()
+        S.check(q, m)
+        q2 = S.qp(dim, n_eq, n_in)
+        _init_solve_check(S, q2, m)
+
+    return case
+
+
+def _mut_H(S, m, dim, n_eq, n_in):  # :163-293
+    m.H = np.eye(dim)
+    return dict(H=m.H)
+
+
+def _mut_A(S, m, dim, n_eq, n_in):  # :294-426
+    m.A = S.sparse_matrix_rand_not_compressed(n_eq, dim, 0.15)
+    return dict(A=m.A)
+
+
+def _mut_C(S, m, dim, n_eq, n_in):  # :427-559
+    m.C = S.sparse_matrix_rand_not_compressed(n_in, dim, 0.15)
+    return dict(C=m.C)
+
+
+def _mut_b(S, m, dim, n_eq, n_in):  # :560-692
+    x_sol = S.vector_rand(dim)
+    m.b = m.A @ x_sol
+    return dict(b=m.b)
+
+
+def _mut_u(S, m, dim, n_eq, n_in):  # :693-828
+    x_sol = S.vector_rand(dim)
+    delta = np.array([S.R.uniform_rand() for _ in range(n_in)])
+    m.u = m.C @ x_sol + delta
+    return dict(u=m.u)
+
+
+def _mut_g(S, m, dim, n_eq, n_in):  # :829-960
+    m.g = S.vector_rand(dim)
+    return dict(g=m.g)
+
+
+def _mut_all(S, m, dim, n_eq, n_in):  # :961-1108  H and A and b and u and l
+    m.H = S.sparse_positive_definite_rand_not_compressed(dim, 1e-2, 0.15)
+    m.A = S.sparse_matrix_rand_not_compressed(n_eq, dim, 0.15)
+    x_sol = S.vector_rand(dim)
+    delta = np.array([S.R.uniform_rand() for _ in range(n_in)])
+    m.b = m.A @ x_sol
+    m.u = m.C @ x_sol + delta
+    m.l = m.C @ x_sol - delta
+    return dict(H=m.H, A=m.A, b=m.b, l=m.l, u=m.u)
+
+
+case_update_H = _update_case(_mut_H)
+case_update_A = _update_case(_mut_A)
+case_update_C = _update_case(_mut_C)
+case_update_b = _update_case(_mut_b)
+case_update_u = _update_case(_mut_u)
+case_update_g = _update_case(_mut_g)
+case_update_H_A_b_u_l = _update_case(_mut_all)
+
+
+# :1109-1238  update rho ("restart the problem with default options")
+def case_update_rho(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in)
+    _init_solve_check(S, q, m)
+    q.update(update_preconditioner=True, rho=1e-7)
+    q.solve()
+    S.check(q, m)
+    q2 = S.qp(dim, n_eq, n_in)
+    _init_solve_check(S, q2, m, compute_preconditioner=True, rho=1e-7)
+
+
+# :1239-1371  update mu_eq and mu_in
+def case_update_mu(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in)
+    _init_solve_check(S, q, m)
+    q.update(update_preconditioner=True, mu_eq=1e-2, mu_in=1e-3)
+    q.solve()
+    S.check(q, m)
+    q2 = S.qp(dim, n_eq, n_in)
+    _init_solve_check(S, q2, m, compute_preconditioner=True, mu_eq=1e-2, mu_in=1e-3)
+
+
+# :1372-1490  warm starting from random vectors
+def case_warm_starting(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in)
+    _init_solve_check(S, q, m)
+    x_wm, y_wm, z_wm = S.vector_rand(dim), S.vector_rand(n_eq), S.vector_rand(n_in)
+    q.settings.initial_guess = WARM
+    q.solve(x_wm, y_wm, z_wm)
+    S.check(q, m)
+    q2 = S.qp(dim, n_eq, n_in, guess=WARM)
+    q2.init(*m.args())
+    q2.solve(x_wm, y_wm, z_wm)
+    S.check(q2, m)
+
+
+# :1491-1538  row-major inputs
+def case_dense_init(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in)
+    q.init(np.ascontiguousarray(m.H), m.g, np.ascontiguousarray(m.A), m.b, np.ascontiguousarray(m.C), m.l, m.u)
+    q.solve()
+    S.check(q, m)
+
+
+def _two_objects(guess):  # :1539-1713  the same option on two objects
+    def case(S):
+        m, dim, n_eq, n_in = S.model()
+        for _ in range(2):
+            q = S.qp(dim, n_eq, n_in, guess=guess)
+            _init_solve_check(S, q, m)
+
+    return case
+
+
+case_no_initial_guess = _two_objects(NO_GUESS)
+case_equality_constrained_initial_guess = _two_objects(EQ_GUESS)
+
+
+def _previous_result(guess, update_preconditioner):
+    """:1714-1958  a second object warm started from the first one's solution pushed through the second's
+    equilibration (ruiz.scale_primal_in_place / scale_dual_in_place_eq / _in: x / delta_x, c y / delta_eq,
+    c z / delta_in), then the first object re-solved from its previous result"""
+
+    def case(S):
+        m, dim, n_eq, n_in = S.model()
+        q = S.qp(dim, n_eq, n_in, guess=EQ_GUESS)
+        _init_solve_check(S, q, m)
+        q2 = S.qp(dim, n_eq, n_in, guess=WARM)
+        q2.init(*m.args(), compute_preconditioner=True)
+        delta, c = S.scaling(q2)
+        r = q.results
+        x = np.array(r.x) / delta[:dim]
+        y = np.array(r.y) / delta[dim:dim + n_eq] * c
+        z = np.array(r.z) / delta[dim + n_eq:] * c
+        q2.solve(x, y, z)
+        S.check(q2, m)
+        q.settings.initial_guess = guess
+        q.update(update_preconditioner=update_preconditioner)
+        q.solve()
+        S.check(q, m)
+
+    return case
+
+
+case_warm_start_with_previous_result = _previous_result(WS_PREV, False)
+case_cold_start_option = _previous_result(COLD_PREV, True)
+
+
+# :1959-2053  equilibration on / off at initialisation
+def case_equilibration_at_init(S):
+    m, dim, n_eq, n_in = S.model()
+    for flag in (True, False):
+        q = S.qp(dim, n_eq, n_in, guess=EQ_GUESS)
+        _init_solve_check(S, q, m, compute_preconditioner=flag)
+
+
+# :2054-2196  equilibration rederived / kept at update: "should get exact same results"
+def case_equilibration_at_update(S):
+    m, dim, n_eq, n_in = S.model()
+    for flag in (True, False):
+        q = S.qp(dim, n_eq, n_in, guess=EQ_GUESS)
+        _init_solve_check(S, q, m, compute_preconditioner=True)
+        first = np.array(q.results.x)
+        q.update(update_preconditioner=flag)
+        q.solve()
+        S.check(q, m)
+        assert np.max(np.abs(np.array(q.results.x) - first)) <= 1e-9
+
+
+def _multi_solve(first, then=None, warm=False):
+    """:2197-2959  four solves in a row; the option may change after the first"""
+
+    def case(S):
+        m, dim, n_eq, n_in = S.model()
+        q = S.qp(dim, n_eq, n_in, guess=first)
+        _init_solve_check(S, q, m)
+        if then is not None:
+            q.settings.initial_guess = then
+        for _ in range(3):
+            if warm:
+                r = q.results
+                q.solve(np.array(r.x), np.array(r.y), np.array(r.z))
+            else:
+                q.solve()
+            S.check(q, m)
+
+    return case
+
+
+case_multi_no_guess = _multi_solve(NO_GUESS)                       # :2197-2320
+case_multi_eq_guess = _multi_solve(EQ_GUESS)                       # :2321-2445
+case_multi_eq_then_previous = _multi_solve(EQ_GUESS, WS_PREV)      # :2446-2574
+case_multi_no_guess_then_previous = _multi_solve(NO_GUESS, WS_PREV)  # :2575-2703
+case_multi_eq_then_cold = _multi_solve(EQ_GUESS, COLD_PREV)        # :2704-2833
+case_multi_warm_start = _multi_solve(NO_GUESS, WARM, warm=True)    # :2834-2959
+
+
+# :2960-3051  warm start of a second object from the first one's solution
+def case_warm_start_from_init(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in, guess=NO_GUESS)
+    _init_solve_check(S, q, m)
+    q2 = S.qp(dim, n_eq, n_in)
+    q2.init(*m.args())
+    q2.settings.initial_guess = WARM
+    r = q.results
+    q2.solve(np.array(r.x), np.array(r.y), np.array(r.z))
+    S.check(q2, m)
+
+
+def _update_multi_solve(first, then=None):
+    """:3052-3750  solve, H *= 2 and a new g with the preconditioner rederived, three more solves"""
+
+    def case(S):
+        m, dim, n_eq, n_in = S.model()
+        q = S.qp(dim, n_eq, n_in, guess=first)
+        _init_solve_check(S, q, m)
+        if then is not None:
+            q.settings.initial_guess = then
+        m.H = m.H * 2.0
+        m.g = S.vector_rand(dim)
+        q.update(H=m.H, g=m.g, update_preconditioner=True)
+        for _ in range(3):
+            q.solve()
+            S.check(q, m)
+
+    return case
+
+
+case_update_multi_no_guess = _update_multi_solve(NO_GUESS)                 # :3052-3188
+case_update_multi_eq_guess = _update_multi_solve(EQ_GUESS)                 # :3189-3326
+case_update_multi_eq_then_previous = _update_multi_solve(EQ_GUESS, WS_PREV)  # :3327-3469
+case_update_multi_no_guess_then_previous = _update_multi_solve(NO_GUESS, WS_PREV)  # :3470-3609
+case_update_multi_eq_then_cold = _update_multi_solve(EQ_GUESS, COLD_PREV)  # :3610-3750
+
+
+# :3751-3927  update + warm start: a void update first ("the warm start should give the exact solution")
+def case_update_multi_warm_start(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in, guess=NO_GUESS)
+    _init_solve_check(S, q, m)
+    q.settings.initial_guess = WARM
+    r = q.results
+    wm = (np.array(r.x), np.array(r.y), np.array(r.z))
+    q.update(H=m.H, g=m.g, update_preconditioner=True)
+    q.solve(*wm)
+    S.check(q, m)
+    r = q.results
+    wm = (np.array(r.x), np.array(r.y), np.array(r.z))
+    m.H = m.H * 2.0
+    m.g = S.vector_rand(dim)
+    q.update(H=m.H, g=m.g, update_preconditioner=True)
+    q.solve(*wm)
+    S.check(q, m)
+    for _ in range(2):
+        r = q.results
+        q.solve(np.array(r.x), np.array(r.y), np.array(r.z))
+        S.check(q, m)
+
+
+_FIVE = (NO_GUESS, WS_PREV, EQ_GUESS, COLD_PREV, WARM)
+
+
+def _solve_for(S, q, guess, donor):
+    if guess == WARM:
+        r = donor.results
+        q.solve(np.array(r.x), np.array(r.y), np.array(r.z))
+    else:
+        q.solve()
+
+
+# :3928-4128  rho given at init survives the solve, for the five options: CHECK(info.rho == 1e-7)
+def case_init_with_rho(S):
+    m, dim, n_eq, n_in = S.model()
+    made = {}
+    for guess in _FIVE:
+        q = S.qp(dim, n_eq, n_in, guess=guess)
+        q.init(*m.args(), compute_preconditioner=True, rho=1e-7)
+        _solve_for(S, q, guess, made.get(EQ_GUESS))
+        S.check(q, m)
+        assert q.results.info.rho == 1e-7
+        made[guess] = q
+
+
+# :4129-4385  g updated, for the five options
+def case_g_update_every_guess(S):
+    m, dim, n_eq, n_in = S.model()
+    old_g = m.g.copy()
+    new_g = S.vector_rand(dim)
+    made = {}
+    for guess in _FIVE:
+        m.g = old_g
+        q = S.qp(dim, n_eq, n_in, guess=guess)
+        q.init(*m.args())
+        _solve_for(S, q, guess, made.get(EQ_GUESS))
+        S.check(q, m)
+        m.g = new_g
+        q.update(g=m.g)
+        q.solve()
+        S.check(q, m)
+        made[guess] = q
+
+
+# :4386-4642  A updated, for the five options
+def case_A_update_every_guess(S):
+    m, dim, n_eq, n_in = S.model()
+    old_A = m.A.copy()
+    new_A = S.sparse_matrix_rand_not_compressed(n_eq, dim, 0.15)
+    made = {}
+    for guess in _FIVE:
+        m.A = old_A
+        q = S.qp(dim, n_eq, n_in, guess=guess)
+        q.init(*m.args())
+        _solve_for(S, q, guess, made.get(EQ_GUESS))
+        S.check(q, m)
+        m.A = new_A
+        q.update(A=m.A)
+        q.solve()
+        S.check(q, m)
+        made[guess] = q
+
+
+# :4643-4937  rho updated, for the five options: CHECK(info.rho == 1e-7) after the re-solve
+def case_rho_update_every_guess(S):
+    m, dim, n_eq, n_in = S.model()
+    made = {}
+    for guess in _FIVE:
+        q = S.qp(dim, n_eq, n_in, guess=guess)
+        q.init(*m.args())
+        _solve_for(S, q, guess, made.get(EQ_GUESS))
+        S.check(q, m)
+        q.update(update_preconditioner=True, rho=1e-7)
+        q.solve()
+        S.check(q, m)
+        assert q.results.info.rho == 1e-7
+        made[guess] = q
+
+
+# :4938-5051  a slightly different g under WARM_START_WITH_PREVIOUS_RESULT
+def case_g_update_previous_result(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in, guess=WS_PREV)
+    _init_solve_check(S, q, m)
+    m.g = m.g * 0.95
+    q.update(g=m.g)
+    q.solve()
+    S.check(q, m)
+    q2 = S.qp(dim, n_eq, n_in, guess=WS_PREV)
+    _init_solve_check(S, q2, m)
+
+
+def _near(a, b):
+    return abs(a - b) <= 1e-9
+
+
+def _defaults_after_updates(guess):
+    """:5052-5815  rho / mu_eq given at init and at update become the defaults and are what info holds before
+    and after every solve.  `guess`: WS_PREV is switched on after the update (the object starts with the
+    default option); the other options are set at construction."""
+
+    def case(S):
+        m, dim, n_eq, n_in = S.model()
+        rho, mu_eq = 1e-7, 1e-4
+        at_start = None if guess == WS_PREV else guess
+
+        def fresh():
+            q = S.make_qp(dim, n_eq, n_in)
+            if at_start is not None:
+                q.settings.initial_guess = at_start
+            assert int(q.settings.initial_guess) == (EQ_GUESS if at_start is None else at_start)
+            q.settings.eps_abs = EPS
+            q.settings.eps_rel = 0
+            return q
+
+        q = fresh()
+        q.init(*m.args(), compute_preconditioner=True, rho=rho)
+        assert _near(q.settings.default_rho, rho) and _near(q.results.info.rho, rho)
+        q.solve()
+        S.check(q, m)
+        assert _near(q.settings.default_rho, rho) and _near(q.results.info.rho, rho)
+        q.update(update_preconditioner=True, rho=1e-6)
+        if guess == WS_PREV:
+            q.settings.initial_guess = WS_PREV
+        assert _near(q.settings.default_rho, 1e-6) and _near(q.results.info.rho, 1e-6)
+        q.solve()
+        S.check(q, m)
+        assert _near(q.settings.default_rho, 1e-6) and _near(q.results.info.rho, 1e-6)
+
+        q2 = fresh()
+        q2.init(*m.args(), compute_preconditioner=True, mu_eq=mu_eq)
+        for when in (0, 1):
+            i = q2.results.info
+            assert _near(q2.settings.default_mu_eq, mu_eq) and _near(i.mu_eq, mu_eq) and _near(i.mu_eq_inv, 1 / mu_eq)
+            if when == 0:
+                q2.solve()
+                S.check(q2, m)
+
+        q3 = fresh()
+        q3.init(*m.args(), compute_preconditioner=True, rho=rho, mu_eq=mu_eq)
+        for when in (0, 1):
+            i = q3.results.info
+            assert _near(q3.settings.default_rho, rho) and _near(i.rho, rho)
+            assert _near(q3.settings.default_mu_eq, mu_eq) and _near(i.mu_eq, mu_eq) and _near(i.mu_eq_inv, 1 / mu_eq)
+            if when == 0:
+                q3.solve()
+                S.check(q3, m)
+        q3.update(update_preconditioner=True, rho=1e-6, mu_eq=1e-3)
+        if guess == WS_PREV:
+            q3.settings.initial_guess = WS_PREV
+        i = q3.results.info
+        assert _near(q3.settings.default_rho, 1e-6) and _near(i.rho, 1e-6)
+        assert _near(q3.settings.default_mu_eq, 1e-3) and _near(i.mu_eq, 1e-3) and _near(i.mu_eq_inv, 1e3)
+        q3.solve()
+        S.check(q3, m)
+
+    return case
+
+
+case_defaults_after_updates_previous = _defaults_after_updates(WS_PREV)  # :5052-5242
+case_defaults_after_updates_cold = _defaults_after_updates(COLD_PREV)    # :5243-5434
+case_defaults_after_updates_eq = _defaults_after_updates(EQ_GUESS)       # :5435-5626
+case_defaults_after_updates_no_guess = _defaults_after_updates(NO_GUESS)  # :5627-5815
+
+
+def _defaults_after_several_solves(guess):
+    """:5816-6732  the same with ten solves between the changes: the parameters given by the user are what
+    info holds before and after each of them"""
+
+    def case(S):
+        m, dim, n_eq, n_in = S.model()
+        rho, mu_eq = 1e-7, 1e-4
+        at_start = None if guess == WS_PREV else guess
+
+        def fresh():
+            q = S.make_qp(dim, n_eq, n_in)
+            if at_start is not None:
+                q.settings.initial_guess = at_start
+            q.settings.eps_abs = EPS
+            q.settings.eps_rel = 0
+            return q
+
+        def holds(q, r=None, me=None):
+            i = q.results.info
+            if r is not None:
+                assert _near(q.settings.default_rho, r) and _near(i.rho, r)
+            if me is not None:
+                assert _near(q.settings.default_mu_eq, me) and _near(i.mu_eq, me) and _near(i.mu_eq_inv, 1 / me)
+
+        def ten(q, **kw):
+            for _ in range(10):
+                holds(q, **kw)
+                q.solve()
+                S.check(q, m)
+                holds(q, **kw)
+
+        q = fresh()
+        q.init(*m.args(), compute_preconditioner=True, rho=rho)
+        holds(q, r=rho)
+        q.solve()
+        S.check(q, m)
+        holds(q, r=rho)
+        if guess == WS_PREV:
+            q.settings.initial_guess = WS_PREV
+        ten(q, r=rho)
+        q.update(update_preconditioner=True, rho=1e-6)
+        ten(q, r=1e-6)
+
+        q2 = fresh()
+        q2.init(*m.args(), compute_preconditioner=True, mu_eq=mu_eq)
+        holds(q2, me=mu_eq)
+        q2.solve()
+        S.check(q2, m)
+        holds(q2, me=mu_eq)
+        if guess == WS_PREV:
+            q2.settings.initial_guess = WS_PREV
+        ten(q2, me=mu_eq)
+
+        q3 = fresh()
+        q3.init(*m.args(), compute_preconditioner=True, rho=rho, mu_eq=mu_eq)
+        ten(q3, r=rho, me=mu_eq)
+        q3.update(update_preconditioner=True, rho=1e-6, mu_eq=1e-3)
+        ten(q3, r=1e-6, me=1e-3)
+
+    return case
+
+
+case_defaults_after_solves_previous = _defaults_after_several_solves(WS_PREV)  # :5816-6051
+case_defaults_after_solves_cold = _defaults_after_several_solves(COLD_PREV)    # :6052-6279
+case_defaults_after_solves_eq = _defaults_after_several_solves(EQ_GUESS)       # :6280-6507
+case_defaults_after_solves_no_guess = _defaults_after_several_solves(NO_GUESS)  # :6508-6732
+
+
+# :6733-6802  update before init: update calls init internally
+def case_update_before_init(S):
+    m, dim, n_eq, n_in = S.model()
+    q = S.qp(dim, n_eq, n_in, guess=NO_GUESS)
+    q.update(*m.args(), update_preconditioner=True)
+    q.solve()
+    S.check(q, m)
+    m.H = m.H * 2.0
+    m.g = S.vector_rand(dim)
+    q.update(H=m.H, g=m.g, update_preconditioner=True)
+    q.solve()
+    S.check(q, m)
+
+
+# :7069-7152  box constraints widened by an update
+def case_box_updates(S):
+    m, dim, n_eq, n_in = S.model(dim=50, sparsity=1.0)
+    q = S.qp(dim, n_eq, n_in, guess=NO_GUESS, box_constraints=True)
+    u_box = np.full(dim, 1e2)
+    l_box = np.full(dim, -1e2)
+    q.init(*m.args(), l_box=l_box, u_box=u_box)
+    q.solve()
+    S.check(q, m, l_box=l_box, u_box=u_box)
+    u_box = u_box + 1e1
+    l_box = l_box - 1e1
+    q.update(l=m.l, u=m.u, l_box=l_box, u_box=u_box)
+    q.solve()
+    S.check(q, m, l_box=l_box, u_box=u_box)
+
+
+# :7618-7673  PrimalLDLT backend, only u given: CHECK(info.mu_updates > 0)
+def case_primal_ldlt_mu_update(S):
+    m, dim, n_eq, n_in = S.model(dim=3, n_eq=0, n_in=9, sparsity=1.0)
+    q = S.qp(dim, 0, n_in, eps=1e-7, dense_backend=PRIMAL_LDLT)
+    q.settings.compute_timings = True
+    q.init(m.H, m.g, None, None, m.C, None, m.u)
+    q.solve()
+    assert q.results.info.mu_updates > 0
+    S.check(q, m, eps=1e-7)
+
+
+CASES = {k[5:]: v for k, v in sorted(globals().items()) if k.startswith("case_")}
+
+
+def compare_traces(dev, ref, tol=1e-8):
+    """device run against the oracle run of the same case, checked solve by checked solve"""
+    assert len(dev) == len(ref)
+    for i, (a, b) in enumerate(zip(dev, ref)):
+        assert a["status"] == b["status"], "solve %d: status %d != %d" % (i, a["status"], b["status"])
+        for k in ("x", "y", "z"):
+            d = float(np.max(np.abs(a[k] - b[k]))) if a[k].size else 0.0
+            assert d <= tol * (1.0 + float(np.max(np.abs(b[k]))) if b[k].size else 1.0), \
+                "solve %d: %s differs by %.3e" % (i, k, d)
+        for k in ("iter", "iter_ext"):
+            assert a[k] == b[k], "solve %d: %s %d != %d" % (i, k, a[k], b[k])
+        for k in ("rho", "mu_eq", "mu_in"):
+            assert abs(a[k] - b[k]) <= 1e-12 * max(1.0, abs(b[k])), "solve %d: %s %r != %r" % (i, k, a[k], b[k])
