@@ -16,11 +16,15 @@ NAMES = sorted(wc.CASES)
 
 
 def oracle_side(oracle, randqp):
-    return wc.Side(oracle.QP, oracle.kkt_residuals, randqp, "oracle")
+    S = wc.Side(oracle.QP, oracle.kkt_residuals, randqp, "oracle")
+    S.one_shot = wc.oracle_one_shot(oracle.QP)
+    return S
 
 
 def device_side(dense, oracle, randqp, name):
-    return wc.Side(dense.QP, oracle.kkt_residuals, randqp, name)
+    S = wc.Side(dense.QP, oracle.kkt_residuals, randqp, name)
+    S.one_shot = dense.solve  # the product's one-shot function
+    return S
 
 
 def _scaling_oracle(q):

@@ -1,6 +1,6 @@
-"""The solver-flow test cases of the reference's dense wrapper suite (test/src/dense_qp_wrapper.cpp), restated
-one by one: same problem generator and seed, same sequence of init / solve / update / settings changes, same
-acceptance lines (primal and dual residual of the UNSCALED problem <= eps_abs, plus the exact-value checks on
+"""The solver-flow test cases of the reference's dense wrapper suite (test/src/dense_qp_wrapper.cpp) and of
+dense_qp_solve.cpp, dense_qp_eq.cpp, dense_unconstrained_qp.cpp, restated one by one: same problem generator and
+seed, same sequence of init / solve / update / settings changes, same acceptance lines (primal and dual residual of the UNSCALED problem <= eps_abs, plus the exact-value checks on
 rho / mu_eq / mu_eq_inv the reference makes).  Each case is a function `case(S)`; `S` is a `Side`: either the
 oracle (tests pin the restatement against the reference's own known answers) or the device engine behind the
 Python facade (emulator build on CPU, the real library on the GPU box).  A side records every checked solve
@@ -31,6 +31,8 @@ class Side:
     def __init__(self, make_qp, kkt, randqp, name):
         self.make_qp, self.kkt, self.R, self.name = make_qp, kkt, randqp, name
         self.trace = []
+        self.tol = 1e-8  # device against oracle on x, y, z (cases with a degenerate solution set widen it)
+        self.unique_x = True
 
     # -- generator stream (random_qp_problems.hpp:150-161, 308-364)
     def vector_rand(self, n):
@@ -76,7 +78,7 @@ class Side:
         pri, dua = self.kkt(m.H, m.g, m.A, m.b, m.C, m.l, m.u, x, y, z, l_box, u_box)
         self.trace.append(dict(x=x, y=y, z=z, iter=int(r.info.iter), iter_ext=int(r.info.iter_ext),
                                status=int(r.info.status), rho=float(r.info.rho), mu_eq=float(r.info.mu_eq),
-                               mu_in=float(r.info.mu_in)))
+                               mu_in=float(r.info.mu_in), tol=self.tol, unique_x=self.unique_x))
         assert pri <= eps, "%s: primal residual %.3e > %.1e" % (self.name, pri, eps)
         assert dua <= eps, "%s: dual residual %.3e > %.1e" % (self.name, dua, eps)
 
@@ -653,15 +655,185 @@ def case_primal_ldlt_mu_update(S):
     S.check(q, m, eps=1e-7)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# test/src/dense_qp_solve.cpp: the one-shot dense::solve function.  `S.one_shot` is the product's
+# proxsuite_amd.proxqp.dense.solve on a device side and, on the oracle side, the reference's free function restated on
+# top of the oracle's QP object (dense/wrapper.hpp:1000-1092: build a QP, copy the options, init, solve).
+def oracle_one_shot(make_qp):
+    def solve(H, g, A, b, C, l, u, x=None, y=None, z=None, eps_abs=None, eps_rel=None, rho=None, mu_eq=None,
+              mu_in=None, verbose=None, compute_preconditioner=True, compute_timings=False, max_iter=None,
+              initial_guess=EQ_GUESS):
+        n = H.shape[0]
+        n_eq = 0 if A is None else A.shape[0]
+        n_in = 0 if C is None else C.shape[0]
+        q = make_qp(n, n_eq, n_in, False, 1, 1)  # (dense Hessian, PrimalDualLDLT: wrapper.hpp:1043)
+        q.settings.initial_guess = initial_guess
+        for k, v in (("eps_abs", eps_abs), ("eps_rel", eps_rel), ("verbose", verbose), ("max_iter", max_iter)):
+            if v is not None:
+                setattr(q.settings, k, v)
+        q.settings.compute_timings = compute_timings
+        q.init(H, g, A, b, C, l, u, compute_preconditioner=compute_preconditioner, rho=rho, mu_eq=mu_eq, mu_in=mu_in)
+        q.solve(x, y, z)
+        return q
+
+    return solve
+
+
+def _results(r):
+    return r if hasattr(r, "info") and hasattr(r, "x") and not hasattr(r, "results") else r.results
+
+
+class _Holder:
+    def __init__(self, results):
+        self.results = results
+
+
+def _one_shot_check(S, m, **kw):
+    out = S.one_shot(*m.args(), **kw)
+    holder = out if hasattr(out, "results") else _Holder(out)
+    S.check(holder, m)
+    return holder.results
+
+
+# dense_qp_solve.cpp:16-83  fixed-size matrices: the solve function, then a QP object with equalities only
+def case_solve_fixed_sizes(S):
+    m, dim, n_eq, n_in = S.model(n_eq=5, n_in=2)
+    _one_shot_check(S, m, eps_abs=EPS, eps_rel=0)
+    q = S.make_qp(dim, n_eq, 0)
+    q.init(m.H, m.g, m.A, m.b, None, None, None)
+    q.settings.eps_abs = EPS
+    q.solve()
+    eq_only = M(m)
+    eq_only.C, eq_only.l, eq_only.u = np.zeros((0, dim)), np.zeros(0), np.zeros(0)
+    S.check(q, eq_only)
+
+
+def case_solve_function(S):  # :85-132
+    m, dim, n_eq, n_in = S.model()
+    _one_shot_check(S, m, eps_abs=EPS, eps_rel=0)
+
+
+def case_solve_with_rho(S):  # :134-182  CHECK(results.info.rho == 1e-7)
+    m, dim, n_eq, n_in = S.model()
+    r = _one_shot_check(S, m, eps_abs=EPS, eps_rel=0, rho=1e-7)
+    assert r.info.rho == 1e-7
+
+
+def case_solve_with_mu(S):  # :184-235
+    m, dim, n_eq, n_in = S.model()
+    _one_shot_check(S, m, eps_abs=EPS, eps_rel=0, mu_eq=1e-2, mu_in=1e-2)
+
+
+def case_solve_warm_start(S):  # :237-276
+    m, dim, n_eq, n_in = S.model()
+    x_wm, y_wm, z_wm = S.vector_rand(dim), S.vector_rand(n_eq), S.vector_rand(n_in)
+    _one_shot_check(S, m, x=x_wm, y=y_wm, z=z_wm, eps_abs=EPS, eps_rel=0)
+
+
+def case_solve_verbose(S):  # :278-329
+    m, dim, n_eq, n_in = S.model()
+    _one_shot_check(S, m, eps_abs=EPS, eps_rel=0, verbose=True)
+
+
+def case_solve_no_initial_guess(S):  # :331-385
+    m, dim, n_eq, n_in = S.model()
+    _one_shot_check(S, m, eps_abs=EPS, eps_rel=0, compute_preconditioner=True, compute_timings=True,
+                    initial_guess=NO_GUESS)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# test/src/dense_qp_eq.cpp:14-54  warm start AT the solution of an equality-constrained QP
+def case_start_from_solution(S):
+    dim, n_eq, n_in = 30, 6, 0
+    S.R.set_seed(1)
+    H = S.sparse_positive_definite_rand_not_compressed(dim, 1e-2, 0.15)
+    A = S.sparse_matrix_rand_not_compressed(n_eq, dim, 0.15)
+    sol = S.vector_rand(dim + n_eq)
+    xs, ys = sol[:dim], sol[dim:]
+    b = A @ xs
+    g = -H @ xs - A.T @ ys
+
+    class _Raw:
+        pass
+
+    raw = _Raw()
+    raw.H, raw.g, raw.A, raw.b, raw.C, raw.l, raw.u = H, g, A, b, np.zeros((0, dim)), np.zeros(0), np.zeros(0)
+    m = M(raw)
+    q = S.make_qp(dim, n_eq, n_in)
+    q.settings.eps_abs = EPS
+    q.settings.initial_guess = WARM
+    q.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u)
+    q.solve(xs, ys, np.zeros(0))
+    S.check(q, m)
+
+
+def _lp_with_equalities(hessian_type):
+    """dense_qp_eq.cpp:103-156 (dense Hessian object) and :158-215 (the dedicated LP interface, HessianType::Zero):
+    H = 0, g = -A^T y_sol keeps the LP bounded on the feasible set; the first dimensions of the reference's loop"""
+
+    def case(S):
+        S.R.set_seed(1)
+        # g = -A^T y_sol makes the cost constant on {A x = b}: every feasible point is optimal, x is not unique and
+        # is not compared between two arithmetic orders (y is: A has full row rank)
+        S.unique_x = False
+        S.tol = 1e-6
+        for dim in (10, 110):
+            m, dim, n_eq, n_in = S.model(dim=dim, n_eq=dim // 2, n_in=0, seed=None)
+            m.H = np.zeros((dim, dim))
+            y_sol = S.vector_rand(n_eq)
+            m.g = -m.A.T @ y_sol
+            q = S.qp(dim, n_eq, n_in, **({} if hessian_type is None else dict(hessian_type=hessian_type)))
+            _init_solve_check(S, q, m)
+
+    return case
+
+
+case_lp_with_equalities = _lp_with_equalities(None)
+case_lp_with_equalities_zero_hessian = _lp_with_equalities(0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# test/src/dense_unconstrained_qp.cpp:63-114  not strongly convex: g in the image of H
+def case_unconstrained_not_strongly_convex(S):
+    S.R.set_seed(1)
+    for dim in (10, 110):
+        m = M(S.R.dense_unconstrained_qp(dim, 0.15, 0.0))
+        x_sol = S.vector_rand(dim)
+        m.g = -m.H @ x_sol
+        q = S.make_qp(dim, 0, 0)
+        q.settings.eps_abs = EPS
+        _init_solve_check(S, q, m)
+
+
+def _unconstrained_identity(zero_g):  # :116-161 (g random as generated) and :163-208 (g = 0)
+    def case(S):
+        S.R.set_seed(1)
+        dim = 100
+        m = M(S.R.dense_unconstrained_qp(dim, 0.15, 1e-2))
+        m.H = np.eye(dim)
+        if zero_g:
+            m.g = np.zeros(dim)
+        q = S.make_qp(dim, 0, 0)
+        q.settings.eps_abs = EPS
+        _init_solve_check(S, q, m)
+
+    return case
+
+
+case_unconstrained_identity = _unconstrained_identity(False)
+case_unconstrained_identity_zero_g = _unconstrained_identity(True)
+
+
 CASES = {k[5:]: v for k, v in sorted(globals().items()) if k.startswith("case_")}
 
 
-def compare_traces(dev, ref, tol=1e-8):
+def compare_traces(dev, ref):
     """device run against the oracle run of the same case, checked solve by checked solve"""
     assert len(dev) == len(ref)
     for i, (a, b) in enumerate(zip(dev, ref)):
+        tol = a["tol"]
         assert a["status"] == b["status"], "solve %d: status %d != %d" % (i, a["status"], b["status"])
-        for k in ("x", "y", "z"):
+        for k in ("x", "y", "z") if a["unique_x"] else ("y", "z"):
             d = float(np.max(np.abs(a[k] - b[k]))) if a[k].size else 0.0
             assert d <= tol * (1.0 + float(np.max(np.abs(b[k]))) if b[k].size else 1.0), \
                 "solve %d: %s differs by %.3e" % (i, k, d)
