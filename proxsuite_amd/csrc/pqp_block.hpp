@@ -603,11 +603,10 @@ gemv_dual_part_len(int nt, int n)
 {
   return (nt / WAVE) * (n < 128 ? n : 128);
 }
-// (symv_lower keeps its partial column sums of ALL column blocks until one closing pass)
 __host__ __device__ inline int
 symv_lower_part_len(int nt, int n)
 {
-  return (nt / WAVE) * n;
+  return gemv_dual_part_len(nt, n);
 }
 
 // GATHER = true: row r of the product is row  r < rowsplit ? r : rowsplit + rowmap[r - rowsplit]
@@ -843,6 +842,9 @@ symv_lower_impl(cgptr M, int ld, int n, clptr v, lptr out, lptr part)
           out[r[u]] = (c0 == 0) ? pr : out[r[u]] + pr;
       }
     }
+    // the column sums of this block meet across the wavefronts; the rows c0 .. c0 + 127 they are added to have all
+    // their row sums by now (columns <= row)
+    const int bw = (n - c0 < 128) ? (n - c0) : 128;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -850,20 +852,20 @@ symv_lower_impl(cgptr M, int ld, int n, clptr v, lptr out, lptr part)
         double a = acc[c][e];
         a += __shfl_xor(a, 16);
         a += __shfl_xor(a, 32);
-        const int col = c0 + 16 * W * c + W * s + e;
-        if (g == 0 && col < n)
-          part[wid * n + col] = a;
+        const int cb = 16 * W * c + W * s + e;
+        if (g == 0 && cb < bw)
+          part[wid * bw + cb] = a;
       }
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += NT) {
-    double a = part[j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < bw; j += NT) {
+      double a = part[j];
 #pragma unroll
-    for (int q = 1; q < NW; ++q)
-      a += part[q * n + j];
-    out[j] += a;
+      for (int q = 1; q < NW; ++q)
+        a += part[q * bw + j];
+      out[c0 + j] += a;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
 template<int NT>

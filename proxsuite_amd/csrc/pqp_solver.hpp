@@ -293,6 +293,15 @@ struct Lds
                          // -> 8.55 ms, C1 1.33 -> 1.40 ms, 8192 QPs 299 k -> 294 k QPs/s): the triangular rows unbalance the
                          // wavefronts and the masked FMAs cost more than the 40 KB they save.  Off.
 #endif
+#ifndef PQP_HESS_LOWER_WIDE
+#define PQP_HESS_LOWER_WIDE 0 // the same switch for the 512- / 1024-thread kernels: also slower, although their matrices stream
+                              // from HBM (profiles/r03_ab_hess_lower_wide.txt: C4 -0.7 %, a 512-thread shape -9.5 %).  Off.
+#endif
+__host__ __device__ constexpr bool
+hess_lower(int nt)
+{
+  return nt == 256 ? (PQP_HESS_LOWER != 0) : (PQP_HESS_LOWER_WIDE != 0);
+}
 // One pass over A_s / C_s per product pair (gemv_dual) in the kernels of every width; 0 keeps the gemv pair over
 // the matrix and its transposed copy in the 512- / 1024-thread kernels (A/B switch).
 #ifndef PQP_DUAL_WIDE
@@ -309,7 +318,7 @@ __host__ __device__ inline int
 part_doubles(int nt, int tmax, int n)
 {
   const int a = gemv_part_len(nt, tmax);
-  const int b = !dual_pass(nt) ? 0 : (nt == 256 && PQP_HESS_LOWER) ? symv_lower_part_len(nt, n) : gemv_dual_part_len(nt, n);
+  const int b = (dual_pass(nt) || hess_lower(nt)) ? gemv_dual_part_len(nt, n) : 0; // (= symv_lower_part_len)
   return a > b ? a : b;
 }
 
@@ -1172,11 +1181,11 @@ struct Solver
   // elements of H_s one hess_mv pass reads (engine byte counter)
   __device__ __forceinline__ long hess_pass_elems() const
   {
-    return (NT == 256 && PQP_HESS_LOWER) ? (long)d.n * (d.n + 1) / 2 : (long)d.n * d.n;
+    return hess_lower(NT) ? (long)d.n * (d.n + 1) / 2 : (long)d.n * d.n;
   }
   __device__ __forceinline__ void hess_mv(clptr v, lptr out)
   {
-    if constexpr (NT == 256 && PQP_HESS_LOWER) // the lower triangle of the symmetric H_s only: half the bytes of a pass
+    if constexpr (hess_lower(NT)) // the lower triangle of the symmetric H_s only: half the bytes of a pass
       symv_lower<NT>(P.Hs(), d.n, d.n, v, out, L.part());
     else if constexpr (dual_pass(NT)) // column sums of the symmetric H_s = H_s v, with 16-byte loads
       gemv_dual<NT, true, false, false>(P.Hs(), d.n, d.n, d.n, v, v, out, out, L.part());
