@@ -294,6 +294,12 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   const bool vectors_in_hbm = h->lds_solve > 160 * 1024 || (force_hbm && force_hbm[0] == '1');
   if (vectors_in_hbm)
     h->nt = 1024;
+  // PQP_LDS_PAD_BYTES=<n>: experiment hook -- the solve kernel is launched with n more bytes of LDS than it uses, i.e.
+  // with the residency it would have if a matrix of that size lived in LDS beside the vectors (DESIGN.md section 4:
+  // what an LDS-resident H_s would cost in occupancy, measured without writing that kernel)
+  if (const char* e = std::getenv("PQP_LDS_PAD_BYTES"))
+    if (!vectors_in_hbm && std::atol(e) > 0 && h->lds_solve + size_t(std::atol(e)) <= 160 * 1024)
+      h->lds_solve += size_t(std::atol(e));
   const size_t B = size_t(batch_size), n = size_t(dim), ne = size_t(n_eq), ni = size_t(n_in),
                nc = size_t(d.nc), nd = size_t(d.nd);
   pqp::Batch& D = h->dev;
