@@ -842,7 +842,7 @@ def case_schur_factor_identity(lib, randqp, n=100, ne=50, ni=100, B=64, tol=1e-1
     return worst, edited
 
 
-def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True):
+def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1, 120)):
     """Randomised robustness sweep: shapes x {box constraints, Dense / Diagonal Hessian, DenseBackend Automatic /
     PrimalDualLDLT / PrimalLDLT} x {cold solve, then update(g) + WARM_START_WITH_PREVIOUS_RESULT re-solve, which
     restores the edited Schur factor -- holes included -- from HBM}, three QPs per shape.  Every QP must end with
@@ -861,7 +861,7 @@ def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True):
     t0 = time.time()
     bad = notes = forks = solved = info_bad = 0
     for it in range(count):
-        n = int(rng.integers(1, 120))
+        n = int(rng.integers(n_range[0], n_range[1]))
         ne = int(rng.integers(0, max(1, n // 2) + 1))
         ni = int(rng.integers(0, 2 * n + 2))
         box = bool(rng.integers(0, 3) == 0)

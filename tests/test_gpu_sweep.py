@@ -18,3 +18,13 @@ def test_random_sweep(oracle, randqp, seed):
     assert r["info_mismatch"] == 0, r
     assert r["solved"] >= 150, r
     assert r["forks"] <= max(3, 0.08 * (r["unsolved_alike"] + r["forks"])), r
+
+
+def test_random_sweep_large_shapes(oracle, randqp):
+    """the same sweep with n in 150 .. 420 (up to ~1300 constraint rows with boxes): the 512- and 1024-thread kernels
+    and the vectors-in-HBM kernel on random data, warm re-solves on edited factors included"""
+    r = pc.case_random_sweep(N.load(), oracle, randqp, 23, 16, n_range=(150, 420))
+    assert r["failures"] == 0, r
+    assert r["info_mismatch"] == 0, r
+    assert r["solved"] >= 40, r
+    assert r["forks"] <= 3, r
