@@ -45,6 +45,24 @@ def test_oracle_meets_reference_acceptance(oracle, randqp, name):
     assert S.trace
 
 
+def _on_python_problem(S, name):
+    """the same flow on the problem of the reference's Python suite (test/src/dense_qp_wrapper.py: its test_case_* /
+    test_sparse_problem_* are these flows on `generate_mixed_qp(10)`)"""
+    S.source = "python"
+    try:
+        wc.CASES[name](S)
+    except wc.NotForThisSource:
+        pytest.skip("this case builds its own problem (C++ suite only)")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_meets_reference_acceptance_python_suite_problem(oracle, randqp, name):
+    S = oracle_side(oracle, randqp)
+    S.scaling = _scaling_oracle
+    _on_python_problem(S, name)
+    assert S.trace
+
+
 @pytest.fixture(scope="module")
 def emu_dense():
     import build as emu_build
@@ -55,19 +73,36 @@ def emu_dense():
     N._lib = saved
 
 
-def _device_against_oracle(dense, oracle, randqp, name, label):
+def _device_against_oracle(dense, oracle, randqp, name, label, source="cpp"):
     ref = oracle_side(oracle, randqp)
     ref.scaling = _scaling_oracle
-    wc.CASES[name](ref)
     dev = device_side(dense, oracle, randqp, label)
     dev.scaling = _scaling_device
-    wc.CASES[name](dev)
+    if source == "python":
+        _on_python_problem(ref, name)
+        _on_python_problem(dev, name)
+    else:
+        wc.CASES[name](ref)
+        wc.CASES[name](dev)
     wc.compare_traces(dev.trace, ref.trace)
 
 
 @pytest.mark.parametrize("name", NAMES)
 def test_emulated_device_matches_oracle(emu_dense, oracle, randqp, name):
     _device_against_oracle(emu_dense, oracle, randqp, name, "device (emulator)")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_emulated_device_matches_oracle_python_suite_problem(emu_dense, oracle, randqp, name):
+    _device_against_oracle(emu_dense, oracle, randqp, name, "device (emulator)", source="python")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_matches_oracle_python_suite_problem(oracle, randqp, name):
+    from proxsuite_amd.proxqp import dense
+    N.load()
+    _device_against_oracle(dense, oracle, randqp, name, "device", source="python")
 
 
 @pytest.mark.gpu

@@ -27,10 +27,43 @@ class M:
         return self.H, self.g, self.A, self.b, self.C, self.l, self.u
 
 
+class NotForThisSource(Exception):
+    """the case builds its own problem and does not exist in the other suite"""
+
+
+class _Plain:
+    pass
+
+
+def mixed_qp(n, seed=1, reg=0.01):
+    """The problem family of the reference's Python tests (test/src/dense_qp_wrapper.py:20-51 `generate_mixed_qp`),
+    restated call for call so that numpy's global stream yields the same numbers: a sparse symmetric P shifted to
+    positive definite, one random matrix split into equalities (first n/4 rows) and one-sided inequalities
+    (from row n/4 on), right-hand sides from a fictitious solution, lower bounds at -1e20."""
+    import scipy.sparse as spa
+    np.random.seed(seed)
+    n_eq = n_in = int(n / 4)
+    m = n_eq + n_in
+    P = spa.random(n, n, density=0.075, data_rvs=np.random.randn, format="csc").toarray()
+    P = (P + P.T) / 2.0
+    s = max(np.absolute(np.linalg.eigvals(P)))
+    P = P + (abs(s) + reg) * np.eye(n)
+    q = np.random.randn(n)
+    A = spa.random(m, n, density=0.15, data_rvs=np.random.randn, format="csc").toarray(order="C")
+    v = np.random.randn(n)
+    np.random.rand(m)  # (the reference draws a vector here that it does not use)
+    u = A @ v
+    l = -1.0e20 * np.ones(m)
+    r = _Plain()
+    r.H, r.g, r.A, r.b, r.C, r.u, r.l = np.asarray(P), q, A[:n_eq, :], u[:n_eq], A[n_in:, :], u[n_in:], l[n_in:]
+    return M(r)
+
+
 class Side:
     def __init__(self, make_qp, kkt, randqp, name):
         self.make_qp, self.kkt, self.R, self.name = make_qp, kkt, randqp, name
         self.trace = []
+        self.source = "cpp"  # "python": the problem of the reference's Python suite instead of the C++ generator's
         self.tol = 1e-8  # device against oracle on x, y, z (cases with a degenerate solution set widen it)
         self.unique_x = True
 
@@ -57,6 +90,13 @@ class Side:
         return h
 
     def model(self, dim=10, n_eq=None, n_in=None, sparsity=0.15, seed=1):
+        if self.source == "python":
+            # the Python suite's problem (test/src/dense_qp_wrapper.py:20-51) for the cases that take the default
+            # model of the C++ suite; the other cases are specific to the C++ suite
+            if (dim, n_eq, n_in, sparsity, seed) != (10, None, None, 0.15, 1):
+                raise NotForThisSource()
+            self.R.set_seed(1)  # (the helpers that draw AFTER the model keep their own stream)
+            return mixed_qp(10), 10, 2, 2
         if seed is not None:
             self.R.set_seed(seed)
         n_eq = dim // 4 if n_eq is None else n_eq
@@ -130,9 +170,20 @@ def _mut_H(S, m, dim, n_eq, n_in):  # :163-293
     return dict(H=m.H)
 
 
+def _new_A(S, m, dim, n_eq):
+    """C++ suite: a fresh random A (b kept); Python suite: A and b of the same family with seed 2
+    (dense_qp_wrapper.py:3343, 3359)"""
+    if S.source == "python":
+        other = mixed_qp(dim, seed=2)
+        return dict(A=other.A, b=other.b)
+    return dict(A=S.sparse_matrix_rand_not_compressed(n_eq, dim, 0.15))
+
+
 def _mut_A(S, m, dim, n_eq, n_in):  # :294-426
-    m.A = S.sparse_matrix_rand_not_compressed(n_eq, dim, 0.15)
-    return dict(A=m.A)
+    upd = _new_A(S, m, dim, n_eq)
+    for k, v in upd.items():
+        setattr(m, k, v)
+    return upd
 
 
 def _mut_C(S, m, dim, n_eq, n_in):  # :427-559
@@ -428,17 +479,18 @@ def case_g_update_every_guess(S):
 # :4386-4642  A updated, for the five options
 def case_A_update_every_guess(S):
     m, dim, n_eq, n_in = S.model()
-    old_A = m.A.copy()
-    new_A = S.sparse_matrix_rand_not_compressed(n_eq, dim, 0.15)
+    old = dict(A=m.A.copy(), b=m.b.copy())
+    new = _new_A(S, m, dim, n_eq)
     made = {}
     for guess in _FIVE:
-        m.A = old_A
+        m.A, m.b = old["A"], old["b"]
         q = S.qp(dim, n_eq, n_in, guess=guess)
         q.init(*m.args())
         _solve_for(S, q, guess, made.get(EQ_GUESS))
         S.check(q, m)
-        m.A = new_A
-        q.update(A=m.A)
+        for k, v in new.items():
+            setattr(m, k, v)
+        q.update(**new)
         q.solve()
         S.check(q, m)
         made[guess] = q
@@ -483,6 +535,14 @@ def _defaults_after_updates(guess):
     default option); the other options are set at construction."""
 
     def case(S):
+        if guess == WS_PREV and S.source == "python":
+            # The C++ case switches to WARM_START_WITH_PREVIOUS_RESULT AFTER an update made under the default option.
+            # That update cleans the workspace (n_c = 0, refactorize = false: workspace.hpp:372), so the solve takes
+            # the first-solve branch without any setup_factorization (solver.hpp:1345-1375) and runs on the factor
+            # the PREVIOUS solve left -- harmless on the C++ suite's problem, whose active set is empty at the
+            # solution, a dimension mismatch (Eigen assertion / undefined behaviour in the reference, an assertion in
+            # the oracle) on a problem with active inequalities.  The Python suite sets the option before init.
+            raise NotForThisSource()
         m, dim, n_eq, n_in = S.model()
         rho, mu_eq = 1e-7, 1e-4
         at_start = None if guess == WS_PREV else guess
@@ -822,6 +882,59 @@ def _unconstrained_identity(zero_g):  # :116-161 (g random as generated) and :16
 
 case_unconstrained_identity = _unconstrained_identity(False)
 case_unconstrained_identity_zero_g = _unconstrained_identity(True)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# test/src/dense_qp_wrapper.py cases without a C++ twin
+def case_py_deterministic_behavior(S):  # :97-141  20 fresh objects give the same x, y, z to 1e-14
+    m = mixed_qp(100)
+    n, n_eq, n_in = 100, 25, 25
+    prev = None
+    for _ in range(21):
+        q = S.make_qp(n, n_eq, n_in)
+        q.settings.eps_abs = EPS
+        q.init(*m.args())
+        q.solve()
+        r = q.results
+        cur = (np.array(r.x), np.array(r.y), np.array(r.z))
+        if prev is None:
+            S.check(q, m)
+        else:
+            for a, b in zip(prev, cur):
+                assert np.max(np.abs(a - b)) <= 1e-14
+        prev = cur
+
+
+def case_py_exact_solution_known(S):  # :3919-3958  x* = (2, ..., 2, 3) at the solver's default precision
+    n = 150
+    Mx = np.eye(n)
+    for i in range(1, n - 1):
+        Mx[i, i + 1] = -1
+        Mx[i, i - 1] = 1
+    raw = _Plain()
+    raw.H, raw.g = Mx @ Mx.T, -np.ones(n)
+    raw.A, raw.b = np.zeros((0, n)), np.zeros(0)
+    raw.C, raw.l, raw.u = np.eye(n), 2.0 * np.ones(n), np.full(n, np.inf)
+    m = M(raw)
+    q = S.make_qp(n, 0, n)
+    q.init(m.H, m.g, None, None, m.C, m.l, m.u)
+    q.solve()
+    S.tol = 1e-6  # (default eps_abs 1e-5: two arithmetic orders stop within that of each other)
+    S.check(q, m, eps=1e-3)
+    assert np.max(np.abs(np.array(q.results.x) - np.array([2.0] * 149 + [3.0]))) <= 1e-3
+
+
+def case_py_initializing_with_None(S):  # :4540-4566
+    raw = _Plain()
+    raw.H = np.array([[65.0, -22.0, -16.0], [-22.0, 14.0, 7.0], [-16.0, 7.0, 5.0]])
+    raw.g = np.array([-13.0, 15.0, 7.0])
+    raw.A, raw.b, raw.C, raw.l, raw.u = np.zeros((0, 3)), np.zeros(0), np.zeros((0, 3)), np.zeros(0), np.zeros(0)
+    m = M(raw)
+    q = S.make_qp(3, 0, 0)
+    q.init(m.H, m.g, None, None, None, None, None)
+    q.solve()
+    S.tol = 1e-6
+    S.check(q, m, eps=1e-3)
 
 
 CASES = {k[5:]: v for k, v in sorted(globals().items()) if k.startswith("case_")}
