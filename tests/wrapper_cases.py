@@ -938,6 +938,11 @@ def case_py_initializing_with_None(S):  # :4540-4566
 
 
 CASES = {k[5:]: v for k, v in sorted(globals().items()) if k.startswith("case_")}
+# cases that build their own problem without Side.model(): nothing changes for them on the Python suite's family
+OWN_PROBLEM = {"py_deterministic_behavior", "py_exact_solution_known", "py_initializing_with_None",
+               "start_from_solution", "lp_with_equalities", "lp_with_equalities_zero_hessian",
+               "unconstrained_not_strongly_convex", "unconstrained_identity", "unconstrained_identity_zero_g"}
+assert OWN_PROBLEM <= set(CASES)
 
 
 def compare_traces(dev, ref):
