@@ -1438,12 +1438,18 @@ ldlt_factor_mfma(gptr M, int ld, int m, lptr d, lptr top)
   for (int kb = 0; kb < nbk; ++kb) {
     const int k0 = kb * NB;
     // ---- P1: update block row kb of the upper triangle
+    // Addressing: row (p * 16 + 4 q + lk) of M = a wave-uniform base (scalar registers) + a per-lane byte offset that does
+    // not change in the loop, so the loads carry no vector address arithmetic.  Operand lanes beyond column m hold
+    // clamped (finite) duplicates and are NOT zeroed: lane lr of the A operand only reaches row lr of the tile, lane lr of
+    // the B operand only its column lr, and rows / columns beyond m are never stored (P2 masks the diagonal tile it reads).
     for (int x = kb + w; x < nbk; x += NWV) {
       const int x0 = x * NB;
       const int xc = x0 + lr;
       const int xcc = (xc < m) ? xc : m - 1;
       const int kcol = k0 + lr;
       const int kcc = (kcol < m) ? kcol : m - 1;
+      const unsigned offk = (unsigned)(lk * ld + kcc) * 8u, offx = (unsigned)(lk * ld + xcc) * 8u;
+      const PQP_GLOBAL char* Mb = reinterpret_cast<const PQP_GLOBAL char*>(M);
       pqp_d4 acc;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1458,20 +1464,18 @@ ldlt_factor_mfma(gptr M, int ld, int m, lptr d, lptr top)
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int pr = ((p + h < kb) ? (p + h) : p) * NB + lk + 4 * q; // a full block: < m
-            ap[h][q] = M[(long)pr * ld + kcc];
-            bp[h][q] = M[(long)pr * ld + xcc];
-            dp[h][q] = d[pr];
+            const int pb = ((p + h < kb) ? (p + h) : p) * NB + 4 * q; // wave-uniform row of the group; a full block: < m
+            const PQP_GLOBAL char* rb = Mb + (long)pb * ld * 8;
+            ap[h][q] = *reinterpret_cast<const PQP_GLOBAL double*>(rb + offk);
+            bp[h][q] = *reinterpret_cast<const PQP_GLOBAL double*>(rb + offx);
+            dp[h][q] = d[pb + lk];
           }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           if (p + h < kb) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const double av = (kcol < m) ? -ap[h][q] * dp[h][q] : 0.0;
-              const double bv = (xc < m) ? bp[h][q] : 0.0;
-              acc = mfma_f64_16x16x4(av, bv, acc);
-            }
+            for (int q = 0; q < 4; ++q)
+              acc = mfma_f64_16x16x4(-ap[h][q] * dp[h][q], bp[h][q], acc);
           }
       }
 #pragma unroll
@@ -1645,22 +1649,27 @@ tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
     for (int j = w; j < i; j += NWV) {
       const int j0 = j * NB;
       pqp_d4 T = { 0.0, 0.0, 0.0, 0.0 };
+      // (addressing as in ldlt_factor_mfma's P1: wave-uniform row base + loop-invariant lane offset; the A-operand lanes of
+      // rows beyond n hold clamped duplicates and only reach rows of the tile that are never stored)
+      const unsigned offa = (unsigned)(lk * ld + irc) * 8u, offb = (unsigned)(lk * ld + j0 + lr) * 8u;
+      const PQP_GLOBAL char* Fb = reinterpret_cast<const PQP_GLOBAL char*>(F);
+      const PQP_GLOBAL char* Wb = reinterpret_cast<const PQP_GLOBAL char*>(WL);
       for (int k = j; k < i; k += 2) {
         double a[2][4], b[2][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int kr = ((k + h < i) ? (k + h) : k) * NB + 4 * q + lk; // full block: < n
-            a[h][q] = F[(long)kr * ld + irc];       // L[i0+lr][kr]   (upper mirror)
-            b[h][q] = WL[(long)kr * ld + j0 + lr];  // W[kr][j0+lr]
+            const long rowoff = (long)(((k + h < i) ? (k + h) : k) * NB + 4 * q) * ld * 8; // wave-uniform; full block: < n
+            a[h][q] = *reinterpret_cast<const PQP_GLOBAL double*>(Fb + rowoff + offa); // L[i0+lr][kr]   (upper mirror)
+            b[h][q] = *reinterpret_cast<const PQP_GLOBAL double*>(Wb + rowoff + offb); // W[kr][j0+lr]
           }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           if (k + h < i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              T = mfma_f64_16x16x4((ir < n) ? a[h][q] : 0.0, b[h][q], T);
+              T = mfma_f64_16x16x4(a[h][q], b[h][q], T);
           }
       }
       double iv[4];
