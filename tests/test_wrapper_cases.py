@@ -94,6 +94,38 @@ def test_emulated_device_matches_oracle(emu_dense, oracle, randqp, name):
     _device_against_oracle(emu_dense, oracle, randqp, name, "device (emulator)")
 
 
+# The same flows on the DenseBackend::PrimalLDLT engine (reference dense/solver.hpp:88-109, 171-227: no test of the
+# reference runs its update / warm-start flows on that backend; oracle and device must still agree solve by solve).
+ONE_SHOT = {n for n in NAMES if n.startswith("solve_")}  # dense::solve fixes PrimalDualLDLT (wrapper.hpp:1043)
+
+
+def _primal_ldlt(dense, oracle, randqp, name, label):
+    if name in ONE_SHOT or name == "primal_ldlt_mu_update":
+        pytest.skip("backend fixed by the case")
+    ref = oracle_side(oracle, randqp)
+    ref.scaling = _scaling_oracle
+    ref.backend = wc.PRIMAL_LDLT
+    wc.CASES[name](ref)
+    dev = device_side(dense, oracle, randqp, label)
+    dev.scaling = _scaling_device
+    dev.backend = wc.PRIMAL_LDLT
+    wc.CASES[name](dev)
+    wc.compare_traces(dev.trace, ref.trace)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_emulated_device_matches_oracle_primal_ldlt_backend(emu_dense, oracle, randqp, name):
+    _primal_ldlt(emu_dense, oracle, randqp, name, "device (emulator)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_matches_oracle_primal_ldlt_backend(oracle, randqp, name):
+    from proxsuite_amd.proxqp import dense
+    N.load()
+    _primal_ldlt(dense, oracle, randqp, name, "device")
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_emulated_device_matches_oracle_python_suite_problem(emu_dense, oracle, randqp, name):
     _device_against_oracle(emu_dense, oracle, randqp, name, "device (emulator)", source="python")

@@ -61,11 +61,17 @@ def mixed_qp(n, seed=1, reg=0.01):
 
 class Side:
     def __init__(self, make_qp, kkt, randqp, name):
-        self.make_qp, self.kkt, self.R, self.name = make_qp, kkt, randqp, name
+        self._make, self.kkt, self.R, self.name = make_qp, kkt, randqp, name
+        self.backend = None  # a DenseBackend value forced on every QP object the case builds (None: the case's own)
         self.trace = []
         self.source = "cpp"  # "python": the problem of the reference's Python suite instead of the C++ generator's
         self.tol = 1e-8  # device against oracle on x, y, z (cases with a degenerate solution set widen it)
         self.unique_x = True
+
+    def make_qp(self, *args, **kw):
+        if self.backend is not None and len(args) < 6:
+            kw.setdefault("dense_backend", self.backend)
+        return self._make(*args, **kw)
 
     # -- generator stream (random_qp_problems.hpp:150-161, 308-364)
     def vector_rand(self, n):
