@@ -40,6 +40,13 @@ constexpr double MACHINE_EPS = 2.220446049250313e-16;
 constexpr int ZG_DEPTH = PQP_ZG_DEPTH; // MFMA k-steps (of 4) whose operand loads are in flight together in build_ZG
 // 512- / 1024-thread kernels: build_ZG works on 2 x 2 tiles per wavefront (four operand tiles feed four products: a
 // third less operand traffic than the 1 x 2 units of the 256-thread kernels, whose matrices mostly sit in L2)
+// Line search of shapes with more breakpoints than threads: bracket the zero of phi' first, evaluate exactly only around it
+#ifndef PQP_LS_UNROLL
+#define PQP_LS_UNROLL 4
+#endif
+#ifndef PQP_LS_BRACKET
+#define PQP_LS_BRACKET 1
+#endif
 #ifndef PQP_ZG_BLOCK2
 #define PQP_ZG_BLOCK2 1
 #endif
@@ -2807,6 +2814,9 @@ struct Solver
     const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
     double sa = 0, sb = 0, sa2 = 0, sb2 = 0;
     clptr vCdx = L.Cdx(), vrup = L.rup(), vsi = L.si(), vdz = L.dz(), vz = L.z();
+    // (four constraints per trip: their LDS reads are issued together -- one trip of this loop is a read latency long --
+    // while the sums still take their terms in the order of the constraints)
+#pragma unroll PQP_LS_UNROLL
     for (int i = 0; i < nc; ++i) {
       double cdx = vCdx[i];
       double up0 = vrup[i], lo0 = vsi[i];
@@ -2830,6 +2840,270 @@ struct Solver
       a_in = info.mu_in_inv * sa + info.nu * info.mu_in_inv * sa2;
       b_in = info.mu_in_inv * sb + info.nu * info.mu_in_inv * sb2;
     }
+  }
+
+  // phi'(alpha) at three step lengths with the inequality sums spread over the workgroup (thread order: NOT the
+  // reference's order of summation -- these values only steer the bracket), plus the number of this thread's breakpoints
+  // in (lo, al[p]] and in (lo, hi], all in ONE fused reduction.  `mag` bounds the size of the terms of each value.
+  __device__ __forceinline__ void ls_grad3(const double (&al)[3], double a0, double b0, const double (&mine)[2], double lo,
+                                           double hi, double (&g)[3], double (&mag)[3], double (&cle)[3], double& ctot)
+  {
+    const int nc = d.nc;
+    const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
+    double sv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      sv[k] = 0.0;
+    for (int i = threadIdx.x; i < nc; i += NT) {
+      const double cdx = L.Cdx()[i], up0 = L.rup()[i], lo0 = L.si()[i];
+      const double dzi = L.dz()[i] * info.mu_in, zi = L.z()[i] * info.mu_in;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bool up = (up0 + cdx * al[p]) > 0.;
+        const bool lw = (lo0 + cdx * al[p]) < 0.;
+        const double e = (up || lw) ? cdx : 0.0;
+        const double apz = (up ? up0 : 0.0) + (lw ? lo0 : 0.0);
+        sv[4 * p + 0] = fma(e, e, sv[4 * p + 0]);
+        sv[4 * p + 1] = fma(apz, e, sv[4 * p + 1]);
+        if (!gpdal) {
+          const double e2 = e - dzi, apz2 = apz - zi;
+          sv[4 * p + 2] = fma(e2, e2, sv[4 * p + 2]);
+          sv[4 * p + 3] = fma(e2, apz2, sv[4 * p + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (mine[r] > lo && mine[r] <= hi) {
+        sv[15] += 1.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          if (mine[r] <= al[p])
+            sv[12 + p] += 1.0;
+      }
+    double none[1] = { 0.0 };
+    R.template mixed<16, 0>(sv, none);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      double ai, bi;
+      if (gpdal) {
+        ai = info.mu_in_inv * sv[4 * p + 0] / st.alpha_gpdal;
+        bi = info.mu_in_inv * sv[4 * p + 1] / st.alpha_gpdal;
+      } else {
+        ai = info.mu_in_inv * sv[4 * p + 0] + info.nu * info.mu_in_inv * sv[4 * p + 2];
+        bi = info.mu_in_inv * sv[4 * p + 1] + info.nu * info.mu_in_inv * sv[4 * p + 3];
+      }
+      g[p] = (a0 + ai) * al[p] + (b0 + bi);
+      mag[p] = fabs((a0 + ai) * al[p]) + fabs(b0) + fabs(bi);
+      cle[p] = sv[12 + p];
+    }
+    ctot = sv[15];
+  }
+
+  // The exact line search through a bracket of its zero (see primal_dual_ls).  Returns false when the full evaluation
+  // has to decide; true with the step length otherwise -- the SAME floating-point value the full evaluation returns,
+  // because the two breakpoints it interpolates between and their phi' are found and evaluated identically.
+  __device__ __forceinline__ bool ls_bracket(double a0, double b0, double& result)
+  {
+    const int nc = d.nc;
+    const double INF = __builtin_inf();
+    constexpr int WCAP = 32;          // breakpoints evaluated exactly at most (one lane each, one wavefront)
+    constexpr double SURE = 1.0e-10;  // |phi'| above this fraction of the size of its terms: the sign is trusted
+    // this thread's breakpoints (as in the full evaluation below)
+    double mine[2] = { -1.0, -1.0 };
+    double cnt = 0, amax = 0, amin_neg = -INF;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int t = threadIdx.x + rep * NT;
+      if (t < 2 * nc) {
+        const int i = t >> 1;
+        const double cdx = L.Cdx()[i];
+        double al = -1.0;
+        if (cdx != 0.) {
+          const double num = (t & 1) ? L.si()[i] : L.rup()[i];
+          al = -num / (cdx + MACHINE_EPS);
+        }
+        if (al > MACHINE_EPS) {
+          mine[rep] = al;
+          cnt += 1.0;
+          amax = fmax(amax, al);
+          amin_neg = fmax(amin_neg, -al);
+        }
+      }
+    }
+    {
+      double sv[1] = { cnt };
+      double mv[2] = { amax, amin_neg };
+      R.template mixed<1, 2>(sv, mv);
+      cnt = sv[0];
+      amax = mv[0];
+      amin_neg = mv[1];
+    }
+    // The breakpoints spread over many decades (ratios of residuals to step components): the bracket is refined on a
+    // geometric scale between `floor_` (half the smallest breakpoint: phi' has no kink below it) and hi.
+    const double floor_ = -0.5 * amin_neg;
+    if (!(cnt > 8.0) || !(amax < INF))
+      return false; // few breakpoints (or none: linesearch.hpp:405-419): the full evaluation is as cheap
+    // bracket (lo, hi]: phi'(lo) < 0 surely, phi'(hi) > 0 surely
+    double lo = 0.0, hi = amax, inside = cnt;
+    bool all_negative = false;
+    {
+      const double al[3] = { 0.0, sqrt(floor_) * sqrt(amax), amax };
+      double g[3], mag[3], cle[3], ctot;
+      ls_grad3(al, a0, b0, mine, 0.0, amax, g, mag, cle, ctot);
+      if (!(g[0] < -SURE * mag[0]))
+        return false;
+      if (g[2] < -SURE * mag[2]) {
+        all_negative = true; // no breakpoint with phi' >= 0: linesearch.hpp:496-526
+      } else if (!(g[2] > SURE * mag[2])) {
+        return false;
+      } else if (g[1] < -SURE * mag[1]) {
+        lo = al[1];
+        inside = ctot - cle[1];
+      } else if (g[1] > SURE * mag[1]) {
+        hi = al[1];
+        inside = cle[1];
+      }
+    }
+    if (!all_negative) {
+      for (int round = 0; round < 6 && inside > 6.0; ++round) {
+        const double base = fmax(lo, floor_);
+        const double r4 = sqrt(sqrt(hi / base)); // quarter steps of the logarithm
+        const double al[3] = { base * r4, base * r4 * r4, base * r4 * r4 * r4 };
+        double g[3], mag[3], cle[3], ctot;
+        ls_grad3(al, a0, b0, mine, lo, hi, g, mag, cle, ctot);
+        // the leftmost sure positive closes the bracket, the rightmost sure negative to its left opens it; a value too small
+        // to trust (the zero is next to that point) tightens nothing -- a wrong bracket is caught by the exact values below
+        double nlo = lo, nhi = hi, below = 0.0, upto = ctot;
+        int first_pos = 3;
+#pragma unroll
+        for (int p = 2; p >= 0; --p)
+          if (g[p] > SURE * mag[p])
+            first_pos = p;
+        if (first_pos < 3) {
+          nhi = al[first_pos];
+          upto = cle[first_pos];
+        }
+        bool moved = first_pos < 3;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          if (p < first_pos && g[p] < -SURE * mag[p]) {
+            nlo = al[p];
+            below = cle[p];
+            moved = true;
+          }
+        const bool stuck = !moved;
+        if (!(nlo < nhi))
+          return false;
+        lo = nlo;
+        hi = nhi;
+        inside = upto - below;
+        if (stuck)
+          break;
+      }
+      if (inside > double(WCAP - 3))
+        return false;
+    }
+    // the breakpoints to evaluate exactly: those in (lo, hi], the last one at or below lo, the first one above hi
+    // (all_negative: the largest breakpoint alone)
+    double pred = 0.0, succ = INF;
+    if (!all_negative) {
+      double below = 0.0, above = -INF;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep)
+        if (mine[rep] > 0) {
+          if (mine[rep] <= lo)
+            below = fmax(below, mine[rep]);
+          if (mine[rep] > hi)
+            above = fmax(above, -mine[rep]);
+        }
+      double none[1] = { 0.0 };
+      double mv[2] = { below, above };
+      liptr counter = L.iscr();
+      if (threadIdx.x == 0)
+        counter[0] = 1; // slot 0: alpha = 0 (below)
+      R.template mixed<0, 2>(none, mv);
+      pred = mv[0];
+      succ = -mv[1];
+    } else {
+      liptr counter = L.iscr();
+      if (threadIdx.x == 0)
+        counter[0] = 1;
+      __syncthreads();
+    }
+    lptr list = L.part(); // [0, WCAP): alpha, [WCAP, 2 WCAP): phi'
+    if (L.part_len() < 2 * WCAP)
+      return false;
+    {
+      liptr counter = L.iscr();
+      // slot 0 holds alpha = 0: phi'(0) is what the interpolation starts from when no breakpoint precedes the zero
+      // (linesearch.hpp:477-495), evaluated beside the others instead of in a serial loop of its own afterwards
+      if (threadIdx.x == 0)
+        list[0] = 0.0;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const double a = mine[rep];
+        const bool take = all_negative ? (a > 0 && a == amax) : (a > 0 && ((a > lo && a <= hi) || a == pred || a == succ));
+        if (take) {
+          const int slot = atomicAdd((int*)counter, 1);
+          if (slot < WCAP)
+            list[slot] = a;
+        }
+      }
+      __syncthreads();
+    }
+    const int nwin = uni(L.iscr()[0]);
+    if (nwin > WCAP || nwin <= 1)
+      return false;
+    count(ST_N_LS_BREAKPOINTS, nwin); // (stats build: breakpoints evaluated exactly)
+    if (threadIdx.x < nwin) {
+      const double al = list[threadIdx.x];
+      double ai, bi;
+      ls_ineq_terms(al, ai, bi);
+      list[WCAP + threadIdx.x] = (threadIdx.x == 0) ? (b0 + bi) : ((a0 + ai) * al + (b0 + bi));
+    }
+    __syncthreads();
+    // every thread reads the short list: the selections of the full evaluation without their reductions
+    double afp = INF, gfp = -INF;
+    for (int k = 1; k < nwin; ++k) {
+      const double al = list[k], gr = list[WCAP + k];
+      if (!(gr < 0) && al < afp)
+        afp = al;
+    }
+    if (all_negative) {
+      if (afp < INF)
+        return false; // the exact value at the largest breakpoint is not negative after all
+      const double aln = amax;
+      double ai, bi;
+      ls_ineq_terms(2 * aln + 1, ai, bi);
+      result = -(b0 + bi) / (a0 + ai);
+      return true;
+    }
+    if (!(afp < INF))
+      return false;
+    if (pred > 0.0 && !(afp > pred))
+      return false; // phi'(pred) >= 0 exactly: the zero lies further left than the bracket said
+    double aln = 0.0;
+    for (int k = 1; k < nwin; ++k) {
+      const double al = list[k], gr = list[WCAP + k];
+      if (al == afp && !(gr < 0))
+        gfp = fmax(gfp, gr);
+      if (al < afp)
+        aln = fmax(aln, al);
+    }
+    double gln = -INF;
+    for (int k = 1; k < nwin; ++k)
+      if (list[k] == aln)
+        gln = fmax(gln, list[WCAP + k]);
+    const double g_at_0 = list[WCAP];
+    __syncthreads(); // (the list lives in `part`: nobody may reuse it before everybody has read it)
+    if (aln == 0.0) { // no breakpoint before afp: linesearch.hpp:477-495
+      if (pred > 0.0)
+        return false;
+      gln = g_at_0; // = b0 + b_in(0): see the evaluation of slot 0
+    }
+    result = fabs(aln - gln * (afp - aln) / (gfp - gln)); // linesearch.hpp:534-536
+    return true;
   }
 
   __device__ __forceinline__ double primal_dual_ls(double& dw_max)
@@ -2887,9 +3161,24 @@ struct Solver
       a0 += info.mu_in * (1. - st.alpha_gpdal) * s_dz2;
       b0 += info.mu_in * (1. - st.alpha_gpdal) * s_dzz;
     }
+    const double INF = __builtin_inf();
+    // More breakpoints than threads (2 n_c > NT: the diagonal-structure configurations C5 / C5box, constraint-heavy
+    // shapes): the all-breakpoints evaluation below would run its serial loop twice in every lane.  phi' is monotone,
+    // and only its values at the two breakpoints around its zero are used: locate the zero with a few workgroup-parallel
+    // evaluations, then evaluate -- in the reference's order, bit for bit as below -- only the handful of breakpoints
+    // around it.  Any doubt (an evaluation too close to zero to trust its sign, too many breakpoints left in the bracket,
+    // an exact value that contradicts the bracket) falls back to the full evaluation.
+    if constexpr (PQP_LS_BRACKET && SPEC == 0 && NT == 256) // (the kernels that serve such shapes; the C2 kernel stays as it is)
+    if (2 * nc > NT) {
+      double alpha_b;
+      sub_tic(ST_CYC_LS_EVAL);
+      const bool ok = ls_bracket(a0, b0, alpha_b);
+      sub_toc(ST_CYC_LS_EVAL);
+      if (ok)
+        return alpha_b;
+    }
     // breakpoints (linesearch.hpp:378-391): every breakpoint gets its own thread and
     // its own phi'(alpha) -- no sort, no sequential walk
-    const double INF = __builtin_inf();
     sub_tic(ST_CYC_LS_EVAL);
     double first_pos_alpha = INF;
     double my_alpha[2] = { -1.0, -1.0 };

@@ -842,7 +842,7 @@ def case_schur_factor_identity(lib, randqp, n=100, ne=50, ni=100, B=64, tol=1e-1
     return worst, edited
 
 
-def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1, 120)):
+def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1, 120), shapes=None):
     """Randomised robustness sweep: shapes x {box constraints, Dense / Diagonal Hessian, DenseBackend Automatic /
     PrimalDualLDLT / PrimalLDLT} x {cold solve, then update(g) + WARM_START_WITH_PREVIOUS_RESULT re-solve, which
     restores the edited Schur factor -- holes included -- from HBM}, three QPs per shape.  Every QP must end with
@@ -873,6 +873,9 @@ def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1
                 ni, box = 0, True
         if ne + ni == 0 and not box:
             ni = 1
+        if shapes is not None:  # fixed shapes instead of the random draw (same data generation and checks)
+            n, ne, ni, box, hess, backend = shapes[it]
+            hess, backend = HessianType(hess), DenseBackend(backend)
         B = 3
         m = R.dense_strongly_convex_qp_batch(B, n, ne, ni, float(rng.uniform(0.1, 0.9)), 1e-2, seed0=int(rng.integers(0, 10000)))
         H = m.H if hess == HessianType.Dense else np.stack([np.diag(np.diag(h)) for h in m.H])

@@ -149,3 +149,15 @@ def test_vectors_in_hbm_path(lib, oracle, randqp, monkeypatch):
     monkeypatch.setenv("PQP_FORCE_HBM_VECTORS", "1")
     pc.case_random_batch(lib, oracle, randqp, 30, 7, 9, B=2)
     pc.case_box_constraints(lib, oracle, randqp, seeds=2)
+
+
+def test_line_search_bracket_path(lib, oracle, randqp):
+    """more breakpoints than threads (2 n_c > 256 in a 256-thread kernel of the general signature): the line search
+    brackets the zero of phi' and evaluates exactly only around it -- iterates and Info counters must stay the oracle's.
+    C5 forms at dim 140 (diagonal-structure path), then a dense boxed shape and a diagonal-Hessian shape with general C,
+    cold solve and warm re-solve"""
+    pc.case_c5(lib, oracle, randqp, B=2, sample=2, box=False, dim=140)
+    pc.case_c5(lib, oracle, randqp, B=2, sample=2, box=True, dim=140)
+    r = pc.case_random_sweep(lib, oracle, randqp, 3, 2, verbose=True,
+                             shapes=[(60, 10, 80, True, 1, 1), (70, 0, 150, False, 2, 1)])
+    assert r["failures"] == 0 and r["info_mismatch"] == 0 and r["solved"] >= 4, r
