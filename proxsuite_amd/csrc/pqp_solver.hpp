@@ -3056,7 +3056,59 @@ struct Solver
     if (nwin > WCAP || nwin <= 1)
       return false;
     count(ST_N_LS_BREAKPOINTS, nwin); // (stats build: breakpoints evaluated exactly)
-    if (threadIdx.x < nwin) {
+    // Exact values.  GPDAL merit, at most four candidates: the per-constraint terms (e_i, a_i) of every candidate -- which
+    // constraints are active at that step length -- are computed by the whole workgroup into LDS vectors that are dead
+    // between two Newton solves (right-hand sides, refinement errors, scratch), and each candidate's lane then only
+    // runs the two chains of fused multiply-adds over them, in the order of the constraints: the same operations on the
+    // same values as ls_ineq_terms, without the tests and selections inside the serial loop.
+    bool chained = false;
+    if (st.merit_function_type == PQP_MERIT_GPDAL && nwin <= 4) {
+      const int n = d.n;
+      int cap = 2; // rd / ed hold n_d >= n_c doubles, t2 max(n, n_d), zfull n_c
+      if (n >= nc)
+        cap = (L.part_len() - 2 * WCAP >= nc) ? 4 : 3; // rx, ex, t1 hold n doubles; the tail of `part` behind the list
+      if (nwin <= cap) {
+        chained = true;
+        lptr e0 = L.rd(), a0v = L.ed(), e1 = L.t2(), a1v = L.zfull(), e2 = L.rx(), a2v = L.ex(), e3 = L.t1(),
+             a3v = L.part() + 2 * WCAP;
+        const double al0 = list[0], al1 = list[nwin > 1 ? 1 : 0], al2 = list[nwin > 2 ? 2 : 0], al3 = list[nwin > 3 ? 3 : 0];
+        for (int i = threadIdx.x; i < nc; i += NT) {
+          const double cdx = L.Cdx()[i], up0 = L.rup()[i], lo0 = L.si()[i];
+#define PQP_LS_TERM(alpha, ev, av)                                                                                     \
+  {                                                                                                                   \
+    const bool up = (up0 + cdx * (alpha)) > 0.;                                                                       \
+    const bool lo = (lo0 + cdx * (alpha)) < 0.;                                                                       \
+    (ev)[i] = (up || lo) ? cdx : 0.0;                                                                                 \
+    (av)[i] = (up ? up0 : 0.0) + (lo ? lo0 : 0.0);                                                                    \
+  }
+          PQP_LS_TERM(al0, e0, a0v)
+          if (nwin > 1)
+            PQP_LS_TERM(al1, e1, a1v)
+          if (nwin > 2)
+            PQP_LS_TERM(al2, e2, a2v)
+          if (nwin > 3)
+            PQP_LS_TERM(al3, e3, a3v)
+#undef PQP_LS_TERM
+        }
+        __syncthreads();
+        if (threadIdx.x < nwin) {
+          const int c = threadIdx.x;
+          clptr ev = (c == 0) ? (clptr)e0 : (c == 1) ? (clptr)e1 : (c == 2) ? (clptr)e2 : (clptr)e3;
+          clptr av = (c == 0) ? (clptr)a0v : (c == 1) ? (clptr)a1v : (c == 2) ? (clptr)a2v : (clptr)a3v;
+          double sa = 0, sb = 0;
+#pragma unroll 4
+          for (int i = 0; i < nc; ++i) {
+            const double e = ev[i], apz = av[i];
+            sa = fma(e, e, sa);
+            sb = fma(apz, e, sb);
+          }
+          const double ai = info.mu_in_inv * sa / st.alpha_gpdal, bi = info.mu_in_inv * sb / st.alpha_gpdal;
+          const double al = list[c];
+          list[WCAP + c] = (c == 0) ? (b0 + bi) : ((a0 + ai) * al + (b0 + bi));
+        }
+      }
+    }
+    if (!chained && threadIdx.x < nwin) {
       const double al = list[threadIdx.x];
       double ai, bi;
       ls_ineq_terms(al, ai, bi);
