@@ -2882,7 +2882,23 @@ struct Solver
             sv[12 + p] += 1.0;
       }
     double none[1] = { 0.0 };
-    R.template mixed<16, 0>(sv, none);
+    if (gpdal) {
+      // (GPDAL: the second pair of sums does not exist -- ten values instead of sixteen through the reduction)
+      double pk[10] = { sv[0], sv[1], sv[4], sv[5], sv[8], sv[9], sv[12], sv[13], sv[14], sv[15] };
+      R.template mixed<10, 0>(pk, none);
+      sv[0] = pk[0];
+      sv[1] = pk[1];
+      sv[4] = pk[2];
+      sv[5] = pk[3];
+      sv[8] = pk[4];
+      sv[9] = pk[5];
+      sv[12] = pk[6];
+      sv[13] = pk[7];
+      sv[14] = pk[8];
+      sv[15] = pk[9];
+    } else {
+      R.template mixed<16, 0>(sv, none);
+    }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
       double ai, bi;
