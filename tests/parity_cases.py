@@ -886,10 +886,13 @@ def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1
         g2 = m.g + 0.1 * rng.standard_normal(m.g.shape)
         b = N.Batch(B, n, ne, ni, box_constraints=box, hessian_type=int(hess), dense_backend=int(backend), lib=lib)
         qs = []
+        merit = 1 if it % 3 == 2 else 0  # every third shape with the PDAL merit function (settings.hpp: GPDAL is the default)
         for i in range(B):
             s = b.settings(i); s.eps_abs = 1e-9; s.eps_rel = 0; s.initial_guess = int(InitialGuess.NO_INITIAL_GUESS); s.max_iter = 2000
+            s.merit_function_type = merit
             q = O.QP(n, ne, ni, box_constraints=box, hessian_type=hess, dense_backend=backend)
             q.settings.eps_abs = 1e-9; q.settings.eps_rel = 0; q.settings.initial_guess = InitialGuess.NO_INITIAL_GUESS; q.settings.max_iter = 2000
+            q.settings.merit_function_type = merit
             qs.append(q)
         args = lambda i=None: [a if i is None else a[i] for a in (H, m.g)] + [
             (m.A if i is None else m.A[i]) if ne else None, (m.b if i is None else m.b[i]) if ne else None,
