@@ -13,7 +13,8 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 import os
 nr = tuple(int(v) for v in os.environ.get('PQP_SWEEP_N', '1,120').split(','))
-r = pc.case_random_sweep(lib, O, R, seed, count, n_range=nr)
+only = os.environ.get('PQP_SWEEP_ONLY')
+r = pc.case_random_sweep(lib, O, R, seed, count, n_range=nr, only=None if only is None else int(only))
 print("sweep2: %d shapes x 3 QPs x 2 phases, %d failures, %d QPs unsolved alike in the oracle, %d infeasible QPs "
       "ending with different non-SOLVED statuses, %d SOLVED QPs compared of which %d with different Info counters, %.1f s"
       % (count, r["failures"], r["unsolved_alike"], r["forks"], r["solved"], r["info_mismatch"], r["seconds"]))
