@@ -17,6 +17,24 @@ ROOT = HERE.parent.parent
 LIB = HERE / "libpqp_emu.so"
 
 
+def build_variant(tag, defines):
+    """A second emulator library with extra -D switches (A/B of a code path on the CPU: tests/test_emu_parity.py)."""
+    csrc = ROOT / "proxsuite_amd" / "csrc"
+    out = HERE / ("libpqp_emu_%s.so" % tag)
+    srcs = [csrc / "pqp_capi.hip", csrc / "pqp_kernels.hip", HERE / "hip_emu.cpp"]
+    deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", csrc / "pqp_host.hpp", HERE / "hip_emu.hpp", Path(__file__)]
+    if out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):
+        return out
+    cmd = ["g++", "-std=gnu++17", "-fPIC", "-shared", "-O2", "-pthread", "-fno-strict-aliasing", "-DPQP_STATS",
+           *["-D" + d for d in defines], "-Wno-unknown-pragmas", "-Wno-attributes",
+           "-I", str(HERE / "include"), "-I", str(ROOT / "include"), "-I", str(csrc),
+           "-x", "c++", *map(str, srcs), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("emulator variant build failed:\n" + r.stdout + r.stderr)
+    return out
+
+
 def build(force=False, debug=False):
     csrc = ROOT / "proxsuite_amd" / "csrc"
     srcs = [csrc / "pqp_capi.hip", csrc / "pqp_kernels.hip", HERE / "hip_emu.cpp"]

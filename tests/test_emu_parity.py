@@ -162,3 +162,41 @@ def test_line_search_bracket_path(lib, oracle, randqp):
                              shapes=[(60, 10, 80, True, 1, 1), (70, 0, 150, False, 2, 1), (60, 10, 80, True, 1, 1)])
     # (the third shape runs with the PDAL merit function: sixteen-value bracket rounds, exact values through ls_ineq_terms)
     assert r["failures"] == 0 and r["info_mismatch"] == 0 and r["solved"] >= 6, r
+
+
+def test_line_search_bracket_is_bit_identical_to_the_full_evaluation(randqp):
+    """The bracketing line search claims the SAME floating-point step as the all-breakpoints evaluation: the same device
+    sources compiled with -DPQP_LS_BRACKET=0 must give bit-identical x, y, z and Info counters on shapes that take the
+    bracket (the C5 form at dim 130 with both merit functions, a dense boxed shape)."""
+    import build as emu_build
+    from proxsuite_amd._ctypes_defs import HessianType
+    full = N.NativeLib(emu_build.build_variant("nobracket", ["PQP_LS_BRACKET=0"]))
+    brk = N.NativeLib(emu_build.build())
+
+    def run(libx, n, ne, ni, box, hess, merit, seed):
+        B = 2
+        m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.4, 1e-2, seed0=seed)
+        H = m.H if hess == 1 else np.stack([np.diag(np.diag(h)) for h in m.H])
+        rng = np.random.default_rng(seed)
+        kw = {}
+        if box:
+            xs = rng.standard_normal((B, n)); sh = rng.uniform(0.1, 1.0, (B, n))
+            kw = dict(l_box=xs - sh, u_box=xs + sh)
+        b = N.Batch(B, n, ne, ni, box_constraints=box, hessian_type=hess, lib=libx)
+        for i in range(B):
+            s = b.settings(i); s.eps_abs = 1e-9; s.eps_rel = 0; s.initial_guess = 0; s.merit_function_type = merit
+        b.init(-1, H, m.g, m.A if ne else None, m.b if ne else None, m.C if ni else None, m.l if ni else None,
+               m.u if ni else None, **kw)
+        b.solve()
+        x, y, z, se, si, info = b.results()
+        out = (x.copy(), y.copy(), z.copy(), [(info[i].iter, info[i].iter_ext, info[i].status) for i in range(B)])
+        b.close()
+        return out
+
+    for (n, ne, ni, box, hess, merit, seed) in [(130, 0, 130, False, 2, 0, 1), (130, 0, 130, False, 2, 1, 3),
+                                                (60, 10, 80, True, 1, 0, 4)]:
+        a = run(brk, n, ne, ni, box, hess, merit, seed)
+        f = run(full, n, ne, ni, box, hess, merit, seed)
+        assert a[3] == f[3], (n, ne, ni, box, hess, merit, a[3], f[3])
+        for u, v in zip(a[:3], f[:3]):
+            assert np.array_equal(u, v), (n, ne, ni, box, hess, merit, float(np.max(np.abs(u - v))))
