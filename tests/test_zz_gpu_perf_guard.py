@@ -37,6 +37,30 @@ def test_c2_kernel_time_within_ten_percent(randqp):
         best, limit, guard["c2_kernel_ms"], guard["source"])
 
 
+def test_c5_kernel_time_within_ten_percent(randqp):
+    """the structured configuration (BASELINE.json configs[4]: 4096 x (200, 0, 200), diagonal Hessian, C = I), whose time is
+    the line search's: the bracketing evaluation must stay in place"""
+    import parity_cases as pc
+    from proxsuite_amd._ctypes_defs import HessianType
+    guard = json.load(open(os.path.join(ROOT, "profiles", "perf_guard.json")))
+    B, dim = 4096, 200
+    H, g, Cm, l, u = pc.c5_models(randqp, B, dim)
+    b = N.Batch(B, dim, 0, dim, hessian_type=int(HessianType.Diagonal), lib=N.load())
+    b.set_all_settings(eps_abs=1e-9, eps_rel=0.0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS))
+    b.init(-1, H, g, None, None, Cm, l, u)
+    b.solve()
+    ms = []
+    for _ in range(5):
+        b.solve()
+        ms.append(b.last_solve_ms)
+    x, y, z, se, si, info = b.results()
+    assert all(info[i].status == 0 for i in range(B))
+    b.close()
+    best = min(ms)
+    limit = 1.10 * guard["c5_kernel_ms"]
+    assert best <= limit, "C5 solve kernel %.3f ms > %.3f ms (recorded %.3f ms + 10 %%)" % (best, limit, guard["c5_kernel_ms"])
+
+
 def test_kernel_resource_record_exists():
     res = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_resources.json")))
     c2 = res["pqp_solve_kernel<256,4,1>"]
