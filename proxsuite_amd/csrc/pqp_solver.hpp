@@ -47,6 +47,9 @@ constexpr int ZG_DEPTH = PQP_ZG_DEPTH; // MFMA k-steps (of 4) whose operand load
 #ifndef PQP_LS_BRACKET
 #define PQP_LS_BRACKET 1
 #endif
+#ifndef PQP_LS_BRACKET_ALL
+#define PQP_LS_BRACKET_ALL 0
+#endif
 #ifndef PQP_ZG_BLOCK2
 #define PQP_ZG_BLOCK2 1
 #endif
@@ -3236,8 +3239,10 @@ struct Solver
     // evaluations, then evaluate -- in the reference's order, bit for bit as below -- only the handful of breakpoints
     // around it.  Any doubt (an evaluation too close to zero to trust its sign, too many breakpoints left in the bracket,
     // an exact value that contradicts the bracket) falls back to the full evaluation.
-    if constexpr (PQP_LS_BRACKET && SPEC == 0 && NT == 256) // (the kernels that serve such shapes; the C2 kernel stays as it is)
-    if (2 * nc > NT) {
+    // (the kernels that serve such shapes; the kernel of the common signature -- C2 -- stays as it is.  PQP_LS_BRACKET_ALL=1
+    // compiles the bracket into every kernel and takes it from 64 constraints on: an A/B switch, not measured yet)
+    if constexpr (PQP_LS_BRACKET && ((SPEC == 0 && NT == 256) || PQP_LS_BRACKET_ALL))
+    if (2 * nc > NT || (PQP_LS_BRACKET_ALL && nc >= 64)) {
       double alpha_b;
       sub_tic(ST_CYC_LS_EVAL);
       const bool ok = ls_bracket(a0, b0, alpha_b);
