@@ -3240,7 +3240,7 @@ struct Solver
     // around it.  Any doubt (an evaluation too close to zero to trust its sign, too many breakpoints left in the bracket,
     // an exact value that contradicts the bracket) falls back to the full evaluation.
     // (the kernels that serve such shapes; the kernel of the common signature -- C2 -- stays as it is.  PQP_LS_BRACKET_ALL=1
-    // compiles the bracket into every kernel and takes it from 64 constraints on: an A/B switch, not measured yet)
+    // compiles the bracket into every kernel and takes it from 64 constraints on: -6.7 % at C2, profiles/r03_ab_linesearch_bracket.txt)
     if constexpr (PQP_LS_BRACKET && ((SPEC == 0 && NT == 256) || PQP_LS_BRACKET_ALL))
     if (2 * nc > NT || (PQP_LS_BRACKET_ALL && nc >= 64)) {
       double alpha_b;
