@@ -642,7 +642,13 @@ enum
   EPI_ROW_DIV = 2,
   EPI_COL_SUBDIV = 3
 };
-template<int NT, bool COLS, bool GATHER, bool ROWS, int W>
+// TRIL = true: M is LOWER triangular with explicit zeros above the diagonal (the inverse factors W_S / W_P): a
+// 16 W-column stripe of a row step is only loaded when some row of the wavefront's step reaches it (wave-uniform
+// test, as in symv_lower); the skipped elements are exact zeros, so every sum keeps its bits.
+#ifndef PQP_TRIL_SKIP
+#define PQP_TRIL_SKIP 1
+#endif
+template<int NT, bool COLS, bool GATHER, bool ROWS, int W, bool TRIL = false>
 __device__ __forceinline__ void
 gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
                cliptr rowmap, int rowsplit, int epi, clptr ea, clptr eb)
@@ -682,9 +688,10 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
         if (GATHER && rsrc >= rowsplit)
           rsrc = rowsplit + rowmap[rsrc - rowsplit];
         cgptr row = M + (long)rsrc * ld;
+        const int rmax = base + u * 4 * NW + 4 * wid + 3; // last row of this wavefront's step (wave-uniform)
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          if (c0 + 16 * W * c < n) { // stripe test is wave-uniform
+          if (c0 + 16 * W * c < n && (!(TRIL && PQP_TRIL_SKIP) || c0 + 16 * W * c <= rmax)) { // stripe test is wave-uniform
             if (W == 2) {
               const Pair t = load_pair(row + off[c]);
               m[u][c][0] = t.x;
@@ -880,16 +887,17 @@ symv_lower(cgptr M, int ld, int n, clptr v, lptr out, lptr part)
 }
 
 // ROWS = false: column sums only (v / rowout unused).
-template<int NT, bool COLS = true, bool GATHER = false, bool ROWS = true>
+template<int NT, bool COLS = true, bool GATHER = false, bool ROWS = true, bool TRIL = false>
 __device__ PQP_CALL void
 gemv_dual(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
           cliptr rowmap = nullptr, int rowsplit = 0, int epi = EPI_NONE, clptr ea = nullptr, clptr eb = nullptr)
 {
+  static_assert(!(TRIL && GATHER), "the triangular skip assumes rows in storage order");
   const bool wide = (((ld | n) & 1) == 0) && ((reinterpret_cast<unsigned long long>(M) & 15ull) == 0);
   if (wide)
-    gemv_dual_impl<NT, COLS, GATHER, ROWS, 2>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit, epi, ea, eb);
+    gemv_dual_impl<NT, COLS, GATHER, ROWS, 2, TRIL>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit, epi, ea, eb);
   else
-    gemv_dual_impl<NT, COLS, GATHER, ROWS, 1>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit, epi, ea, eb);
+    gemv_dual_impl<NT, COLS, GATHER, ROWS, 1, TRIL>(M, ld, R, n, v, w, rowout, colout, part, rowmap, rowsplit, epi, ea, eb);
 }
 
 // ---------------------------------------------------------------------------

@@ -285,6 +285,17 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     h->lpt = std::string(e) == "lpt";
   if (const char* e = std::getenv("PQP_SPLIT_SOLVE"))
     h->split_solve = e[0] == '1';
+  h->dev.rep_phase = 0;
+  h->dev.rep_count = 1;
+  if (const char* e = std::getenv("PQP_REPEAT_PHASE")) // (only the instrumented build reads them: traffic attribution)
+    h->dev.rep_phase = std::atoi(e);
+  if (const char* e = std::getenv("PQP_REPEAT_COUNT"))
+    h->dev.rep_count = std::atoi(e);
+  if (const char* e = std::getenv("PQP_FORCE_NT")) { // experiment hook: a wider workgroup per QP than the shape needs
+    const int f = std::atoi(e);
+    if ((f == 512 || f == 1024) && f > h->nt)
+      h->nt = f;
+  }
   h->lds_solve = pqp::lds_bytes(d, h->nt);
   h->lds_setup = pqp::setup_lds_bytes(d, h->nt);
   // per-QP vector state beyond the 160 KiB of LDS of one CU (e.g. n = 760 with 837 constraint rows): the

@@ -202,6 +202,11 @@ struct Batch
   int* act;       // nc      active list kept across solves
   long long* stats; // ST_COUNT per QP
   double wall_us_per_tick; // microseconds per wall_clock64() tick of this device (Info timings)
+  // traffic attribution harness (instrumented build only, PQP_REPEAT_PHASE / PQP_REPEAT_COUNT at pqp_batch_create):
+  // the idempotent phase `rep_phase` (1 line search, 2 KKT residual, 3 first KKT solve of a step, 4 Schur
+  // re-factorisation, 5 global residuals, 6 primal block + Z / G) runs rep_count times per occurrence, so that
+  // the difference of the PMC byte counters against the plain run is that phase's HBM traffic
+  int rep_phase, rep_count;
 };
 
 // QPLayer backward (reference dense/compute_ECJ.hpp): inputs and outputs of one launch.
@@ -1155,6 +1160,17 @@ struct Solver
   }
   // compulsory HBM bytes of the engine (one pass over a matrix = its size; no reuse assumed)
   __device__ __forceinline__ void bytes(long long b) { count(ST_BYTES_ENGINE, b); }
+  __device__ __forceinline__ int reps(int phase) const
+  {
+#ifdef PQP_STATS
+    int c = (batch.rep_phase == phase && batch.rep_count > 1) ? batch.rep_count : 1;
+    PQP_OPAQUE_SCALAR(c);
+    return c;
+#else
+    (void)phase;
+    return 1;
+#endif
+  }
 
   // ---- small helpers --------------------------------------------------------
   __device__ __forceinline__ void vzero(lptr v, int len)
@@ -1924,7 +1940,7 @@ struct Solver
     }
     cgptr W = P.WS();
     // t = W v : row sums (16 lanes per row of the row-major factor)
-    gemv_dual<NT, false>(W, d.nd, rr, rr, v, v, L.t2(), L.t2(), L.part(), nullptr, 0, EPI_ROW_DIV, L.dS());
+    gemv_dual<NT, false, false, true, true>(W, d.nd, rr, rr, v, v, L.t2(), L.t2(), L.part(), nullptr, 0, EPI_ROW_DIV, L.dS());
     // v = W^T (t / D) : thread per column, rows below the diagonal only
     gemv<NT>(W, d.nd, rr, rr, L.t2(), v, L.part(), nullptr, 0, nullptr, 0, -1);
     bytes((long)rr * (rr + 1) * 8);
@@ -2018,7 +2034,7 @@ struct Solver
     double delta = scc;
     if (rr > 0) {
       // u = S^{-1} g ;  d_new = s_cc - g . u = s_cc - sum t_j^2 / d_j  with t = W g
-      gemv_dual<NT, false>(W, nd, rr, rr, gv, gv, tv, tv, L.part());
+      gemv_dual<NT, false, false, true, true>(W, nd, rr, rr, gv, gv, tv, tv, L.part());
       double acc = 0.0;
       for (int j = threadIdx.x; j < rr; j += NT) {
         const double t = tv[j], dj = L.dS()[j];
@@ -2059,7 +2075,7 @@ struct Solver
     if (cid < ni) {
       vload(L.t1(), P.Cs() + (long)cid * n, n);
       __syncthreads();
-      gemv_dual<NT, false>(W, n, n, n, L.t1(), L.t1(), pv, pv, L.part());
+      gemv_dual<NT, false, false, true, true>(W, n, n, n, L.t1(), L.t1(), pv, pv, L.part());
     } else {
       const int k = cid - ni;
       const double ik = L.isc()[k];
@@ -2150,7 +2166,7 @@ struct Solver
       __syncthreads();
     }
     // x = P_J^{-1} t1 = W^T D^{-1} W t1
-    gemv_dual<NT, false>(P.WL(), n, n, n, L.t1(), L.t1(), L.CTdz(), L.CTdz(), L.part());
+    gemv_dual<NT, false, false, true, true>(P.WL(), n, n, n, L.t1(), L.t1(), L.CTdz(), L.CTdz(), L.part());
     for (int k = threadIdx.x; k < n; k += NT)
       L.CTdz()[k] /= L.dF()[k];
     __syncthreads();
@@ -2219,8 +2235,11 @@ struct Solver
     // waiting for its panel of LS: touch every cache line of the factor's triangle NOW (one or
     // two loads per thread, results unused) so that those panels come from L2 instead of HBM by
     // the time the two mat-vecs in front of them have run.
+#ifndef PQP_TOUCH_WS
+#define PQP_TOUCH_WS 1
+#endif
     double touched = 0.0;
-    if (rr > 0) {
+    if (PQP_TOUCH_WS && rr > 0) {
       cgptr WSp = P.WS();
       const int chunks = (rr + 15) / 16 + 1;
       for (int idx = threadIdx.x; idx < rr * chunks; idx += NT) {
@@ -2364,7 +2383,17 @@ struct Solver
     UD preverr = 0, cur = 0;
     while (true) {
       tic();
-      kkt_solve_in_place(L.ex(), L.ed());
+      {
+        const int nrep = (it == 0) ? reps(3) : 1;
+        for (int rp = 0; rp < nrep; ++rp) {
+          if (rp > 0) { // (harness: the first solve of the step again, from the same right-hand side)
+            vcopy(L.ex(), L.rx(), n);
+            vcopy(L.ed(), L.rd(), r);
+            __syncthreads();
+          }
+          kkt_solve_in_place(L.ex(), L.ed());
+        }
+      }
       for (int k = threadIdx.x; k < n; k += NT)
         L.dx()[k] += L.ex()[k];
       // the dual part of the solution, also scattered by constraint id for the residual's C^T dz
@@ -2380,7 +2409,8 @@ struct Solver
           L.zfull()[i] = 0.0;
       __syncthreads();
       toc(ST_CYC_KKT_SOLVE);
-      cur = kkt_residual();
+      for (int rp = 0; rp < reps(2); ++rp)
+        cur = kkt_residual();
       toc(ST_CYC_RESIDUAL);
       ++it;
 #ifdef PQP_TRACE
@@ -2550,8 +2580,10 @@ struct Solver
     r = ne + n_slots;
     schur_dirty = true; // the slots were renumbered
     toc(ST_CYC_ZG);
-    if (r > 0 || pm()) // (PrimalLDLT factorises P_J even with no constraint in it)
-      factor_schur();
+    if (r > 0 || pm()) { // (PrimalLDLT factorises P_J even with no constraint in it)
+      for (int rp = 0; rp < reps(4); ++rp)
+        factor_schur();
+    }
     else
       schur_dirty = false;
     toc(ST_CYC_SCHUR);
@@ -3591,7 +3623,8 @@ struct Solver
       // |alpha dw|_inf, and max_k fl(|alpha| |dw_k|) = fl(|alpha| max_k |dw_k|): rounding is monotone)
       double dw_max = 0;
       if (ni > 0 || has_box()) {
-        alpha = primal_dual_ls(dw_max);
+        for (int rp = 0; rp < reps(1); ++rp)
+          alpha = primal_dual_ls(dw_max);
         // (the tail of the line search still reads rup / si / z / dz, which the update below rewrites)
         __syncthreads();
       } else {
@@ -3800,7 +3833,8 @@ struct Solver
 #endif
       tic();
       if constexpr (PART != 2) {
-        factor_primal_block();
+        for (int rp = 0; rp < reps(6); ++rp)
+          factor_primal_block();
       } else {
         vload(L.dF(), P.dF(), n); // (the prepare kernel of this launch left F, W, Z, G and D in HBM)
         __syncthreads();
@@ -3897,8 +3931,9 @@ struct Solver
       const bool want_primal = (stage != 2);
       const bool want_dual_pre = (stage != 1);
       if (want_primal && !gpr_fresh) {
-        global_primal_residual(pl, primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0,
-                               primal_feasibility_eq_lhs, primal_feasibility_in_lhs);
+        for (int rp = 0; rp < reps(5); ++rp)
+          global_primal_residual(pl, primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0,
+                                 primal_feasibility_eq_lhs, primal_feasibility_in_lhs);
         pl_cache = pl;
         gpr_fresh = true;
       }
@@ -3912,8 +3947,9 @@ struct Solver
         want_dual = is_primal_feasible;
       }
       if (want_dual && !gdr_fresh) {
-        global_dual_residual(dl, dual_feasibility_rhs_0, dual_feasibility_rhs_1, dual_feasibility_rhs_3,
-                             rhs_duality_gap, duality_gap);
+        for (int rp = 0; rp < reps(5); ++rp)
+          global_dual_residual(dl, dual_feasibility_rhs_0, dual_feasibility_rhs_1, dual_feasibility_rhs_3,
+                               rhs_duality_gap, duality_gap);
         dl_cache = dl;
         gdr_fresh = true;
       }
