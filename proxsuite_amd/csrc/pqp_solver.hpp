@@ -2198,7 +2198,7 @@ struct Solver
   // (reference solver.hpp:320-335 -> ldlt.hpp:767-782)
   __device__ __forceinline__ void kkt_solve_in_place(lptr bx, lptr bd)
   {
-    const int n = d.n, nd = d.nd;
+    const int n = d.n;
     const int rr = r;
     if (pm()) {
       kkt_solve_pm(bx, bd);
@@ -2231,25 +2231,9 @@ struct Solver
       count(ST_N_KKT_SOLVES);
       return;
     }
-    // The triangular solves on the Schur factor below are chains of dependent block steps, each
-    // waiting for its panel of LS: touch every cache line of the factor's triangle NOW (one or
-    // two loads per thread, results unused) so that those panels come from L2 instead of HBM by
-    // the time the two mat-vecs in front of them have run.
-#ifndef PQP_TOUCH_WS
-#define PQP_TOUCH_WS 1
-#endif
-    double touched = 0.0;
-    if (PQP_TOUCH_WS && rr > 0) {
-      cgptr WSp = P.WS();
-      const int chunks = (rr + 15) / 16 + 1;
-      for (int idx = threadIdx.x; idx < rr * chunks; idx += NT) {
-        const int j = idx / chunks, c = idx - j * chunks;
-        const long first = (long)j * nd, last = (long)j * nd + j; // row j, columns 0 .. j
-        const long line = (first >> 4) + c;
-        const long e = (line << 4) > first ? (line << 4) : first;
-        touched += WSp[(e <= last) ? e : last];
-      }
-    }
+    // (rounds 1-3 touched every cache line of the Schur factor's triangle here, ahead of the two passes over it:
+    // measured in round 4, most of those lines are evicted again before their pass and fetched twice --
+    // profiles/r04_ab_c2_traffic.txt: -0.75 MB of HBM traffic per QP and +1.3 % QPs/s without the touch)
     apply_Linv(bx, L.t1(), false, L.t2(), L.dF()); // t = L^{-1} bx ; t2 = t / D
     if (rr > 0) {
       // s_a = z_a . (t / D) - bd_a : row sums over the ACTIVE rows of Zr (contiguous rows; a column
@@ -2278,7 +2262,6 @@ struct Solver
       __syncthreads();
     }
     apply_Linv(L.t1(), bx, true); // x = L^{-T} (.)
-    keep_alive(touched);
     bytes((long)n * (n + 1) * 8 + (long)rr * n * 16);
     count(ST_N_KKT_SOLVES);
   }

@@ -7,7 +7,7 @@ import json
 import os
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from proxsuite_amd import _native as N
 from proxsuite_amd.utils import random_qp as R
 
