@@ -109,6 +109,33 @@ int pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count);
  * the `count` QPs idx[0..count) of the batch, in ONE launch (workgroup i solves QP idx[i]). */
 int pqp_batch_solve_subset(pqp_batch* h, const int64_t* idx, int64_t count);
 
+/* Asynchronous forms (SURVEY 8(b) threading row: "synchronous by default, async if a stream is given"): the
+ * launch is enqueued on the handle's stream (pqp_batch_set_stream; NULL = the null stream) and the call returns
+ * without waiting for the device.  pqp_batch_wait blocks until the solve in flight has finished and runs its
+ * host-side bookkeeping (device time, verbose report); every other entry of the same handle waits first, so a
+ * caller can never observe a half-finished solve.  One solve in flight per handle; several handles -- on one
+ * device or on several -- run concurrently: dense::solve_in_parallel over the pools of a BatchQP launches all of
+ * them and then waits (reference parallel/qp_solve.hpp:41-59 returns when every QP is solved). */
+int pqp_batch_solve_async(pqp_batch* h);
+int pqp_batch_solve_range_async(pqp_batch* h, int64_t first, int64_t count);
+int pqp_batch_solve_subset_async(pqp_batch* h, const int64_t* idx, int64_t count);
+int pqp_batch_wait(pqp_batch* h);
+
+/* Host-resident results.  In the reference `qp.results` are host members when solve / solve_in_parallel return
+ * (parallel/qp_solve.hpp:33-37).  With this switch on, the handle owns pinned, device-mapped host mirrors
+ * [B][...] of x, y, z, se, si and Info, and the epilogue of the solve kernel writes every QP's results into them
+ * beside the device arrays -- each workgroup pushes its own QP over the host link as it finishes, overlapped with
+ * the QPs still being solved -- so the results ARE on the host when the solve returns (or pqp_batch_wait does):
+ * no device-to-host copy behind the kernel.  pqp_batch_host_results hands out the mirrors (valid until the
+ * switch is turned off or the handle destroyed; contents defined for the QPs whose last solve finished after the
+ * switch was turned on and whose results no init / update / warm_start / cleanup has touched since:
+ * pqp_batch_host_results_fresh(h, idx) == 1, idx == -1: every QP).  pqp_batch_get_results is served from the
+ * mirrors whenever they are fresh. */
+int pqp_batch_enable_host_results(pqp_batch* h, int enable);
+int pqp_batch_host_results(pqp_batch* h, const double** x, const double** y, const double** z, const double** se,
+                           const double** si, const pqp_info** info);
+int pqp_batch_host_results_fresh(pqp_batch* h, int64_t idx);
+
 /* Copy construction / assignment of a QP (reference dense/wrapper.hpp: QP<T> is copyable and
  * BatchQP / std::vector<QP> rely on it): every per-QP device array, the settings and the
  * initialisation state of QP src_idx of `src` go to QP dst_idx of `dst` (same shape required;
@@ -116,8 +143,13 @@ int pqp_batch_solve_subset(pqp_batch* h, const int64_t* idx, int64_t count);
 int pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_idx);
 
 /* HIP stream (hipStream_t, passed as void*) the setup and solve kernels are launched on;
- * NULL (the default) is the null stream.  Calls stay synchronous with respect to the host. */
+ * NULL (the default) is the null stream.  pqp_batch_solve* stay synchronous with respect to the host; the
+ * *_async forms above return once the launch is enqueued on this stream. */
 int pqp_batch_set_stream(pqp_batch* h, void* stream);
+/* gives the handle a non-blocking stream of its own (created on its device, destroyed with it): handles with their
+ * own streams overlap on one device -- what the facade does for every pool, so that the pools of a BatchQP and the
+ * standalone QPs of different signatures run concurrently under dense::solve_in_parallel. */
+int pqp_batch_own_stream(pqp_batch* h);
 
 /* dense::compute_backward / solve_backward_in_parallel (reference dense/compute_ECJ.hpp:29-189,
  * parallel/qp_solve.hpp:83-137): derivatives of a loss wrt (H, g, A, b, C, u, l) of SOLVED QPs.
@@ -130,6 +162,10 @@ int pqp_batch_backward(pqp_batch* h, const double* loss_derivatives, double eps,
                        double mu_backward);
 int pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const double* loss_derivatives,
                              double eps, double rho_backward, double mu_backward);
+/* solve_backward_in_parallel(std::vector<QP>&) (reference parallel/qp_solve.hpp:83-110): compute_backward on the
+ * `count` QPs idx[0..count) in ONE launch; row i of loss_derivatives ([count][dim + n_eq + n_in]) belongs to QP idx[i]. */
+int pqp_batch_backward_subset(pqp_batch* h, const int64_t* idx, int64_t count, const double* loss_derivatives,
+                              double eps, double rho_backward, double mu_backward);
 /* Model::backward_data (reference dense/backward_data.hpp:27-133) of QP idx (-1: the whole
  * batch, arrays [B][...]); row-major; any pointer may be NULL. */
 int pqp_batch_get_backward(pqp_batch* h, int64_t idx, double* dL_dH, double* dL_dg, double* dL_dA,
@@ -178,6 +214,55 @@ int pqp_batch_get_stats(pqp_batch* h, int64_t* stats);
 double pqp_batch_last_solve_ms(const pqp_batch* h);
 /* bytes of dynamic LDS and threads per workgroup chosen for this batch */
 int pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * One batch over several GPUs of the node, in ONE process (SURVEY 8(b) `device_mask`, 7 step 7; reference
+ * parallel/qp_solve.hpp:41-59: solve_in_parallel uses every core of the host -- here every listed device).
+ * A pqp_multi owns G shards: shard g is an ordinary pqp_batch on device devices[g] holding the contiguous range
+ * [first_g, first_g + count_g) of the B QPs (count_g = B / G, the first B % G shards one more), with its own HIP
+ * stream and host-resident results.  QPs are independent: nothing is exchanged during a solve.  pqp_multi_solve
+ * launches every shard (no host synchronisation between the launches) and then waits for all of them; the results
+ * are then in the shards' host mirrors and, through pqp_multi_gather_device, in ONE device buffer on a chosen
+ * device (pack kernel per shard + peer copies over xGMI -- the in-process form of the final all_gather of
+ * proxsuite_amd/sharding.py).  A device may be listed several times (logical shards on one GPU: how the path is
+ * tested on a one-GPU box).  `idx` / `first` are indices into the WHOLE batch; idx == -1 addresses all of it,
+ * arrays then carry a leading [B] dimension exactly as for pqp_batch_*. */
+typedef struct pqp_multi pqp_multi;
+int pqp_multi_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, int box_constraints,
+                     int hessian_type, int dense_backend, const int* devices, int n_devices, pqp_multi** out);
+void pqp_multi_destroy(pqp_multi* m);
+int64_t pqp_multi_size(const pqp_multi* m);
+int pqp_multi_shard_count(const pqp_multi* m);
+/* shard g: its batch handle (owned by `m`), its first QP and its number of QPs; any output may be NULL */
+int pqp_multi_shard(pqp_multi* m, int g, pqp_batch** shard, int64_t* first, int64_t* count);
+/* shard and local index of QP idx */
+int pqp_multi_locate(const pqp_multi* m, int64_t idx, int* shard, int64_t* local);
+pqp_settings* pqp_multi_settings(pqp_multi* m, int64_t idx);
+int pqp_multi_init(pqp_multi* m, int64_t idx, const double* H, const double* g, const double* A, const double* b,
+                   const double* C, const double* l, const double* u, const double* l_box, const double* u_box,
+                   int compute_preconditioner, double rho, double mu_eq, double mu_in,
+                   double manual_minimal_H_eigenvalue);
+int pqp_multi_update(pqp_multi* m, int64_t idx, const double* H, const double* g, const double* A, const double* b,
+                     const double* C, const double* l, const double* u, const double* l_box, const double* u_box,
+                     int update_preconditioner, double rho, double mu_eq, double mu_in,
+                     double manual_minimal_H_eigenvalue);
+int pqp_multi_warm_start(pqp_multi* m, int64_t idx, const double* x, const double* y, const double* z);
+int pqp_multi_cleanup(pqp_multi* m, int64_t idx);
+int pqp_multi_flush(pqp_multi* m);
+/* dense::solve_in_parallel over every device; _range: the QPs [first, first + count) of the whole batch */
+int pqp_multi_solve(pqp_multi* m);
+int pqp_multi_solve_range(pqp_multi* m, int64_t first, int64_t count);
+int pqp_multi_solve_async(pqp_multi* m);
+int pqp_multi_solve_range_async(pqp_multi* m, int64_t first, int64_t count);
+int pqp_multi_wait(pqp_multi* m);
+int pqp_multi_get_results(pqp_multi* m, int64_t idx, double* x, double* y, double* z, double* se, double* si,
+                          pqp_info* info);
+/* (x, y, z, status, iter) of ALL QPs as one row-major [B][dim + n_eq + n_c + 2] fp64 buffer `out` in the memory of
+ * the device of shard `root_shard` (allocated there by the caller): pack kernel on every shard's stream, then
+ * asynchronous peer copies into place; returns when the buffer is complete. */
+int pqp_multi_gather_device(pqp_multi* m, int root_shard, double* out);
+/* device time of the last solve: the slowest shard (the job's time), milliseconds */
+double pqp_multi_last_solve_ms(const pqp_multi* m);
 
 #ifdef __cplusplus
 }

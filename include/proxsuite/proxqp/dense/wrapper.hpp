@@ -24,6 +24,7 @@
 #define PROXSUITE_AMD_PROXQP_DENSE_WRAPPER_HPP
 
 #include <algorithm>
+#include <cstring>
 #include <deque>
 #include <limits>
 #include <map>
@@ -63,9 +64,26 @@ bad_size(const char* what, isize got, isize expected)
                               ", got " + std::to_string(got) + "\nhint: " + what);
 }
 
+// A batch spread over several devices (pqp_multi_*): its shards are ordinary batch handles that the pools of a
+// BatchQP adopt; the owner lives as long as any of those pools.
+struct MultiOwner
+{
+  pqp_multi* m = nullptr;
+  explicit MultiOwner(pqp_multi* m_)
+    : m(m_)
+  {
+  }
+  MultiOwner(const MultiOwner&) = delete;
+  MultiOwner& operator=(const MultiOwner&) = delete;
+  ~MultiOwner() { pqp_multi_destroy(m); }
+};
+
 struct Pool
 {
   pqp_batch* h = nullptr;
+  std::shared_ptr<MultiOwner> multi; // set: `h` is shard `shard` of that multi-device batch (not owned here)
+  int shard = 0;
+  isize first = 0; // index of slot 0 in the whole multi-device batch
   isize capacity = 0, used = 0;
   isize dim = 0, n_eq = 0, n_in = 0, n_c = 0;
   std::vector<isize> free_slots; // registry pools only: slots given back by destroyed QPs
@@ -83,10 +101,32 @@ struct Pool
     , n_c(n_in_ + (box ? dim_ : 0))
   {
     check(pqp_batch_create(cap, dim_, n_eq_, n_in_, box ? 1 : 0, int(hessian), int(backend), device, &h));
+    // results are host members when a solve returns (reference parallel/qp_solve.hpp:33-37): the solve kernel
+    // writes them into pinned host mirrors; a stream of its own lets this pool overlap with the others
+    check(pqp_batch_enable_host_results(h, 1));
+    check(pqp_batch_own_stream(h));
+  }
+  // shard `g` of a multi-device batch (already has its stream and its host mirrors)
+  Pool(std::shared_ptr<MultiOwner> owner, int g, isize dim_, isize n_eq_, isize n_in_, bool box)
+    : multi(std::move(owner))
+    , shard(g)
+    , dim(dim_)
+    , n_eq(n_eq_)
+    , n_in(n_in_)
+    , n_c(n_in_ + (box ? dim_ : 0))
+  {
+    int64_t f = 0, c = 0;
+    check(pqp_multi_shard(multi->m, g, &h, &f, &c));
+    first = isize(f);
+    capacity = isize(c);
   }
   Pool(const Pool&) = delete;
   Pool& operator=(const Pool&) = delete;
-  ~Pool() { pqp_batch_destroy(h); }
+  ~Pool()
+  {
+    if (!multi)
+      pqp_batch_destroy(h);
+  }
 };
 using PoolLock = std::lock_guard<std::recursive_mutex>;
 
@@ -335,7 +375,7 @@ public:
     detail::PoolLock lock(pool_->mtx);
     push_settings();
     detail::check(pqp_batch_solve_range(pool_->h, slot_, 1));
-    pull();
+    pull_from_mirrors();
   }
   // QP::solve(x, y, z) (reference wrapper.hpp:940-957; warm_start helpers.hpp:715-763)
   void solve(optional<VecRef<T>> x, optional<VecRef<T>> y, optional<VecRef<T>> z)
@@ -371,6 +411,30 @@ public:
     detail::check(pqp_batch_get_results(pool_->h, slot_, results.x.data(), results.y.data(), results.z.data(),
                                         results.se.data(), results.si.data(), &info));
     results.info.from_c(info);
+  }
+  // results of this QP straight from the pool's host mirrors (valid after a finished solve of the slot: the solve
+  // kernel's epilogue wrote them; no device-to-host copy).  The caller holds the pool lock.
+  void pull_from_mirrors()
+  {
+    pull_settings();
+    const double *mx, *my, *mz, *mse, *msi;
+    const pqp_info* mi;
+    detail::check(pqp_batch_host_results(pool_->h, &mx, &my, &mz, &mse, &msi, &mi));
+    if (!pqp_batch_host_results_fresh(pool_->h, slot_)) { // (cannot happen behind a solve of this slot; stay correct anyway)
+      pull();
+      return;
+    }
+    const usize s = usize(slot_);
+    auto put = [s](Vec<T>& dst, const double* src) {
+      if (dst.size())
+        std::memcpy(dst.data(), src + s * usize(dst.size()), usize(dst.size()) * sizeof(T));
+    };
+    put(results.x, mx);
+    put(results.y, my);
+    put(results.z, mz);
+    put(results.se, mse);
+    put(results.si, msi);
+    results.info.from_c(mi[s]);
   }
   const std::shared_ptr<detail::Pool>& pool() const { return pool_; }
   isize slot() const { return slot_; }
@@ -596,9 +660,30 @@ solve(optional<MatRef<T>> H, optional<VecRef<T>> g, optional<MatRef<T>> A, optio
 template<typename T>
 struct BatchQP
 {
-  explicit BatchQP(usize batch_size = 0, int device = 0)
+  // `device`: a HIP device ordinal, or all_devices (the default): with more than one device visible the batch is
+  // spread over all of them -- every signature gets a multi-device batch (pqp_multi_create) of `batch_size` QPs whose
+  // shards hold contiguous ranges, and solve_in_parallel launches every shard before it waits for any (the
+  // reference's solve_in_parallel uses every core of the host, parallel/qp_solve.hpp:41-59).  With one device
+  // visible this is BatchQP(batch_size, 0).
+  static constexpr int all_devices = -1;
+  explicit BatchQP(usize batch_size = 0, int device = all_devices)
     : capacity_(isize(batch_size) > 0 ? isize(batch_size) : 1)
     , device_(device)
+  {
+    if (device_ == all_devices) {
+      const int nd = pqp_device_count();
+      if (nd > 1)
+        for (int g = 0; g < nd; ++g)
+          devices_.push_back(g);
+      else
+        device_ = 0;
+    }
+  }
+  // the batch spread over exactly these devices (an ordinal may repeat: logical shards on one GPU)
+  BatchQP(usize batch_size, const std::vector<int>& devices)
+    : capacity_(isize(batch_size) > 0 ? isize(batch_size) : 1)
+    , device_(devices.empty() ? 0 : devices[0])
+    , devices_(devices.size() > 1 ? devices : std::vector<int>())
   {
   }
 
@@ -642,6 +727,8 @@ struct BatchQP
     std::vector<isize> members; // members[slot] = index of the QP in that slot
   };
   const std::vector<PoolEntry>& pools() const { return pools_; }
+  const std::vector<int>& devices() const { return devices_; } // empty: one device (device())
+  int device() const { return device_; }
 
 private:
   using Key = std::tuple<isize, isize, isize, bool, int, int>;
@@ -652,20 +739,39 @@ private:
         "wrong argument size: the dimension wrt the primal variable x should be strictly positive.");
     Key key{ dim, n_eq, n_in, box, int(hessian), int(backend) };
     auto it = open_.find(key);
+    // (the shards of a multi-device batch are consecutive pools: a full shard hands over to the next one)
+    while (it != open_.end() && pools_[it->second].pool->used == pools_[it->second].pool->capacity &&
+           pools_[it->second].pool->multi && it->second + 1 < pools_.size() &&
+           pools_[it->second + 1].pool->multi == pools_[it->second].pool->multi)
+      ++it->second;
     if (it == open_.end() || pools_[it->second].pool->used == pools_[it->second].pool->capacity) {
-      pools_.push_back({ std::make_shared<detail::Pool>(capacity_, dim, n_eq, n_in, box, hessian, backend, device_), {} });
-      open_[key] = pools_.size() - 1;
+      const usize at = pools_.size();
+      if (devices_.empty()) {
+        pools_.push_back({ std::make_shared<detail::Pool>(capacity_, dim, n_eq, n_in, box, hessian, backend, device_), {} });
+      } else {
+        pqp_multi* m = nullptr;
+        detail::check(pqp_multi_create(capacity_, dim, n_eq, n_in, box ? 1 : 0, int(hessian), int(backend), devices_.data(),
+                                       int(devices_.size()), &m));
+        auto owner = std::make_shared<detail::MultiOwner>(m);
+        for (int g = 0; g < pqp_multi_shard_count(m); ++g) {
+          auto sp = std::make_shared<detail::Pool>(owner, g, dim, n_eq, n_in, box);
+          if (sp->capacity > 0)
+            pools_.push_back({ sp, {} });
+        }
+      }
+      open_[key] = at;
       it = open_.find(key);
     }
     PoolEntry& e = pools_[it->second];
     const isize slot = e.pool->used++;
     e.members.push_back(isize(qps_.size()));
-    qps_.push_back(QP<T>(dim, n_eq, n_in, box, hessian, backend, e.pool, slot, device_));
+    qps_.push_back(QP<T>(dim, n_eq, n_in, box, hessian, backend, e.pool, slot, e.pool->multi ? devices_[usize(e.pool->shard)] : device_));
     return qps_.back();
   }
 
   isize capacity_;
   int device_;
+  std::vector<int> devices_; // more than one entry: every signature lives in a multi-device batch over these
   std::deque<QP<T>> qps_;
   std::vector<PoolEntry> pools_;
   std::map<Key, usize> open_;

@@ -57,7 +57,7 @@ OBJ_DIR = ROOT / "build" / "obj"
 
 
 def hip_sources():
-    return [CSRC / "pqp_capi.hip", CSRC / "pqp_kernels.hip"]
+    return [CSRC / "pqp_capi.hip", CSRC / "pqp_multi.hip", CSRC / "pqp_kernels.hip"]
 
 
 def hip_headers():
@@ -130,7 +130,8 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
     odir = OBJ_DIR / tag
     odir.mkdir(parents=True, exist_ok=True)
     flags = hip_flags(extra_flags)
-    jobs = [([hipcc, *flags, "-c", str(CSRC / "pqp_capi.hip"), "-o", str(odir / "capi.o")], odir / "capi.o")]
+    jobs = [([hipcc, *flags, "-c", str(CSRC / "pqp_capi.hip"), "-o", str(odir / "capi.o")], odir / "capi.o"),
+            ([hipcc, *flags, "-c", str(CSRC / "pqp_multi.hip"), "-o", str(odir / "multi.o")], odir / "multi.o")]
     for k in tus:
         o = odir / ("kernels_%d.o" % k)
         jobs.append(([hipcc, *flags, *TU_FLAGS.get(k, []), "-DPQP_TU=%d" % k, "-c", str(CSRC / "pqp_kernels.hip"),
@@ -186,7 +187,7 @@ def build_hip_variants(force: bool = False):
             _run([hipcc, *hip_flags(("-DPQP_WPS_512=%d" % w,)), *TU_FLAGS.get(3, []), "-DPQP_TU=3", "-c",
                   str(CSRC / "pqp_kernels.hip"),
                   "-o", str(o3)])
-            objs = [base / "capi.o"] + [o3 if k == 3 else base / ("kernels_%d.o" % k) for k in KERNEL_TUS]
+            objs = [base / "capi.o", base / "multi.o"] + [o3 if k == 3 else base / ("kernels_%d.o" % k) for k in KERNEL_TUS]
             _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)])
         out.append(lib)
     return out

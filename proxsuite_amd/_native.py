@@ -38,7 +38,14 @@ class NativeLib:
                "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_solve_subset", "pqp_batch_copy_qp", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
                "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs", "pqp_batch_pack_results",
                "pqp_batch_get_scaled", "pqp_batch_get_schur_factor", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
-               "pqp_batch_launch_config")
+               "pqp_batch_launch_config", "pqp_batch_solve_async", "pqp_batch_solve_range_async",
+               "pqp_batch_solve_subset_async", "pqp_batch_wait", "pqp_batch_enable_host_results",
+               "pqp_batch_host_results", "pqp_batch_host_results_fresh", "pqp_batch_own_stream", "pqp_batch_backward_subset",
+               "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_size", "pqp_multi_shard_count", "pqp_multi_shard",
+               "pqp_multi_locate", "pqp_multi_settings", "pqp_multi_init", "pqp_multi_update", "pqp_multi_warm_start",
+               "pqp_multi_cleanup", "pqp_multi_flush", "pqp_multi_solve", "pqp_multi_solve_range",
+               "pqp_multi_solve_async", "pqp_multi_solve_range_async", "pqp_multi_wait", "pqp_multi_get_results",
+               "pqp_multi_gather_device", "pqp_multi_last_solve_ms")
 
     def __init__(self, path):
         self.path = str(path)
@@ -78,6 +85,37 @@ class NativeLib:
         L.pqp_batch_last_solve_ms.argtypes = [vp]
         L.pqp_batch_last_solve_ms.restype = C.c_double
         L.pqp_batch_launch_config.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.pqp_batch_solve_async.argtypes = [vp]
+        L.pqp_batch_solve_range_async.argtypes = [vp, C.c_int64, C.c_int64]
+        L.pqp_batch_solve_subset_async.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64]
+        L.pqp_batch_wait.argtypes = [vp]
+        L.pqp_batch_enable_host_results.argtypes = [vp, C.c_int]
+        L.pqp_batch_host_results.argtypes = [vp] + [C.POINTER(_DP)] * 5 + [C.POINTER(C.POINTER(pqp_info))]
+        L.pqp_batch_host_results_fresh.argtypes = [vp, C.c_int64]
+        L.pqp_batch_own_stream.argtypes = [vp]
+        L.pqp_batch_backward_subset.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64, _DP] + [C.c_double] * 3
+        L.pqp_multi_create.argtypes = [C.c_int64] * 4 + [C.c_int] * 3 + [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.pqp_multi_destroy.argtypes = [vp]
+        L.pqp_multi_destroy.restype = None
+        L.pqp_multi_size.argtypes = [vp]
+        L.pqp_multi_size.restype = C.c_int64
+        L.pqp_multi_shard_count.argtypes = [vp]
+        L.pqp_multi_shard.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.pqp_multi_locate.argtypes = [vp, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.pqp_multi_settings.argtypes = [vp, C.c_int64]
+        L.pqp_multi_settings.restype = C.POINTER(pqp_settings)
+        for name in ("pqp_multi_init", "pqp_multi_update"):
+            getattr(L, name).argtypes = [vp, C.c_int64] + [_DP] * 9 + [C.c_int] + [C.c_double] * 4
+        L.pqp_multi_warm_start.argtypes = [vp, C.c_int64] + [_DP] * 3
+        L.pqp_multi_cleanup.argtypes = [vp, C.c_int64]
+        for name in ("pqp_multi_flush", "pqp_multi_solve", "pqp_multi_solve_async", "pqp_multi_wait"):
+            getattr(L, name).argtypes = [vp]
+        for name in ("pqp_multi_solve_range", "pqp_multi_solve_range_async"):
+            getattr(L, name).argtypes = [vp, C.c_int64, C.c_int64]
+        L.pqp_multi_get_results.argtypes = [vp, C.c_int64] + [_DP] * 5 + [C.POINTER(pqp_info)]
+        L.pqp_multi_gather_device.argtypes = [vp, C.c_int, vp]
+        L.pqp_multi_last_solve_ms.argtypes = [vp]
+        L.pqp_multi_last_solve_ms.restype = C.c_double
         self.L = L
 
     def check(self, rc):
@@ -244,6 +282,42 @@ class Batch:
         else:
             self.lib.check(self.lib.L.pqp_batch_solve_range(self._h, int(first), int(1 if count is None else count)))
 
+    def solve_async(self, first=None, count=None):
+        """the launch is enqueued on the handle's stream; `wait()` (or any other call on the handle) completes it"""
+        if first is None:
+            self.lib.check(self.lib.L.pqp_batch_solve_async(self._h))
+        else:
+            self.lib.check(self.lib.L.pqp_batch_solve_range_async(self._h, int(first), int(1 if count is None else count)))
+
+    def wait(self):
+        self.lib.check(self.lib.L.pqp_batch_wait(self._h))
+
+    def enable_host_results(self, on=True):
+        """pinned host mirrors of (x, y, z, se, si, Info) written by the epilogue of the solve kernel: the results are
+        on the host when solve() / wait() returns, with no device-to-host copy (include/proxqp_hip.h)"""
+        self.lib.check(self.lib.L.pqp_batch_enable_host_results(self._h, int(bool(on))))
+
+    def host_results(self):
+        """numpy views (no copy) of the host mirrors: x [B, n], y [B, n_eq], z [B, n_c], se, si and the Info records
+        as a structured array; contents are those of the last finished solve (see `host_results_fresh`)"""
+        px = [_DP() for _ in range(5)]
+        pi = C.POINTER(pqp_info)()
+        self.lib.check(self.lib.L.pqp_batch_host_results(self._h, *[C.byref(p) for p in px], C.byref(pi)))
+        shapes = ((self.B, self.n), (self.B, self.n_eq), (self.B, self.n_c), (self.B, self.n_eq), (self.B, self.n_c))
+        out = []
+        for p, sh in zip(px, shapes):
+            cnt = sh[0] * sh[1]
+            out.append(np.ctypeslib.as_array(p, shape=(cnt,)).reshape(sh) if cnt else np.zeros(sh))
+        if self.B:
+            arr = (pqp_info * self.B).from_address(C.addressof(pi.contents))
+            info = np.frombuffer(arr, dtype=np.dtype(pqp_info))
+        else:
+            info = np.zeros(0, dtype=np.dtype(pqp_info))
+        return (*out, info)
+
+    def host_results_fresh(self, idx=-1):
+        return bool(self.lib.L.pqp_batch_host_results_fresh(self._h, int(idx)))
+
     def backward(self, loss_derivatives, eps=1e-4, rho_backward=1e-6, mu_backward=1e-6, first=None, count=None):
         """dense::compute_backward for the whole batch (or the QPs first .. first+count-1).
         `loss_derivatives`: [B or count, n + n_eq + n_in] (numpy or torch, host or device)."""
@@ -294,6 +368,18 @@ class Batch:
         """Dispatch order of whole-batch solves: index order (default) or longest-processing-time first
         (uses the device cycle counts of the previous whole-batch solve of this handle)."""
         self.lib.check(self.lib.L.pqp_batch_set_schedule(self._h, int(bool(longest_first))))
+
+    def own_stream(self):
+        """a non-blocking stream of the handle's own: handles with their own streams overlap on one device"""
+        self.lib.check(self.lib.L.pqp_batch_own_stream(self._h))
+
+    def backward_subset(self, idx, loss_derivatives, eps=1e-4, rho_backward=1e-6, mu_backward=1e-6):
+        """compute_backward on the QPs idx[0..] in one launch; row i of loss_derivatives belongs to QP idx[i]"""
+        ntot = self.n + self.n_eq + self.n_in
+        ii = np.ascontiguousarray(idx, dtype=np.int64)
+        k, p = _as_array(loss_derivatives, (len(ii), ntot), "loss_derivatives")
+        self.lib.check(self.lib.L.pqp_batch_backward_subset(self._h, ii.ctypes.data_as(C.POINTER(C.c_int64)), len(ii), p,
+                                                            float(eps), float(rho_backward), float(mu_backward)))
 
     def set_stream(self, stream):
         """`stream`: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""
@@ -381,3 +467,114 @@ class Batch:
         x, y, z = _DP(), _DP(), _DP()
         self.lib.check(self.lib.L.pqp_batch_result_device_ptrs(self._h, C.byref(x), C.byref(y), C.byref(z)))
         return tuple(C.cast(p, C.c_void_p).value for p in (x, y, z))
+
+
+
+class MultiBatch:
+    """One batch over several GPUs of the node from ONE process (pqp_multi_*, include/proxqp_hip.h): shard g is an
+    ordinary batch on devices[g] holding a contiguous range of the QPs; a solve launches every shard and then waits
+    for all of them.  `devices` may repeat an ordinal (logical shards on one GPU)."""
+
+    def __init__(self, batch_size, n, n_eq, n_in, devices, box_constraints=False, hessian_type=1, dense_backend=0,
+                 lib: NativeLib | None = None):
+        self.lib = lib if lib is not None else load()
+        self.B, self.n, self.n_eq, self.n_in = int(batch_size), int(n), int(n_eq), int(n_in)
+        self.box = bool(box_constraints)
+        self.n_c = self.n_in + (self.n if self.box else 0)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.pqp_multi_create(self.B, self.n, self.n_eq, self.n_in, int(self.box), int(hessian_type),
+                                                   int(dense_backend), devs, len(devices), C.byref(h)))
+        self._h = h
+        self.devices = [int(d) for d in devices]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.L.pqp_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def shard_count(self):
+        return self.lib.L.pqp_multi_shard_count(self._h)
+
+    def shard(self, g):
+        """(first, count) of shard g"""
+        f, c = C.c_int64(0), C.c_int64(0)
+        self.lib.check(self.lib.L.pqp_multi_shard(self._h, int(g), None, C.byref(f), C.byref(c)))
+        return f.value, c.value
+
+    def settings(self, idx) -> pqp_settings:
+        p = self.lib.L.pqp_multi_settings(self._h, int(idx))
+        if not p:
+            raise IndexError(idx)
+        return p.contents
+
+    _shapes = Batch._shapes
+
+    def _setup(self, fn, idx, H, g, A, b, Cm, l, u, l_box, u_box, flag, rho, mu_eq, mu_in, min_eig):
+        Batch._setup(self, fn, idx, H, g, A, b, Cm, l, u, l_box, u_box, flag, rho, mu_eq, mu_in, min_eig)
+
+    def init(self, idx=-1, H=None, g=None, A=None, b=None, C=None, l=None, u=None, l_box=None, u_box=None,
+             compute_preconditioner=True, rho=None, mu_eq=None, mu_in=None, manual_minimal_H_eigenvalue=None):
+        self._setup(self.lib.L.pqp_multi_init, idx, H, g, A, b, C, l, u, l_box, u_box, compute_preconditioner, rho, mu_eq,
+                    mu_in, manual_minimal_H_eigenvalue)
+
+    def update(self, idx=-1, H=None, g=None, A=None, b=None, C=None, l=None, u=None, l_box=None, u_box=None,
+               update_preconditioner=False, rho=None, mu_eq=None, mu_in=None, manual_minimal_H_eigenvalue=None):
+        self._setup(self.lib.L.pqp_multi_update, idx, H, g, A, b, C, l, u, l_box, u_box, update_preconditioner, rho,
+                    mu_eq, mu_in, manual_minimal_H_eigenvalue)
+
+    def warm_start(self, idx=-1, x=None, y=None, z=None):
+        pre = (self.B,) if idx < 0 else ()
+        kx, px = _as_array(x, pre + (self.n,), "x")
+        ky, py = _as_array(y, pre + (self.n_eq,), "y")
+        kz, pz = _as_array(z, pre + (self.n_c,), "z")
+        self.lib.check(self.lib.L.pqp_multi_warm_start(self._h, int(idx), px, py, pz))
+
+    def cleanup(self, idx=-1):
+        self.lib.check(self.lib.L.pqp_multi_cleanup(self._h, int(idx)))
+
+    def flush(self):
+        self.lib.check(self.lib.L.pqp_multi_flush(self._h))
+
+    def solve(self, first=None, count=None):
+        if first is None:
+            self.lib.check(self.lib.L.pqp_multi_solve(self._h))
+        else:
+            self.lib.check(self.lib.L.pqp_multi_solve_range(self._h, int(first), int(1 if count is None else count)))
+
+    def solve_async(self):
+        self.lib.check(self.lib.L.pqp_multi_solve_async(self._h))
+
+    def wait(self):
+        self.lib.check(self.lib.L.pqp_multi_wait(self._h))
+
+    @property
+    def last_solve_ms(self):
+        return self.lib.L.pqp_multi_last_solve_ms(self._h)
+
+    def results(self, idx=-1):
+        pre = (self.B,) if idx < 0 else ()
+        x = np.zeros(pre + (self.n,))
+        y = np.zeros(pre + (self.n_eq,))
+        z = np.zeros(pre + (self.n_c,))
+        se = np.zeros(pre + (self.n_eq,))
+        si = np.zeros(pre + (self.n_c,))
+        info = (pqp_info * self.B)() if idx < 0 else pqp_info()
+        p = lambda a: a.ctypes.data_as(_DP)
+        ip = C.cast(info, C.POINTER(pqp_info)) if idx < 0 else C.byref(info)
+        self.lib.check(self.lib.L.pqp_multi_get_results(self._h, int(idx), p(x), p(y), p(z), p(se), p(si), ip))
+        return x, y, z, se, si, info
+
+    def gather_device(self, out, root_shard=0):
+        """(x, y, z, status, iter) of every QP -> `out` ([B][n + n_eq + n_c + 2] fp64, memory of the root shard's device:
+        a torch ROCm tensor or a raw pointer): pack kernel per shard + peer copies"""
+        ptr = out.data_ptr() if hasattr(out, "data_ptr") else (out.ctypes.data if hasattr(out, "ctypes") else int(out))
+        self.lib.check(self.lib.L.pqp_multi_gather_device(self._h, int(root_shard), C.c_void_p(ptr)))
+        return out

@@ -93,6 +93,25 @@ check_idx(pqp_batch* h, int64_t idx)
   return PQP_OK;
 }
 
+// an asynchronous solve still in flight is waited for before anything else touches the handle
+int
+settle(pqp_batch* h)
+{
+  return (h && h->solve_in_flight) ? pqp_batch_wait(h) : PQP_OK;
+}
+
+// the device copy of the results of QP idx (-1: all) is about to change outside a solve: its host mirror is stale
+void
+mirror_stale(pqp_batch* h, int64_t idx)
+{
+  if (!h->host_results)
+    return;
+  if (idx < 0)
+    std::fill(h->mirror_fresh.begin(), h->mirror_fresh.end(), char(0));
+  else
+    h->mirror_fresh[size_t(idx)] = 0;
+}
+
 // copies `count` QPs worth of one model array
 int
 copy_in(double* dst_base, const double* src, int64_t idx, int64_t B, size_t per_qp)
@@ -151,6 +170,9 @@ enqueue_setup(pqp_batch* h, int64_t idx, bool update_call, const double* H, cons
 {
   if (int rc = check_idx(h, idx))
     return rc;
+  if (int rc = settle(h))
+    return rc;
+  mirror_stale(h, idx); // (setup resets or rescales the results by the initial guess, helpers.hpp:522-572)
   const pqp::Dims& d = h->dev.d;
   // wrapper.hpp:367-372, 542-546, 736-741, 846-850
   if (!d.box && (l_box || u_box))
@@ -425,7 +447,12 @@ pqp_batch_destroy(pqp_batch* h)
 {
   if (!h)
     return;
+  (void)settle(h);
   DeviceGuard guard_(h->device);
+  for (void* p : h->host_allocs)
+    (void)hipHostFree(p);
+  if (h->owned_stream)
+    (void)hipStreamDestroy(h->owned_stream);
   for (void* p : h->allocs)
     (void)hipFree(p);
   if (h->ev0)
@@ -486,6 +513,9 @@ pqp_batch_warm_start(pqp_batch* h, int64_t idx, const double* x, const double* y
     return rc;
   if (!x && !y && !z) // helpers.hpp:724-725
     return PQP_OK;
+  if (int rc = settle(h))
+    return rc;
+  mirror_stale(h, idx);
   PQP_ON_DEVICE(h->device);
   // the guess must land after any queued cleanup of the results
   if (h->cmd_pending)
@@ -508,6 +538,9 @@ pqp_batch_cleanup(pqp_batch* h, int64_t idx)
 {
   if (int rc = check_idx(h, idx))
     return rc;
+  if (int rc = settle(h))
+    return rc;
+  mirror_stale(h, idx);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
@@ -531,6 +564,9 @@ pqp_batch_reset_qp(pqp_batch* h, int64_t idx)
 {
   if (!h || idx < 0 || idx >= h->dev.B)
     return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+  if (int rc = settle(h))
+    return rc;
+  mirror_stale(h, idx);
   PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
@@ -578,6 +614,8 @@ pqp_batch_flush(pqp_batch* h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
   if (!h->cmd_pending || h->dev.B == 0)
     return PQP_OK;
+  if (int rc = settle(h))
+    return rc;
   PQP_ON_DEVICE(h->device);
   if (int rc = upload_settings(h))
     return rc;
@@ -624,7 +662,29 @@ pqp_batch_set_stream(pqp_batch* h, void* stream)
 {
   if (!h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (int rc = settle(h)) // (a solve in flight stays on the stream it was launched on)
+    return rc;
+  if (h->owned_stream && static_cast<hipStream_t>(stream) != h->owned_stream) {
+    PQP_ON_DEVICE(h->device);
+    (void)hipStreamDestroy(h->owned_stream);
+    h->owned_stream = nullptr;
+  }
   h->stream = static_cast<hipStream_t>(stream);
+  return PQP_OK;
+}
+
+int
+pqp_batch_own_stream(pqp_batch* h)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (h->owned_stream)
+    return PQP_OK;
+  if (int rc = settle(h))
+    return rc;
+  PQP_ON_DEVICE(h->device);
+  HIP_TRY(hipStreamCreateWithFlags(&h->owned_stream, hipStreamNonBlocking));
+  h->stream = h->owned_stream;
   return PQP_OK;
 }
 
@@ -696,37 +756,107 @@ verbose_report(pqp_batch* h, const int64_t* idx, int64_t first, int64_t count)
   return PQP_OK;
 }
 
-int
-pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
+// Host-side bookkeeping of a finished solve (qp_solve ends with work.is_initialized = true, solver.hpp:1836)
+static int
+finish_solve(pqp_batch* h)
+{
+  const int64_t* idx = h->flight_idx.empty() ? nullptr : h->flight_idx.data();
+  const int64_t first = h->flight_first, count = h->flight_count;
+  for (int64_t i = 0; i < count; ++i) {
+    const size_t q = size_t(idx ? idx[i] : first + i);
+    h->is_initialized[q] = 1;
+    if (h->host_results)
+      h->mirror_fresh[q] = 1; // the epilogue of the solve wrote the mirror of this QP
+  }
+  return verbose_report(h, idx, first, count);
+}
+
+// one launch of the solve kernel over a range or a subset; `async`: return once it is enqueued
+static int
+solve_impl(pqp_batch* h, int64_t first, int64_t count, const int64_t* idx, bool async)
 {
   if (!h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
-  if (first < 0 || count < 0 || first + count > h->dev.B)
-    return fail(PQP_ERR_INVALID_ARGUMENT, "solve range [" + std::to_string(first) + ", " +
-                                            std::to_string(first + count) + ") outside the batch of " +
-                                            std::to_string(h->dev.B) + " QPs");
-  if (count == 0)
-    return PQP_OK;
-  h->range_first = first;
-  h->range_count = count;
+  if (int rc = settle(h))
+    return rc;
+  std::vector<int> order;
+  if (idx) {
+    if (count < 0 || count > h->dev.B)
+      return fail(PQP_ERR_INVALID_ARGUMENT, "subset larger than the batch");
+    if (count == 0)
+      return PQP_OK;
+    order.resize(static_cast<size_t>(count));
+    std::vector<char> seen(static_cast<size_t>(h->dev.B), 0);
+    for (int64_t i = 0; i < count; ++i) {
+      if (idx[i] < 0 || idx[i] >= h->dev.B)
+        return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+      if (seen[size_t(idx[i])]) // two workgroups on one QP would race on its x / y / z / state / factors
+        return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_solve_subset: a QP index is listed twice");
+      seen[size_t(idx[i])] = 1;
+      order[size_t(i)] = int(idx[i]);
+    }
+  } else {
+    if (first < 0 || count < 0 || first + count > h->dev.B)
+      return fail(PQP_ERR_INVALID_ARGUMENT, "solve range [" + std::to_string(first) + ", " +
+                                              std::to_string(first + count) + ") outside the batch of " +
+                                              std::to_string(h->dev.B) + " QPs");
+    if (count == 0)
+      return PQP_OK;
+  }
   PQP_ON_DEVICE(h->device);
   if (int rc = pqp_batch_flush(h))
     return rc;
   if (int rc = upload_settings(h))
     return rc;
-  if (int rc = pqp_launch_solve(h))
+  int rc = 0;
+  if (idx) {
+    // the dispatch-order array doubles as the subset list (a learned order is dropped)
+    HIP_TRY(hipMemcpy(h->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->order_valid = false;
+    h->range_first = 0;
+    h->range_count = long(count);
+    h->subset_order = h->d_order;
+    rc = pqp_launch_solve(h);
+    h->subset_order = nullptr;
+    h->flight_idx.assign(idx, idx + count);
+  } else {
+    h->range_first = first;
+    h->range_count = count;
+    rc = pqp_launch_solve(h);
+    h->flight_idx.clear();
+    if (!rc && h->lpt && first == 0 && count == h->dev.B && count > 1) {
+      // feedback for the next whole-batch launch: order by the device cycles this solve took (same stream: ordered
+      // behind the solve, in front of the next launch)
+      rc = pqp_launch_order(h, long(count));
+      h->order_valid = rc == 0;
+    }
+  }
+  if (rc)
     return rc;
+  h->flight_first = long(first);
+  h->flight_count = long(count);
+  h->solve_in_flight = true;
+  return async ? PQP_OK : pqp_batch_wait(h);
+}
+
+int
+pqp_batch_wait(pqp_batch* h)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (!h->solve_in_flight)
+    return PQP_OK;
+  PQP_ON_DEVICE(h->device);
+  h->solve_in_flight = false;
   HIP_TRY(hipEventSynchronize(h->ev1));
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-  if (h->lpt && first == 0 && count == h->dev.B && count > 1) {
-    // feedback for the next whole-batch launch: order by the device cycles this solve took
-    if (int rc = pqp_launch_order(h, long(count)))
-      return rc;
-    h->order_valid = true;
-  }
-  // qp_solve ends with work.is_initialized = true (solver.hpp:1836)
-  std::fill(h->is_initialized.begin() + first, h->is_initialized.begin() + first + count, char(1));
-  return verbose_report(h, nullptr, first, count);
+  return finish_solve(h);
+}
+
+int
+pqp_batch_solve_range(pqp_batch* h, int64_t first, int64_t count)
+{
+  return solve_impl(h, first, count, nullptr, false);
 }
 
 int
@@ -734,40 +864,129 @@ pqp_batch_solve_subset(pqp_batch* h, const int64_t* idx, int64_t count)
 {
   if (!h || (count > 0 && !idx))
     return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
-  if (count < 0 || count > h->dev.B)
-    return fail(PQP_ERR_INVALID_ARGUMENT, "subset larger than the batch");
   if (count == 0)
     return PQP_OK;
-  std::vector<int> order(static_cast<size_t>(count));
-  std::vector<char> seen(static_cast<size_t>(h->dev.B), 0);
-  for (int64_t i = 0; i < count; ++i) {
-    if (idx[i] < 0 || idx[i] >= h->dev.B)
-      return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
-    if (seen[size_t(idx[i])]) // two workgroups on one QP would race on its x / y / z / state / factors
-      return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_solve_subset: a QP index is listed twice");
-    seen[size_t(idx[i])] = 1;
-    order[size_t(i)] = int(idx[i]);
-  }
+  return solve_impl(h, 0, count, idx, false);
+}
+
+int
+pqp_batch_solve_async(pqp_batch* h)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  return solve_impl(h, 0, h->dev.B, nullptr, true);
+}
+
+int
+pqp_batch_solve_range_async(pqp_batch* h, int64_t first, int64_t count)
+{
+  return solve_impl(h, first, count, nullptr, true);
+}
+
+int
+pqp_batch_solve_subset_async(pqp_batch* h, const int64_t* idx, int64_t count)
+{
+  if (!h || (count > 0 && !idx))
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
+  if (count == 0)
+    return PQP_OK;
+  return solve_impl(h, 0, count, idx, true);
+}
+
+// Host-resident results: pinned, device-mapped mirrors of (x, y, z, se, si, Info) that the solve kernel's epilogue
+// writes beside the device arrays (pqp::Batch::hx ...).
+int
+pqp_batch_enable_host_results(pqp_batch* h, int enable)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (int rc = settle(h))
+    return rc;
+  if ((enable != 0) == h->host_results)
+    return PQP_OK;
   PQP_ON_DEVICE(h->device);
-  if (int rc = pqp_batch_flush(h))
+  pqp::Batch& D = h->dev;
+  if (!enable) {
+    for (void* p : h->host_allocs)
+      (void)hipHostFree(p);
+    h->host_allocs.clear();
+    D.hx = D.hy = D.hz = D.hse = D.hsi = nullptr;
+    D.hinfo = nullptr;
+    h->m_x = h->m_y = h->m_z = h->m_se = h->m_si = nullptr;
+    h->m_info = nullptr;
+    h->host_results = false;
+    return PQP_OK;
+  }
+  const pqp::Dims& d = D.d;
+  const size_t B = size_t(D.B);
+  auto halloc = [&](size_t bytes, void** host, void** dev) -> int {
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocMapped));
+    h->host_allocs.push_back(p);
+    std::memset(p, 0, bytes ? bytes : 8);
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, p, 0));
+    *host = p;
+    *dev = dp;
+    return PQP_OK;
+  };
+  int rc = 0;
+  if ((rc = halloc(B * size_t(d.n) * 8, (void**)&h->m_x, (void**)&D.hx)) ||
+      (rc = halloc(B * size_t(d.n_eq) * 8, (void**)&h->m_y, (void**)&D.hy)) ||
+      (rc = halloc(B * size_t(d.nc) * 8, (void**)&h->m_z, (void**)&D.hz)) ||
+      (rc = halloc(B * size_t(d.n_eq) * 8, (void**)&h->m_se, (void**)&D.hse)) ||
+      (rc = halloc(B * size_t(d.nc) * 8, (void**)&h->m_si, (void**)&D.hsi)) ||
+      (rc = halloc(B * sizeof(pqp_info), (void**)&h->m_info, (void**)&D.hinfo))) {
+    for (void* p : h->host_allocs)
+      (void)hipHostFree(p);
+    h->host_allocs.clear();
+    D.hx = D.hy = D.hz = D.hse = D.hsi = nullptr;
+    D.hinfo = nullptr;
     return rc;
-  if (int rc = upload_settings(h))
+  }
+  h->mirror_fresh.assign(B, 0);
+  h->host_results = true;
+  return PQP_OK;
+}
+
+int
+pqp_batch_host_results(pqp_batch* h, const double** x, const double** y, const double** z, const double** se,
+                       const double** si, const pqp_info** info)
+{
+  if (!h)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  if (!h->host_results)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_enable_host_results has not been called on this batch");
+  if (int rc = settle(h))
     return rc;
-  // the dispatch-order array doubles as the subset list (a learned order is dropped)
-  HIP_TRY(hipMemcpy(h->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
-  h->order_valid = false;
-  h->range_first = 0;
-  h->range_count = long(count);
-  h->subset_order = h->d_order;
-  int rc = pqp_launch_solve(h);
-  h->subset_order = nullptr;
-  if (rc)
-    return rc;
-  HIP_TRY(hipEventSynchronize(h->ev1));
-  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-  for (int64_t i = 0; i < count; ++i)
-    h->is_initialized[size_t(idx[i])] = 1;
-  return verbose_report(h, idx, 0, count);
+  if (x)
+    *x = h->m_x;
+  if (y)
+    *y = h->m_y;
+  if (z)
+    *z = h->m_z;
+  if (se)
+    *se = h->m_se;
+  if (si)
+    *si = h->m_si;
+  if (info)
+    *info = h->m_info;
+  return PQP_OK;
+}
+
+int
+pqp_batch_host_results_fresh(pqp_batch* h, int64_t idx)
+{
+  if (!h || !h->host_results || idx < -1 || idx >= h->dev.B)
+    return 0;
+  if (settle(h))
+    return 0;
+  if (idx >= 0)
+    return h->mirror_fresh[size_t(idx)] ? 1 : 0;
+  for (char c : h->mirror_fresh)
+    if (!c)
+      return 0;
+  return 1;
 }
 
 int
@@ -781,6 +1000,11 @@ pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_i
   if (a.n != b.n || a.n_eq != b.n_eq || a.n_in != b.n_in || a.box != b.box || a.hessian != b.hessian ||
       dst->per_qp.size() != src->per_qp.size())
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_copy_qp: the two batches hold QPs of different shapes");
+  if (int rc = settle(src))
+    return rc;
+  if (int rc = settle(dst))
+    return rc;
+  mirror_stale(dst, dst_idx);
   PQP_ON_DEVICE(src->device);
   if (int rc = pqp_batch_flush(src))
     return rc;
@@ -800,14 +1024,28 @@ pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_i
   return PQP_OK;
 }
 
-int
-pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const double* loss_derivatives,
-                         double eps, double rho_backward, double mu_backward)
+static int
+backward_impl(pqp_batch* h, int64_t first, int64_t count, const int64_t* idx, const double* loss_derivatives,
+              double eps, double rho_backward, double mu_backward)
 {
   if (!h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
   const pqp::Dims& d = h->dev.d;
-  if (first < 0 || count < 0 || first + count > h->dev.B)
+  std::vector<int> order;
+  if (idx) {
+    if (count < 0 || count > h->dev.B)
+      return fail(PQP_ERR_INVALID_ARGUMENT, "subset larger than the batch");
+    order.resize(size_t(count));
+    std::vector<char> seen(size_t(h->dev.B), 0);
+    for (int64_t i = 0; i < count; ++i) {
+      if (idx[i] < 0 || idx[i] >= h->dev.B)
+        return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+      if (seen[size_t(idx[i])])
+        return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_backward_subset: a QP index is listed twice");
+      seen[size_t(idx[i])] = 1;
+      order[size_t(i)] = int(idx[i]);
+    }
+  } else if (first < 0 || count < 0 || first + count > h->dev.B)
     return fail(PQP_ERR_INVALID_ARGUMENT, "backward range outside the batch");
   if (h->vec_scratch)
     return fail(PQP_ERR_UNSUPPORTED, "compute_backward is not built for shapes whose per-QP vectors exceed the LDS of a "
@@ -819,6 +1057,8 @@ pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const doubl
     return fail(PQP_ERR_INVALID_ARGUMENT, "loss_derivatives is required");
   if (count == 0)
     return PQP_OK;
+  if (int rc = settle(h))
+    return rc;
   PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
@@ -828,8 +1068,15 @@ pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const doubl
   // the reference throws for a dual infeasible QP (compute_ECJ.hpp:37-45)
   {
     std::vector<pqp_info> info;
-    info.resize(size_t(count));
-    HIP_TRY(hipMemcpy(info.data(), h->dev.info + first, size_t(count) * sizeof(pqp_info), hipMemcpyDeviceToHost));
+    if (idx) {
+      std::vector<pqp_info> all(B);
+      HIP_TRY(hipMemcpy(all.data(), h->dev.info, B * sizeof(pqp_info), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < count; ++i)
+        info.push_back(all[size_t(idx[i])]);
+    } else {
+      info.resize(size_t(count));
+      HIP_TRY(hipMemcpy(info.data(), h->dev.info + first, size_t(count) * sizeof(pqp_info), hipMemcpyDeviceToHost));
+    }
     for (int64_t i = 0; i < count; ++i)
       if (info[size_t(i)].status == PQP_DUAL_INFEASIBLE)
         return fail(PQP_ERR_INVALID_ARGUMENT,
@@ -860,11 +1107,34 @@ pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const doubl
   bw.dL_du = h->bw_du;
   bw.dL_dl = h->bw_dl;
   bw.first = long(first);
+  bw.order = nullptr;
+  if (idx) {
+    // (the dispatch-order array doubles as the subset list: a learned order is dropped)
+    HIP_TRY(hipMemcpy(h->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->order_valid = false;
+    bw.order = h->d_order;
+  }
   int rc = pqp_launch_backward(h, bw, long(count));
   if (rc)
     return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return PQP_OK;
+}
+
+int
+pqp_batch_backward_range(pqp_batch* h, int64_t first, int64_t count, const double* loss_derivatives, double eps,
+                         double rho_backward, double mu_backward)
+{
+  return backward_impl(h, first, count, nullptr, loss_derivatives, eps, rho_backward, mu_backward);
+}
+
+int
+pqp_batch_backward_subset(pqp_batch* h, const int64_t* idx, int64_t count, const double* loss_derivatives, double eps,
+                          double rho_backward, double mu_backward)
+{
+  if (!h || (count > 0 && !idx))
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
+  return backward_impl(h, 0, count, idx, loss_derivatives, eps, rho_backward, mu_backward);
 }
 
 int
@@ -884,6 +1154,8 @@ pqp_batch_get_backward(pqp_batch* h, int64_t idx, double* dL_dH, double* dL_dg, 
     return rc;
   if (!h->bw_dH)
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_backward has not been called on this batch");
+  if (int rc = settle(h))
+    return rc;
   PQP_ON_DEVICE(h->device);
   const pqp::Dims& d = h->dev.d;
   const size_t n = size_t(d.n), ne = size_t(d.n_eq), ni = size_t(d.n_in);
@@ -903,22 +1175,29 @@ pqp_batch_get_results(pqp_batch* h, int64_t idx, double* x, double* y, double* z
 {
   if (int rc = check_idx(h, idx))
     return rc;
+  if (int rc = settle(h))
+    return rc;
   PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
       return rc;
   const pqp::Dims& d = h->dev.d;
   const pqp::Batch& D = h->dev;
+  // the host mirrors serve the call when they hold what the device holds (no device-to-host copy)
+  const bool mirrored = pqp_batch_host_results_fresh(h, idx) != 0;
+  const double *sx = mirrored ? h->m_x : D.x, *sy = mirrored ? h->m_y : D.y, *sz = mirrored ? h->m_z : D.z,
+               *sse = mirrored ? h->m_se : D.se, *ssi = mirrored ? h->m_si : D.si;
+  const pqp_info* sinfo = mirrored ? h->m_info : D.info;
   int rc = 0;
-  if ((rc = copy_out(x, D.x, idx, D.B, size_t(d.n))) || (rc = copy_out(y, D.y, idx, D.B, size_t(d.n_eq))) ||
-      (rc = copy_out(z, D.z, idx, D.B, size_t(d.nc))) || (rc = copy_out(se, D.se, idx, D.B, size_t(d.n_eq))) ||
-      (rc = copy_out(si, D.si, idx, D.B, size_t(d.nc))))
+  if ((rc = copy_out(x, sx, idx, D.B, size_t(d.n))) || (rc = copy_out(y, sy, idx, D.B, size_t(d.n_eq))) ||
+      (rc = copy_out(z, sz, idx, D.B, size_t(d.nc))) || (rc = copy_out(se, sse, idx, D.B, size_t(d.n_eq))) ||
+      (rc = copy_out(si, ssi, idx, D.B, size_t(d.nc))))
     return rc;
   if (info) {
     if (idx < 0)
-      HIP_TRY(hipMemcpy(info, D.info, size_t(D.B) * sizeof(pqp_info), hipMemcpyDefault));
+      HIP_TRY(hipMemcpy(info, sinfo, size_t(D.B) * sizeof(pqp_info), hipMemcpyDefault));
     else
-      HIP_TRY(hipMemcpy(info, D.info + idx, sizeof(pqp_info), hipMemcpyDefault));
+      HIP_TRY(hipMemcpy(info, sinfo + idx, sizeof(pqp_info), hipMemcpyDefault));
   }
   return PQP_OK;
 }
@@ -946,6 +1225,10 @@ pqp_batch_pack_results(pqp_batch* h, int64_t first, int64_t count, double* out, 
     return fail(PQP_ERR_INVALID_ARGUMENT, "pack range outside the batch");
   if (count == 0)
     return PQP_OK;
+  // (on the launch stream of a solve in flight the pack kernel is ordered behind it: no host wait)
+  if (static_cast<hipStream_t>(stream) != h->stream || h->cmd_pending)
+    if (int rc = settle(h))
+      return rc;
   PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
@@ -961,6 +1244,8 @@ pqp_batch_get_scaled(pqp_batch* h, int64_t idx, double* H, double* g, double* A,
     return rc;
   if (idx < 0)
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_get_scaled addresses one QP");
+  if (int rc = settle(h))
+    return rc;
   PQP_ON_DEVICE(h->device);
   if (h->cmd_pending)
     if (int rc = pqp_batch_flush(h))
@@ -996,6 +1281,8 @@ pqp_batch_get_schur_factor(pqp_batch* h, int64_t idx, double* WS, double* dS, do
     return rc;
   if (idx < 0)
     return fail(PQP_ERR_INVALID_ARGUMENT, "pqp_batch_get_schur_factor addresses one QP");
+  if (int rc = settle(h))
+    return rc;
   PQP_ON_DEVICE(h->device);
   const pqp::Dims& d = h->dev.d;
   const pqp::Batch& D = h->dev;
@@ -1032,6 +1319,8 @@ pqp_batch_get_stats(pqp_batch* h, int64_t* stats)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
   static_assert(PQP_STATS_COUNT == pqp::ST_COUNT, "stats record size");
   static_assert(sizeof(long long) == sizeof(int64_t), "stats element size");
+  if (int rc = settle(h))
+    return rc;
   PQP_ON_DEVICE(h->device);
   HIP_TRY(hipMemcpy(stats, h->dev.stats, size_t(h->dev.B) * pqp::ST_COUNT * sizeof(int64_t), hipMemcpyDefault));
   return PQP_OK;
@@ -1040,6 +1329,8 @@ pqp_batch_get_stats(pqp_batch* h, int64_t* stats)
 double
 pqp_batch_last_solve_ms(const pqp_batch* h)
 {
+  if (h && h->solve_in_flight) // the time of a solve in flight is known once it has finished
+    (void)pqp_batch_wait(const_cast<pqp_batch*>(h));
   return h ? double(h->last_ms) : 0.0;
 }
 

@@ -54,8 +54,23 @@ struct pqp_batch
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
-  bool solve_in_flight = false; // ev1 recorded, elapsed time not read yet (asynchronous solves)
+  // Asynchronous solves (pqp_batch_solve*_async): the launch is enqueued, ev1 recorded, nothing waited for.
+  // pqp_batch_wait -- or any other entry of the handle, which waits first -- reads the elapsed time, runs the
+  // host-side bookkeeping of the finished solve (learned dispatch order, is_initialized, verbose report, mirror
+  // freshness) and clears the flag.
+  bool solve_in_flight = false;
+  long flight_first = 0, flight_count = 0; // the range in flight ...
+  std::vector<int64_t> flight_idx;         // ... or the subset (non-empty)
+  // Host-resident results (pqp_batch_enable_host_results): pinned device-mapped mirrors the solve epilogue writes
+  // (pqp::Batch::hx ...).  mirror_fresh[q]: the mirror of QP q holds what the device holds (set when a solve of q
+  // completes, cleared by everything else that writes x, y, z, se, si or Info of q on the device).
+  bool host_results = false;
+  std::vector<char> mirror_fresh;
+  std::vector<void*> host_allocs;
+  double *m_x = nullptr, *m_y = nullptr, *m_z = nullptr, *m_se = nullptr, *m_si = nullptr; // host addresses of the mirrors
+  pqp_info* m_info = nullptr;
   hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
+  hipStream_t owned_stream = nullptr; // pqp_batch_own_stream: a non-blocking stream created for (and destroyed with) the handle
   bool split_solve = false; // device-filling launches of the C2 kernel run as prepare + iterate kernels (PQP_SPLIT_SOLVE)
   double* vec_scratch = nullptr; // non-null: per-QP vectors live in HBM (B slices of lds_solve bytes), see pqp_kernels.hip TU 9
   long range_first = 0, range_count = 0;

@@ -207,6 +207,13 @@ struct Batch
   // re-factorisation, 5 global residuals, 6 primal block + Z / G) runs rep_count times per occurrence, so that
   // the difference of the PMC byte counters against the plain run is that phase's HBM traffic
   int rep_phase, rep_count;
+  // Host-resident results (pqp_batch_enable_host_results): pinned, device-mapped mirrors [B][...] of x, y, z, se, si
+  // and Info that the epilogue of the solve writes beside the device arrays -- every workgroup pushes its own QP
+  // over the host link as it finishes, so the results are on the host when the launch's event fires, with no
+  // device-to-host copy behind the kernel (reference parallel/qp_solve.hpp:33-37: results are host members when
+  // solve_in_parallel returns).  Null = off.
+  double *hx, *hy, *hz, *hse, *hsi;
+  pqp_info* hinfo;
 };
 
 // QPLayer backward (reference dense/compute_ECJ.hpp): inputs and outputs of one launch.
@@ -218,6 +225,7 @@ struct BackwardArgs
   double eps, rho_new, mu_new;
   double *dL_dH, *dL_dg, *dL_dA, *dL_db, *dL_dC, *dL_du, *dL_dl;
   long first;
+  const int* order; // optional (pqp_batch_backward_subset): workgroup i works on QP order[i]; row i of `ld` is its loss derivative
 };
 
 // LDS carve-up -------------------------------------------------------------------------
@@ -4197,6 +4205,13 @@ struct Solver
     vstore(P.se(), L.se(), ne);
     vstore(P.si(), L.si(), nc);
     vstore(P.dS(), L.dS(), d.nd);
+    if (batch.hx) { // host-mapped mirrors (see Batch)
+      vstore((gptr)(batch.hx + P.lq() * n), L.x(), n);
+      vstore((gptr)(batch.hy + P.lq() * ne), L.y(), ne);
+      vstore((gptr)(batch.hz + P.lq() * nc), L.z(), nc);
+      vstore((gptr)(batch.hse + P.lq() * ne), L.se(), ne);
+      vstore((gptr)(batch.hsi + P.lq() * nc), L.si(), nc);
+    }
     if (pm())
       vstore(P.dF(), L.dF(), n); // D of P_J, beside its inverse factor in the WL buffer
     {
@@ -4217,6 +4232,8 @@ struct Solver
         info.run_time = info.solve_time + info.setup_time;
       }
       info.store(*P.info());
+      if (batch.hinfo)
+        info.store(batch.hinfo[q]);
       W.dirty = 1;
       W.is_initialized = 1;
       W.n_c = n_c;
@@ -4399,7 +4416,7 @@ template<int NT>
 __device__ __forceinline__ void
 backward_body(const Batch& batch, const BackwardArgs& bw, long slot, lptr lds_base)
 {
-  Solver<NT, 0> S(batch, bw.first + slot, lds_base);
+  Solver<NT, 0> S(batch, bw.order ? (long)bw.order[slot] : bw.first + slot, lds_base);
   S.backward(bw, slot);
 }
 

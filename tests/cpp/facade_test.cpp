@@ -404,6 +404,101 @@ main(int argc, char** argv)
     }
   }
 
+  // --- a BatchQP spread over several devices from ONE process (pqp_multi_*; here three logical shards on device 0,
+  // the way the path is exercised on a one-GPU box): same answers bit for bit as the one-device BatchQP above, QPs
+  // land on the shards in contiguous ranges, and two signatures are in flight together
+  {
+    dense::BatchQP<T> multi(usize(num_qps + 1), std::vector<int>{ 0, 0, 0 });
+    CHECK(multi.devices().size() == 3);
+    for (int i = 0; i < num_qps; i++) {
+      const auto& m = models[usize(i)];
+      auto& qp = multi.init_qp_in_place(dim, n_eq, n_in);
+      qp.settings.eps_abs = eps_abs;
+      qp.settings.eps_rel = 0;
+      qp.settings.initial_guess = InitialGuessStatus::NO_INITIAL_GUESS;
+      qp.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+    }
+    // a second signature in the same container: its own multi-device batch, launched alongside
+    utils::rand::set_seed(77);
+    dense::Model<T> other = utils::dense_strongly_convex_qp(dim + 2, n_eq, n_in + 1, sparsity_factor, strong_convexity_factor);
+    auto& qo = multi.init_qp_in_place(dim + 2, n_eq, n_in + 1);
+    qo.settings.eps_abs = eps_abs;
+    qo.settings.eps_rel = 0;
+    qo.init(other.H, other.g, other.A, other.b, other.C, other.l, other.u);
+    CHECK(multi.pools().size() >= 4); // three shards of the first signature + the (one-QP) second
+    usize placed = 0;
+    for (const auto& e : multi.pools())
+      placed += e.members.size();
+    CHECK(isize(placed) == multi.size());
+    dense::solve_in_parallel(multi);
+    for (int i = 0; i < num_qps; i++) {
+      CHECK(multi[i].results.info.status == QPSolverOutput::PROXQP_SOLVED);
+      CHECK(multi[i].results.info.iter == qps_vector[i].results.info.iter);
+      for (isize j = 0; j < dim; ++j)
+        CHECK(multi[i].results.x[j] == qps_vector[i].results.x[j]);
+      for (isize j = 0; j < n_in; ++j)
+        CHECK(multi[i].results.z[j] == qps_vector[i].results.z[j]);
+    }
+    {
+      T pri, dua;
+      residuals(other, qo.results, pri, dua);
+      CHECK(qo.results.info.status == QPSolverOutput::PROXQP_SOLVED);
+      CHECK(pri <= eps_abs && dua <= eps_abs);
+    }
+    // per-QP methods address the right shard: update one QP of the last shard, re-solve it alone
+    auto& last = multi[num_qps - 1];
+    dense::Vec<T> g2 = models[usize(num_qps - 1)].g;
+    for (isize j = 0; j < dim; ++j)
+      g2[j] *= 2;
+    last.update(nullopt, g2, nullopt, nullopt, nullopt, nullopt, nullopt);
+    last.solve();
+    dense::QP<T> ref(dim, n_eq, n_in);
+    ref.settings.eps_abs = eps_abs;
+    ref.settings.eps_rel = 0;
+    ref.settings.initial_guess = InitialGuessStatus::NO_INITIAL_GUESS;
+    {
+      const auto& m = models[usize(num_qps - 1)];
+      ref.init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+      ref.solve();
+      ref.update(nullopt, g2, nullopt, nullopt, nullopt, nullopt, nullopt);
+      ref.solve();
+    }
+    for (isize j = 0; j < dim; ++j)
+      CHECK(last.results.x[j] == ref.results.x[j]);
+    // default constructor: every visible device (one here unless the box has more)
+    dense::BatchQP<T> dflt(4);
+    CHECK(dflt.devices().empty() ? dflt.device() == 0 : dflt.devices().size() > 1);
+  }
+
+  // --- solve_backward_in_parallel over a std::vector of QPs (reference parallel/qp_solve.hpp:83-110): one launch per
+  // pool (pqp_batch_backward_subset), same numbers as compute_backward QP by QP
+  {
+    std::vector<dense::QP<T>> vq, vr;
+    std::vector<dense::Vec<T>> lds;
+    for (int k = 0; k < 3; ++k) {
+      const auto& m = models[usize(k)];
+      for (auto* v : { &vq, &vr }) {
+        v->emplace_back(dim, n_eq, n_in);
+        v->back().settings.eps_abs = eps_abs;
+        v->back().init(m.H, m.g, m.A, m.b, m.C, m.l, m.u);
+      }
+      dense::Vec<T> ld(dim + n_eq + n_in);
+      ld[k] = 1;
+      ld[dim + 1] = 0.5;
+      lds.push_back(ld);
+    }
+    dense::solve_in_parallel(vq);
+    dense::solve_in_parallel(vr);
+    dense::qp_solve_backward_in_parallel<T>(nullopt, vq, lds, 1e-5, 1e-7, 1e-7);
+    for (usize k = 0; k < 3; ++k) {
+      dense::compute_backward<T>(vr[k], lds[k], 1e-5, 1e-7, 1e-7);
+      for (isize j = 0; j < dim; ++j)
+        CHECK(vq[k].model.backward_data.dL_dg[j] == vr[k].model.backward_data.dL_dg[j]);
+      for (isize j = 0; j < n_in; ++j)
+        CHECK(vq[k].model.backward_data.dL_du[j] == vr[k].model.backward_data.dL_du[j]);
+    }
+  }
+
   std::printf("facade_test: %d failure(s)\n", failures);
   return failures == 0 ? 0 : 1;
 }

@@ -295,6 +295,42 @@ hipStreamDestroy(hipStream_t)
 {
   return hipSuccess;
 }
+enum
+{
+  hipStreamNonBlocking = 1,
+  hipHostMallocMapped = 2
+};
+inline hipError_t
+hipStreamCreateWithFlags(hipStream_t* s, unsigned)
+{
+  *s = nullptr;
+  return hipSuccess;
+}
+// pinned, device-mapped host memory: the emulated device IS the host
+inline hipError_t
+hipHostMalloc(void** p, size_t n, unsigned = 0)
+{
+  *p = std::calloc(n ? n : 1, 1);
+  return *p ? hipSuccess : hipErrorInvalidValue;
+}
+inline hipError_t
+hipHostGetDevicePointer(void** dp, void* hp, unsigned)
+{
+  *dp = hp;
+  return hipSuccess;
+}
+inline hipError_t
+hipHostFree(void* p)
+{
+  std::free(p);
+  return hipSuccess;
+}
+inline hipError_t
+hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t = nullptr)
+{
+  std::memmove(d, s, n);
+  return hipSuccess;
+}
 inline hipError_t
 hipGetLastError()
 {
@@ -308,7 +344,10 @@ hipGetErrorString(hipError_t)
 inline hipError_t
 hipGetDeviceCount(int* n)
 {
-  *n = 1;
+  // HIPEMU_DEVICES=<k>: k emulated devices (all of them the host), for the multi-device host logic
+  const char* e = std::getenv("HIPEMU_DEVICES");
+  const int k = e ? std::atoi(e) : 1;
+  *n = k > 0 ? k : 1;
   return hipSuccess;
 }
 inline hipError_t
