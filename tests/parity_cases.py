@@ -483,6 +483,40 @@ def case_c4_shape(lib, oracle, randqp, B=8):
     case_random_batch(lib, oracle, randqp, 512, 200, 400, B=B, compare="all")
 
 
+def case_c3_one_launch(lib, oracle, randqp, B=16384, chunk=2048, n=100, ne=50, ni=100):
+    """BASELINE.json configs[2] on ONE GPU: the 16 384 QPs of the 8-GPU configuration (n=100, n_eq=50, n_in=100,
+    seeds 0 .. B-1: rank r of the sharded run owns the seeds r B/8 ...) in one launch of one handle -- the N = 1 point of
+    the strong-scaling curve.  The full gate on EVERY QP: SOLVED, unscaled KKT residuals <= 1e-9 in numpy, (x, y, z)
+    against the oracle to 1e-10 and equal Info counters (the oracle runs chunk by chunk to bound host memory)."""
+    m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2)
+    b = N.Batch(B, n, ne, ni, lib=lib)
+    b.set_all_settings(eps_abs=EPS, eps_rel=0.0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS))
+    b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
+    b.solve()
+    ms = b.last_solve_ms
+    x, y, z, se, si, info = b.results()
+    st = np.array([info[i].status for i in range(B)])
+    assert np.all(st == int(QPSolverOutput.PROXQP_SOLVED)), np.nonzero(st)[0][:10]
+    dua = np.einsum("bij,bj->bi", m.H, x) + m.g + np.einsum("bij,bi->bj", m.A, y) + np.einsum("bij,bi->bj", m.C, z)
+    Cx = np.einsum("bij,bj->bi", m.C, x)
+    pri = np.maximum(np.abs(np.einsum("bij,bj->bi", m.A, x) - m.b).max(axis=1),
+                     np.abs(np.maximum(Cx - m.u, 0) + np.minimum(Cx - m.l, 0)).max(axis=1))
+    worst = float(max(pri.max(), np.abs(dua).max()))
+    assert worst <= EPS, worst
+    worst_delta = 0.0
+    for lo in range(0, B, chunk):
+        idx = range(lo, min(B, lo + chunk))
+        qs = oracle_solve_many(oracle, [(m.H[i], m.g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i]) for i in idx], n, ne, ni)
+        for i, q in zip(idx, qs):
+            assert close(x[i], q.results.x) and close(y[i], q.results.y) and close(z[i], q.results.z), i
+            bad = info_close(info[i], q.results.info)
+            assert bad is None, (i, bad)
+            worst_delta = max(worst_delta, float(np.max(np.abs(x[i] - q.results.x))), float(np.max(np.abs(z[i] - q.results.z))))
+        del qs
+    b.close()
+    return dict(qps=B, kernel_ms=ms, qps_per_s=B / (ms * 1e-3), max_kkt=worst, max_abs_delta_vs_oracle=worst_delta)
+
+
 def c5_models(randqp, B, dim=200, seed0=0):
     """BASELINE.json configs[4]: dense_box_constrained_qp(dim, 0, dim) (reference
     utils/random_qp_problems.hpp:591-628) with H <- diag(H) (benchmark/timings-diagonal-hessian.cpp:43-56)."""
@@ -665,6 +699,10 @@ def case_closest_feasible(lib, oracle, randqp, seeds, max_oracle_iter_ext=None):
                 # decided at the rounding level, so the device may leave the cycle where the oracle does not.  If it
                 # does, its answer must pass the reference test's acceptance lines, checked below.)
                 assert info[j].status in done + (QPSolverOutput.PROXQP_MAX_ITER_REACHED,), (pis, i, info[j].status)
+                # ... and whichever way it ends, it must end by the MECHANISM (case_seed14_mechanism): the run left
+                # the cycle through the safe guard, and the outcome is the one the value of mu at that exit implies
+                assert info[j].iter > 10000, (i, info[j].iter)
+                assert (info[j].status in done) == (info[j].mu_in < 5e-3), (i, info[j].status, info[j].mu_in)
             else:
                 assert info[j].status == r.info.status, (pis, i, info[j].status, r.info.status)
             if not pis:
@@ -692,6 +730,73 @@ def case_closest_feasible(lib, oracle, randqp, seeds, max_oracle_iter_ext=None):
                 assert pri <= scaled_eps and dua <= eps, (i, pri, dua)
         b.close()
     return seen
+
+
+def case_seed14_mechanism(lib, randqp, guards=range(40, 55), max_iter=2500):
+    """Seed 14 of the reference's closest-feasible family (test/src/dense_qp_wrapper.cpp:7153-7215) ON THE DEVICE: the
+    mechanism that tests/test_oracle_known_answers.py::test_seed14_is_a_fixed_point_of_the_reference_bcl_rule
+    establishes for the oracle, asserted on the kernel's own Info records instead of accepting either outcome.
+      * 11 outer iterations bring the run to the mu floors with y = z = 0 and the primal residual of the penalty
+        minimiser there, 0.129091 (computed in numpy, no oracle) -- above the BCL threshold 0.125893: a bad step
+        for ever, i.e. the cycle;
+      * the only exit is the safe guard (info.iter > safe_guard: every step accepted, mu frozen where the cycle
+        stood): sweeping the guard over one period of the cycle, every run that ends SOLVED passes the reference
+        test's acceptance lines and has mu_in < 5e-3 at the exit, every other run ends MAX_ITER_REACHED with
+        mu_in >= 5e-3 and fails them -- the outcome is a function of the PHASE -- and over a full period (15 guard
+        values) 11 phases end SOLVED, as for the oracle."""
+    (H, g, A, b, C, l, u), = infeasible_family(randqp, [14])[0]
+    dim, ne, ni = 20, 5, 5
+    mu_eq, mu_in = 1e-9, 1e-8
+    act = np.ones(ni, bool)
+    for _ in range(50):
+        K = H + A.T @ A / mu_eq + C[act].T @ C[act] / mu_in
+        xs = np.linalg.solve(K, -g + A.T @ b / mu_eq + C[act].T @ u[act] / mu_in)
+        new = (C @ xs - u) > 0
+        if (new == act).all():
+            break
+        act = new
+    pri_fixed_point = max(np.max(np.abs(A @ xs - b)), np.max(np.maximum(C @ xs - u, 0)))
+    assert abs(pri_fixed_point - 0.129091) < 1e-6
+
+    def batch(B):
+        bt = N.Batch(B, dim, ne, ni, lib=lib)
+        settings_all(bt, eps_abs=1e-5, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS),
+                     primal_infeasibility_solving=1, eps_primal_inf=1e-4, eps_dual_inf=1e-4)
+        bt.init(-1, *[np.stack([a] * B) for a in (H, g, A, b, C, l, u)])
+        return bt
+
+    b1 = batch(1)
+    b1.settings(0).max_iter = 11
+    b1.solve()
+    x, y, z, se, si, info = b1.results()
+    assert abs(info[0].pri_res - pri_fixed_point) <= 1e-6 * pri_fixed_point, info[0].pri_res
+    assert np.max(np.abs(y)) == 0 and np.max(np.abs(z)) == 0
+    # (the 11th outer iteration is the first to see both residuals unchanged at the floors mu_in = 1e-8, mu_eq = 1e-9,
+    # settings.hpp:222-223, so it ends with the cold restart of solver.hpp:1700-1712: mu back to 1 / 1.1)
+    assert abs(info[0].mu_in - 1.0 / 1.1) <= 1e-15 and abs(info[0].mu_eq - 1.0 / 1.1) <= 1e-15, (info[0].mu_in, info[0].mu_eq)
+    b1.close()
+    guards = list(guards)
+    bg = batch(len(guards))
+    for k, gd in enumerate(guards):
+        st = bg.settings(k)
+        st.safe_guard, st.max_iter = gd, max_iter
+    bg.solve()
+    x, y, z, se, si, info = bg.results()
+    done = (QPSolverOutput.PROXQP_SOLVED, QPSolverOutput.PROXQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE)
+    n_ok = 0
+    for k, gd in enumerate(guards):
+        scaled_eps = float(np.max(np.abs(A.T @ np.ones(ne) + C.T @ np.ones(ni)))) * 1e-5
+        Cx = C @ x[k]
+        pri = np.max(np.abs(A.T @ (A @ x[k] - b) + C.T @ (np.maximum(Cx - u, 0) + np.minimum(Cx - l, 0))))
+        dua = np.max(np.abs(H @ x[k] + g + A.T @ y[k] + C.T @ z[k]))
+        ok = bool(pri <= scaled_eps and dua <= 1e-5)
+        assert info[k].iter > gd, (gd, info[k].iter)  # left through the guard
+        assert (info[k].status in done and ok) or (info[k].status == QPSolverOutput.PROXQP_MAX_ITER_REACHED and not ok), \
+            (gd, info[k].status, pri, dua)
+        assert ok == (info[k].mu_in < 5e-3), (gd, info[k].mu_in)  # decided by mu at the exit = the phase of the cycle
+        n_ok += ok
+    bg.close()
+    return n_ok, len(guards)
 
 
 def case_primal_ldlt(lib, oracle, randqp, dim, B, seed0=1):

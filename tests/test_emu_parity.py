@@ -96,6 +96,12 @@ def test_infeasibility_statuses(lib, oracle):
     pc.case_infeasibility_statuses(lib, oracle)
 
 
+def test_seed14_mechanism_on_the_emulated_device(lib, randqp):
+    """(three phases of the cycle here -- the emulator is slow; the MI355X run sweeps the full period)"""
+    n_ok, n = pc.case_seed14_mechanism(lib, randqp, guards=(41, 46, 52), max_iter=2500)
+    assert n == 3
+
+
 def test_closest_feasible(lib, oracle, randqp):
     """seeds whose oracle run is short enough for the emulator (the GPU test runs all 20)"""
     seen = pc.case_closest_feasible(lib, oracle, randqp, seeds=range(6), max_oracle_iter_ext=60)

@@ -943,11 +943,75 @@ def case_py_initializing_with_None(S):  # :4540-4566
     S.check(q, m, eps=1e-3)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# dense_qp_wrapper.cpp:7212-7568: the estimate of the minimal eigenvalue of H handed to init() must come back in
+# results.info.minimal_H_eigenvalue_estimate -- three cases (Eigen's exact solver, a manual value, power iteration),
+# each on a 2 x 2 diagonal H with one negative entry, on 20 random diagonal H (dim 50) and on 20 dense H whose
+# diagonal is shifted by 100 * normal draws (dim 50; generator stream as in the reference: the model first, then
+# vector_rand for the diagonal).  The estimator is the product's host helper
+# (proxsuite_amd.proxqp.dense.estimate_minimal_eigen_value_of_symmetric_matrix: the reference's
+# dense/helpers.hpp:24-166 restated); the value the reference compares with is numpy's here (Eigen's there).
+def _eig_estimator():
+    from proxsuite_amd.proxqp import dense as _d
+    return _d.estimate_minimal_eigen_value_of_symmetric_matrix, _d.EigenValueEstimateMethodOption
+
+
+def _min_eig_case(method, tol, trivial_last):
+    """method: "exact" | "manual" | "power"; trivial_last: the negative diagonal entry of the 2 x 2 problem"""
+
+    def estimate(H, truth):
+        est, Opt = _eig_estimator()
+        if method == "exact":
+            return est(H, Opt.ExactMethod, 1.0e-6, 10000)
+        if method == "power":
+            return est(H, Opt.PowerIteration, 1.0e-6, 10000)
+        return truth
+
+    def run(S, H, m, dim, truth):
+        q = S.make_qp(dim, dim, dim)
+        q.settings.max_iter = 1
+        q.settings.max_iter_in = 1
+        q.settings.initial_guess = NO_GUESS
+        e = estimate(H, truth)
+        q.init(H, m.g, m.A, m.b, m.C, m.l, m.u, compute_preconditioner=True, manual_minimal_H_eigenvalue=e)
+        got = float(q.results.info.minimal_H_eigenvalue_estimate)
+        S.trace.append(dict(value=got, handed=float(e)))
+        assert abs(got - truth) <= tol, "%s: minimal_H_eigenvalue_estimate %.9g, expected %.9g" % (S.name, got, truth)
+
+    def case(S):
+        if S.source == "python":
+            raise NotForThisSource()
+        # trivial 2 x 2 problem (seed 0)
+        S.R.set_seed(0)
+        m = M(S.R.dense_strongly_convex_qp(2, 2, 2, 1.0, 1e-2))
+        H = np.diag([1.0, trivial_last])
+        run(S, H, m, 2, trivial_last)
+        for i in range(20):  # random diagonal H, dim 50
+            S.R.set_seed(i)
+            m = M(S.R.dense_strongly_convex_qp(50, 50, 50, 1.0, 1e-2))
+            d = S.vector_rand(50)
+            run(S, np.diag(d), m, 50, float(d.min()))
+        for i in range(20):  # dense H with a shifted diagonal, dim 50
+            S.R.set_seed(i)
+            m = M(S.R.dense_strongly_convex_qp(50, 50, 50, 1.0, 1e-2))
+            H = m.H.copy()
+            H[np.diag_indices(50)] += 100.0 * S.vector_rand(50)
+            run(S, H, m, 50, float(np.linalg.eigvalsh(H).min()))
+
+    return case
+
+
+case_min_eigenvalue_exact = _min_eig_case("exact", 1e-6, -1.0)    # :7212-7330
+case_min_eigenvalue_manual = _min_eig_case("manual", 1e-6, -1.0)  # :7331-7438
+case_min_eigenvalue_power = _min_eig_case("power", 1e-3, -0.5)    # :7439-7568
+
+
 CASES = {k[5:]: v for k, v in sorted(globals().items()) if k.startswith("case_")}
 # cases that build their own problem without Side.model(): nothing changes for them on the Python suite's family
 OWN_PROBLEM = {"py_deterministic_behavior", "py_exact_solution_known", "py_initializing_with_None",
                "start_from_solution", "lp_with_equalities", "lp_with_equalities_zero_hessian",
-               "unconstrained_not_strongly_convex", "unconstrained_identity", "unconstrained_identity_zero_g"}
+               "unconstrained_not_strongly_convex", "unconstrained_identity", "unconstrained_identity_zero_g",
+               "min_eigenvalue_exact", "min_eigenvalue_manual", "min_eigenvalue_power"}
 assert OWN_PROBLEM <= set(CASES)
 
 
@@ -955,6 +1019,9 @@ def compare_traces(dev, ref):
     """device run against the oracle run of the same case, checked solve by checked solve"""
     assert len(dev) == len(ref)
     for i, (a, b) in enumerate(zip(dev, ref)):
+        if "value" in a:  # a recorded scalar (minimal_H_eigenvalue_estimate after init): the same number on both sides
+            assert a["value"] == b["value"] and a["handed"] == b["handed"], "entry %d: %r != %r" % (i, a, b)
+            continue
         tol = a["tol"]
         assert a["status"] == b["status"], "solve %d: status %d != %d" % (i, a["status"], b["status"])
         for k in ("x", "y", "z") if a["unique_x"] else ("y", "z"):
