@@ -299,10 +299,22 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   h->dev.B = batch_size;
   const int need = d.nd > d.n ? d.nd : d.n;
   h->nt = need <= 256 ? 256 : (need <= 512 ? 512 : 1024);
-  if (need > 1024 || d.nc > 1024) {
+  // Above 1024 rows the 1024-thread kernel walks its one-thread-per-row stages in chunks (the reference has no size
+  // limit, dense/model.hpp:65-68; linalg/dense/factorize.hpp:360-370 switches to a blocked factorisation there).  What
+  // bounds a batch here: the 16-bit constraint ids of the persistent slot list and the LDS of the set-up kernel
+  // (2 (n + n_eq + n_c) doubles of Ruiz scaling).
+  if (need > pqp::MAX_ROWS || pqp::setup_lds_bytes(d, 1024) > 160 * 1024) {
     delete h;
-    return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq+n_in(+n)) > 1024 is not supported by this build");
+    return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq + n_in (+ n)) > " + std::to_string(pqp::MAX_ROWS) +
+                                       " (or n + n_eq + n_in (+ n) > ~10000) is not supported by this build");
   }
+#if PQP_CHUNK_ALL
+  if (const char* e = std::getenv("PQP_TEST_NT_MAX")) { // test hook of the emulator variant: a workgroup narrower than the rows
+    const int f = std::atoi(e);
+    if ((f == 256 || f == 512) && h->nt > f)
+      h->nt = f;
+  }
+#endif
   if (const char* e = std::getenv("PQP_SCHEDULE"))
     h->lpt = std::string(e) == "lpt";
   if (const char* e = std::getenv("PQP_SPLIT_SOLVE"))
@@ -1295,7 +1307,7 @@ pqp_batch_get_schur_factor(pqp_batch* h, int64_t idx, double* WS, double* dS, do
     std::vector<int> raw(nc);
     HIP_TRY(hipMemcpy(raw.data(), D.act + size_t(idx) * nc, nc * sizeof(int), hipMemcpyDefault));
     for (size_t j = 0; j < nc; ++j)
-      slots[j] = (raw[j] & 0xffff) - 1; // (bits 16-17 carry the persistent up / low flags)
+      slots[j] = pqp::act_cid(raw[j]); // (bits 16-17 carry the persistent up / low flags)
   }
   pqp::State s;
   HIP_TRY(hipMemcpy(&s, D.state + idx, sizeof(s), hipMemcpyDefault));

@@ -85,6 +85,33 @@ incr_max(int r)
   return v < PQP_INCR_BASE ? (PQP_INCR_BASE < INCR_MAX ? PQP_INCR_BASE : INCR_MAX) : (v > INCR_MAX ? INCR_MAX : v);
 }
 
+// Rows beyond the workgroup size: the stages with one thread per row walk them in chunks of NT rows in the 1024-thread
+// kernels (problems above 1024 rows; reference dense/model.hpp:65-68 has no size limit).  PQP_CHUNK_ALL = 1 compiles the
+// chunk loops into every kernel width -- the emulator build of tests/test_emu_parity.py, which then runs shapes wider
+// than a deliberately narrow workgroup (PQP_TEST_NT_MAX) through them.
+#ifndef PQP_CHUNK_ALL
+#define PQP_CHUNK_ALL 0
+#endif
+constexpr int MAX_ROWS = 4096; // max(n, n_eq + n_c) a batch may have (pqp_batch_create)
+// the persistent slot list packs (constraint id + 1) of a slot in bits 0-15 and the active_set_up / active_set_low
+// flags of constraint i in bits 16-17 of act[i] (solver, backward, pqp_batch_get_schur_factor)
+static_assert(MAX_ROWS + 1 < (1 << 16), "act[] packs constraint ids into 16 bits");
+__host__ __device__ inline int
+act_pack(int cid, int flags)
+{
+  return (cid + 1) | ((flags & 3) << 16);
+}
+__host__ __device__ inline int
+act_cid(int packed) // -1: hole / no slot
+{
+  return (packed & 0xffff) - 1;
+}
+__host__ __device__ inline int
+act_flags(int packed)
+{
+  return (packed >> 16) & 3;
+}
+
 struct Dims
 {
   int n, n_eq, n_in; // problem sizes
@@ -1963,25 +1990,37 @@ struct Solver
     lptr pv = L.rd(), beta = L.ed(), wp = L.sd();
     // p_i = -W[i][p] (i > p): the vector L33^{-1} l_p of the rank-1 update; row p of W for the
     // columns left of it
-    const int i_own = p + 1 + threadIdx.x; // NT >= rr: one thread per trailing row
-    double my_p = 0.0, my_d = 1.0, my_e = 0.0;
-    if (i_own < rr) {
-      my_p = -W[(long)i_own * nd + p];
-      my_d = L.dS()[i_own];
-      my_e = my_p * my_p / my_d;
-    }
     for (int c = threadIdx.x; c < p; c += NT)
       wp[c] = W[(long)p * nd + c];
-    // 1 / alpha_{i+1} = 1 / d_p + sum_{p < k <= i} p_k^2 / d_k   (update.hpp:243-262, as a scan)
-    const double incl = block_scan_inclusive<NT>(my_e, L.part());
-    const double inv_a0 = 1.0 / L.dS()[p];
-    if (i_own < rr) {
-      const double c_i = inv_a0 + incl, c_im1 = c_i - my_e;
-      pv[i_own] = my_p;
-      beta[i_own] = my_p / (my_d * c_i);     // beta_i = alpha_{i+1} p_i / d_i
-      L.dS()[i_own] = my_d * (c_i / c_im1);  // d'_i   = d_i alpha_i / alpha_{i+1}
+    // one thread per trailing row; the 1024-thread kernels walk blocks beyond 1024 rows in chunks of NT rows, the
+    // prefix sum carried from chunk to chunk (one chunk, carry 0, in every other kernel: the code of rounds 2-3)
+    constexpr bool CHUNKED = (NT == 1024) || PQP_CHUNK_ALL;
+    double carry = 0.0;
+    for (int base = p + 1; base == p + 1 || (CHUNKED && base < rr); base += NT) {
+      const int i_own = base + threadIdx.x;
+      double my_p = 0.0, my_d = 1.0, my_e = 0.0;
+      if (i_own < rr) {
+        my_p = -W[(long)i_own * nd + p];
+        my_d = L.dS()[i_own];
+        my_e = my_p * my_p / my_d;
+      }
+      // 1 / alpha_{i+1} = 1 / d_p + sum_{p < k <= i} p_k^2 / d_k   (update.hpp:243-262, as a scan)
+      const double incl = carry + block_scan_inclusive<NT>(my_e, L.part());
+      const double inv_a0 = 1.0 / L.dS()[p];
+      if (i_own < rr) {
+        const double c_i = inv_a0 + incl, c_im1 = c_i - my_e;
+        pv[i_own] = my_p;
+        beta[i_own] = my_p / (my_d * c_i);     // beta_i = alpha_{i+1} p_i / d_i
+        L.dS()[i_own] = my_d * (c_i / c_im1);  // d'_i   = d_i alpha_i / alpha_{i+1}
+      }
+      if (CHUNKED && base + NT < rr) {
+        if (threadIdx.x == NT - 1)
+          L.part()[NT / WAVE] = incl;
+        __syncthreads();
+        carry = L.part()[NT / WAVE];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // W' = Ltilde^{-1} (W + p w_p^T on the columns left of p):  x_i = y_i - p_i s,  s += beta_i x_i
     // down each column; all lanes walk the same row (coalesced), entries above the diagonal read
     // as the zeros they are and are not written
@@ -2013,8 +2052,8 @@ struct Solver
     // the slot becomes a hole: identity row and column, unit pivot
     for (int c = threadIdx.x; c < p; c += NT)
       W[(long)p * nd + c] = 0.0;
-    if (i_own < rr)
-      W[(long)i_own * nd + p] = 0.0;
+    for (int i = p + 1 + threadIdx.x; i < rr; i += NT)
+      W[(long)i * nd + p] = 0.0;
     if (threadIdx.x == 0)
       L.dS()[p] = 1.0;
     bytes((long)(rr - p) * rr * 16);
@@ -2091,23 +2130,35 @@ struct Solver
         pv[i] = (i >= k) ? ik * W[(long)i * n + k] : 0.0;
       __syncthreads();
     }
-    const int i_own = threadIdx.x; // NT >= n
-    double my_p = 0.0, my_d = 1.0, my_e = 0.0;
-    if (i_own < n) {
-      my_p = pv[i_own];
-      my_d = L.dF()[i_own];
-      my_e = my_p * my_p / my_d;
-    }
-    const double incl = block_scan_inclusive<NT>(my_e, L.part());
     const double inv_a0 = sign * double(info.mu_in); // 1 / alpha_0, alpha_0 = +- 1 / mu_in
     double bad = 0.0;
-    if (i_own < n) {
-      const double c_i = inv_a0 + incl, c_im1 = c_i - my_e;
-      const double dn = my_d * (c_i / c_im1);
-      beta[i_own] = my_p / (my_d * c_i);
-      L.dF()[i_own] = dn;
-      if (!(dn > 0.0) || !(c_i * c_im1 > 0.0))
-        bad = 1.0;
+    // one thread per row; beyond 1024 rows the 1024-thread kernels walk them in chunks (see schur_delete)
+    constexpr bool CHUNKED = (NT == 1024) || PQP_CHUNK_ALL;
+    double carry = 0.0;
+    for (int base = 0; base == 0 || (CHUNKED && base < n); base += NT) {
+      const int i_own = base + threadIdx.x;
+      double my_p = 0.0, my_d = 1.0, my_e = 0.0;
+      if (i_own < n) {
+        my_p = pv[i_own];
+        my_d = L.dF()[i_own];
+        my_e = my_p * my_p / my_d;
+      }
+      const double incl = carry + block_scan_inclusive<NT>(my_e, L.part());
+      if (i_own < n) {
+        const double c_i = inv_a0 + incl, c_im1 = c_i - my_e;
+        const double dn = my_d * (c_i / c_im1);
+        beta[i_own] = my_p / (my_d * c_i);
+        L.dF()[i_own] = dn;
+        if (!(dn > 0.0) || !(c_i * c_im1 > 0.0))
+          bad = 1.0;
+      }
+      if (CHUNKED && base + NT < n) {
+        if (threadIdx.x == NT - 1)
+          L.part()[NT / WAVE] = incl;
+        __syncthreads();
+        carry = L.part()[NT / WAVE];
+        __syncthreads();
+      }
     }
     bad = R.max(bad);
     for (int c = threadIdx.x; c < n; c += NT) {
@@ -3265,7 +3316,7 @@ struct Solver
     // (the kernels that serve such shapes; the kernel of the common signature -- C2 -- stays as it is.  PQP_LS_BRACKET_ALL=1
     // compiles the bracket into every kernel and takes it from 64 constraints on: -6.7 % at C2, profiles/r03_ab_linesearch_bracket.txt)
     if constexpr (PQP_LS_BRACKET && ((SPEC == 0 && NT == 256) || PQP_LS_BRACKET_ALL))
-    if (2 * nc > NT || (PQP_LS_BRACKET_ALL && nc >= 64)) {
+    if ((2 * nc > NT || (PQP_LS_BRACKET_ALL && nc >= 64)) && nc <= NT) { // (its per-thread lists hold two breakpoints)
       double alpha_b;
       sub_tic(ST_CYC_LS_EVAL);
       const bool ok = ls_bracket(a0, b0, alpha_b);
@@ -3273,6 +3324,10 @@ struct Solver
       if (ok)
         return alpha_b;
     }
+    // more breakpoints than two per thread (n_c > NT: only the 1024-thread kernels meet such shapes, above 1024 rows)
+    if constexpr (NT == 1024 || PQP_CHUNK_ALL)
+      if (PQP_UNLIKELY(nc > NT))
+        return ls_all_breakpoints_wide(a0, b0);
     // breakpoints (linesearch.hpp:378-391): every breakpoint gets its own thread and
     // its own phi'(alpha) -- no sort, no sequential walk
     sub_tic(ST_CYC_LS_EVAL);
@@ -3341,6 +3396,94 @@ struct Solver
     for (int rep = 0; rep < 2; ++rep)
       if (my_alpha[rep] > 0 && my_alpha[rep] == aln)
         gln = fmax(gln, my_grad[rep]);
+    gln = R.max(gln);
+    if (aln == 0.0) { // :477-495
+      double ai, bi;
+      ls_ineq_terms(0.0, ai, bi);
+      gln = b0 + bi;
+    }
+    if (!(afp < INF)) { // :496-526
+      double ai, bi;
+      ls_ineq_terms(2 * aln + 1, ai, bi);
+      return -(b0 + bi) / (a0 + ai);
+    }
+    return fabs(aln - gln * (afp - aln) / (gfp - gln)); // :534-536
+  }
+
+  // The all-breakpoints evaluation of primal_dual_ls for n_c > NT: a thread owns the breakpoints t, t + NT, t + 2 NT ...
+  // and, instead of keeping (alpha, phi') of each in registers, walks them three times -- phi' (the serial loop over
+  // the constraints) is only evaluated for every breakpoint in the first walk, afterwards for the ones that tie with
+  // the selected step lengths.  Same expressions, same selections, same result as the two-per-thread form.
+  __device__ __forceinline__ double ls_all_breakpoints_wide(double a0, double b0)
+  {
+    const int nc = d.nc;
+    const double INF = __builtin_inf();
+    auto alpha_of = [&](int t) -> double {
+      const int i = t >> 1;
+      const double cdx = L.Cdx()[i];
+      double al = -1.0;
+      if (cdx != 0.) {
+        const double num = (t & 1) ? L.si()[i] : L.rup()[i];
+        al = -num / (cdx + MACHINE_EPS);
+      }
+      return al;
+    };
+    auto grad_of = [&](double al) -> double {
+      double ai, bi;
+      ls_ineq_terms(al, ai, bi);
+      return (a0 + ai) * al + (b0 + bi);
+    };
+    double first_pos_alpha = INF;
+    int cnt = 0;
+    for (int t = threadIdx.x; t < 2 * nc; t += NT) {
+      const double al = alpha_of(t);
+      if (al > MACHINE_EPS) {
+        const double gr = grad_of(al);
+        ++cnt;
+        if (!(gr < 0) && al < first_pos_alpha)
+          first_pos_alpha = al;
+      }
+    }
+    count(ST_N_LS_BREAKPOINTS, cnt);
+    double afp, cntd;
+    {
+      double sv[1] = { (double)cnt };
+      double mv[1] = { -first_pos_alpha };
+      R.template mixed<1, 1>(sv, mv);
+      cntd = sv[0];
+      afp = -mv[0];
+    }
+    if (cntd == 0.0) { // :405-419
+      double ai, bi;
+      ls_ineq_terms(0.0, ai, bi);
+      return -(b0 + bi) / (a0 + ai);
+    }
+    double gfp = -INF, aln = 0;
+    for (int t = threadIdx.x; t < 2 * nc; t += NT) {
+      const double al = alpha_of(t);
+      if (al > MACHINE_EPS) {
+        if (al == afp) {
+          const double gr = grad_of(al);
+          if (!(gr < 0))
+            gfp = fmax(gfp, gr);
+        }
+        if (al < afp)
+          aln = fmax(aln, al); // last breakpoint strictly before it
+      }
+    }
+    {
+      double none[1] = { 0.0 };
+      double mv[2] = { gfp, aln };
+      R.template mixed<0, 2>(none, mv);
+      gfp = mv[0];
+      aln = mv[1];
+    }
+    double gln = -INF;
+    for (int t = threadIdx.x; t < 2 * nc; t += NT) {
+      const double al = alpha_of(t);
+      if (al > MACHINE_EPS && al == aln)
+        gln = fmax(gln, grad_of(al));
+    }
     gln = R.max(gln);
     if (aln == 0.0) { // :477-495
       double ai, bi;
@@ -3732,7 +3875,7 @@ struct Solver
       // persistent slot list (bits 16-17 of act[i]; zero for a new object).
       const PQP_GLOBAL int* ga = P.act();
       for (int i = threadIdx.x; i < nc; i += NT) {
-        L.aflags()[i] = (ga[i] >> 16) & 3;
+        L.aflags()[i] = act_flags(ga[i]);
         L.slot_of()[i] = -1;
       }
     }
@@ -3854,7 +3997,7 @@ struct Solver
       {
         const PQP_GLOBAL int* ga = P.act();
         for (int j = threadIdx.x; j < n_slots; j += NT) {
-          const int i = (ga[j] & 0xffff) - 1;
+          const int i = act_cid(ga[j]);
           L.act()[j] = (i >= 0) ? i : 0; // a hole keeps a valid row index; no slot_of points at it
           if (i >= 0)
             L.slot_of()[i] = j;
@@ -4219,7 +4362,7 @@ struct Solver
       // live slot, 0 for a hole (low 16 bits); the persistent up / low flags of constraint i in bits 16-17
       PQP_GLOBAL int* ga = P.act();
       for (int i = threadIdx.x; i < nc; i += NT)
-        ga[i] = (((i < n_slots && slot_live(ne + i)) ? L.act()[i] : -1) + 1) | ((L.aflags()[i] & 3) << 16);
+        ga[i] = act_pack((i < n_slots && slot_live(ne + i)) ? L.act()[i] : -1, L.aflags()[i]);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -4397,7 +4540,7 @@ struct Solver
       // forward solve starts from them (see solve())
       PQP_GLOBAL int* ga = P.act();
       for (int i = threadIdx.x; i < ni; i += NT)
-        ga[i] = (ga[i] & 0xffff) | ((L.aflags()[i] & 3) << 16);
+        ga[i] = act_pack(act_cid(ga[i]), L.aflags()[i]);
     }
     __syncthreads();
     if (threadIdx.x == 0) {

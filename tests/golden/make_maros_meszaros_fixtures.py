@@ -20,11 +20,15 @@ SRC = "/root/reference/test/data/maros_meszaros_data"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "maros_meszaros_small.npz")
 OUT_MEDIUM = os.path.join(HERE, "maros_meszaros_medium.npz")
+# beyond the reference test's own selection (it stops at 1000 rows): problems whose constraint rows exceed the 1024
+# threads of the widest workgroup, for the chunked stages of the 1024-thread kernel
+OUT_LARGE = os.path.join(HERE, "maros_meszaros_large.npz")
+LARGE = ("GOULDQP2", "CVXQP2_M")
 
 
-def load(path):
+def load(path, any_size=False):
     d = sio.loadmat(path)
-    if d["P"].shape[0] > 1000 or d["A"].shape[0] > 1000:
+    if not any_size and (d["P"].shape[0] > 1000 or d["A"].shape[0] > 1000):
         return None
     dense = lambda m: m.toarray() if hasattr(m, "toarray") else np.asarray(m)
     P, A = dense(d["P"]).astype(np.float64), dense(d["A"]).astype(np.float64)
@@ -49,7 +53,24 @@ def load_medium(path=OUT_MEDIUM, only=None):
     return out
 
 
+def pack_coo(store, name, P, q, A, l, u):
+    for k, m in (("P", P), ("A", A)):
+        c = sp.coo_matrix(m)
+        store["%s/%s_row" % (name, k)] = c.row.astype(np.int32)
+        store["%s/%s_col" % (name, k)] = c.col.astype(np.int32)
+        store["%s/%s_val" % (name, k)] = c.data
+        store["%s/%s_shape" % (name, k)] = np.array(m.shape, dtype=np.int64)
+    for k, v in zip("qlu", (q, l, u)):
+        store["%s/%s" % (name, k)] = v
+
+
 def main():
+    large = {}
+    for name in LARGE:
+        pack_coo(large, name, *load(os.path.join(SRC, name + ".mat"), any_size=True))
+    large["names"] = np.array(LARGE)
+    np.savez_compressed(OUT_LARGE, **large)
+    print("wrote", OUT_LARGE, len(LARGE), "problems", os.path.getsize(OUT_LARGE), "bytes")
     small, medium = {}, {}
     names_small, names_medium = [], []
     for f in sorted(glob.glob(os.path.join(SRC, "*.mat"))):

@@ -93,7 +93,7 @@ def oracle_solve(oracle, m, i, n, ne, ni, guess, **qpkw):
 
 
 def case_random_batch(lib, oracle, randqp, n, ne, ni, B, guess=InitialGuess.NO_INITIAL_GUESS, sparsity=0.15,
-                      compare=True):
+                      compare=True, info_residuals=True):
     """benchmark/timings-parallel.cpp:43-63 workload at arbitrary size."""
     m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, sparsity, 1e-2)
     b = N.Batch(B, n, ne, ni, lib=lib)
@@ -113,7 +113,9 @@ def case_random_batch(lib, oracle, randqp, n, ne, ni, B, guess=InitialGuess.NO_I
                                n, ne, ni, guess)
         for i, q in zip(idx, qs):
             assert close(x[i], q.results.x) and close(y[i], q.results.y) and close(z[i], q.results.z), i
-            bad = info_close(info[i], q.results.info)
+            # (info_residuals=False: shapes of thousands of rows, whose duality gap is a sum of thousands of terms of
+            # size 1 that cancel to 1e-9 -- the two summation orders differ by 1e-11 there; everything else is compared)
+            bad = info_close(info[i], q.results.info, residuals=info_residuals)
             assert bad is None, (i, bad)
     b.close()
     return x, y, z, info

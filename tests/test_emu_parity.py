@@ -96,6 +96,24 @@ def test_infeasibility_statuses(lib, oracle):
     pc.case_infeasibility_statuses(lib, oracle)
 
 
+def test_rows_beyond_the_workgroup(oracle, randqp):
+    """Problems above 1024 rows run the 1024-thread kernel with its one-thread-per-row stages (row deletion from the
+    Schur factor, the rank-1 update of the PrimalLDLT factor) walking the rows in chunks.  Here the same chunk loops
+    (emulator variant -DPQP_CHUNK_ALL=1) under a deliberately narrow workgroup (PQP_TEST_NT_MAX=256 for shapes of 600
+    constraint rows / 300 variables), against the oracle."""
+    import build as emu_build
+    lib2 = N.NativeLib(emu_build.build_variant("chunkall", ["PQP_CHUNK_ALL=1"]))
+    os.environ["PQP_TEST_NT_MAX"] = "256"
+    try:
+        b = N.Batch(1, 30, 4, 600, lib=lib2)
+        assert b.launch_config()[0] == 256
+        b.close()
+        pc.case_random_batch(lib2, oracle, randqp, 30, 4, 600, B=2)
+        pc.case_primal_ldlt(lib2, oracle, randqp, dim=280, B=1)
+    finally:
+        del os.environ["PQP_TEST_NT_MAX"]
+
+
 def test_seed14_mechanism_on_the_emulated_device(lib, randqp):
     """(three phases of the cycle here -- the emulator is slow; the MI355X run sweeps the full period)"""
     n_ok, n = pc.case_seed14_mechanism(lib, randqp, guards=(41, 46, 52), max_iter=2500)

@@ -116,6 +116,32 @@ def test_launch_size_invariance(lib, randqp, shape):
     pc.case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk, box=box)
 
 
+@pytest.mark.parametrize("shape", [(1500, 300, 600), (60, 10, 1500), (40, 0, 2100)])
+def test_rows_above_1024(lib, oracle, randqp, shape):
+    """More rows than the widest workgroup has threads (reference dense/model.hpp:65-68 has no size limit): 1500
+    variables with 900 constraint rows; 1510 and 2100 constraint rows on a few variables (3000 / 4200 line-search
+    breakpoints on 1024 threads).  The 1024-thread kernel walks its one-thread-per-row stages in chunks; every QP
+    against the oracle (1e-10, equal Info counters) like any other shape."""
+    n, ne, ni = shape
+    pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B=2, compare="all", info_residuals=False)
+
+
+@pytest.mark.parametrize("name", ["GOULDQP2", "CVXQP2_M"])
+def test_maros_meszaros_above_1024_rows(lib, name):
+    """Maros-Meszaros problems with 1048 and 1250 constraint rows (beyond the reference test's own 1000-row cut),
+    to the reference test's acceptance lines"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_maros_meszaros_fixtures as mm
+    pc.case_maros_meszaros(lib, *mm.load_medium(mm.OUT_LARGE, only=name)[name])
+
+
+def test_size_limit_is_reported(lib):
+    """beyond 4096 rows the library says so instead of computing garbage"""
+    with pytest.raises(N.NativeError):
+        N.Batch(1, 10, 0, 5000, lib=lib)
+
+
 def test_full_size_c2_all_against_oracle(lib, oracle, randqp):
     """BASELINE.json configs[1]: 2048 random dense QPs, n=100 n_eq=50 n_in=100.  Every QP must
     reach SOLVED with unscaled KKT residuals <= 1e-9 (numpy), and EVERY solution is compared with

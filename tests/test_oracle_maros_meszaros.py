@@ -70,3 +70,12 @@ def test_maros_meszaros_medium(oracle, name):
     """the other 29 problems the reference test runs (n <= 1000 and n_eq + n_in <= 1000,
     test/src/dense_maros_meszaros.cpp:97), from the committed triplet fixture"""
     _check(oracle, *_medium().load_medium(only=name)[name])
+
+
+@pytest.mark.parametrize("name", ["GOULDQP2", "CVXQP2_M"])
+def test_maros_meszaros_above_1024_rows(oracle, name):
+    """two problems beyond the reference test's selection (1048 and 1250 constraint rows: more rows than the widest
+    workgroup has threads), to the same acceptance lines; the GPU suite runs them through the chunked 1024-thread
+    kernel (tests/test_gpu_parity.py::test_maros_meszaros_above_1024_rows)"""
+    mm = _medium()
+    _check(oracle, *mm.load_medium(mm.OUT_LARGE, only=name)[name])
