@@ -29,6 +29,22 @@ class NativeError(RuntimeError):
     pass
 
 
+class _Tolerant:
+    """prototype sink for NativeLib(legacy=True): attributes of symbols the library lacks are swallowed"""
+
+    class _Sink:
+        pass
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_lib", lib)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(object.__getattribute__(self, "_lib"), name)
+        except AttributeError:
+            return _Tolerant._Sink()
+
+
 class NativeLib:
     """Prototypes of every symbol include/proxqp_hip.h declares."""
 
@@ -47,9 +63,12 @@ class NativeLib:
                "pqp_multi_solve_async", "pqp_multi_solve_range_async", "pqp_multi_wait", "pqp_multi_get_results",
                "pqp_multi_gather_device", "pqp_multi_last_solve_ms")
 
-    def __init__(self, path):
+    def __init__(self, path, legacy=False):
+        """legacy=True (A/B scripts only): an older build of the library that lacks the newer entries can still be
+        driven through the entries it has -- the product path (`load()`) binds every symbol or fails"""
         self.path = str(path)
-        L = C.CDLL(self.path)
+        real = C.CDLL(self.path)
+        L = _Tolerant(real) if legacy else real
         vp = C.c_void_p
         L.pqp_last_error.restype = C.c_char_p
         L.pqp_device_count.restype = C.c_int
@@ -116,7 +135,7 @@ class NativeLib:
         L.pqp_multi_gather_device.argtypes = [vp, C.c_int, vp]
         L.pqp_multi_last_solve_ms.argtypes = [vp]
         L.pqp_multi_last_solve_ms.restype = C.c_double
-        self.L = L
+        self.L = real
 
     def check(self, rc):
         if rc != 0:

@@ -603,11 +603,6 @@ gemv_dual_part_len(int nt, int n)
 {
   return (nt / WAVE) * (n < 128 ? n : 128);
 }
-__host__ __device__ inline int
-symv_lower_part_len(int nt, int n)
-{
-  return gemv_dual_part_len(nt, n);
-}
 
 // GATHER = true: row r of the product is row  r < rowsplit ? r : rowsplit + rowmap[r - rowsplit]
 // of M (the gemv convention; rowmap in LDS).
@@ -645,9 +640,6 @@ enum
 // TRIL = true: M is LOWER triangular with explicit zeros above the diagonal (the inverse factors W_S / W_P): a
 // 16 W-column stripe of a row step is only loaded when some row of the wavefront's step reaches it (wave-uniform
 // test, as in symv_lower); the skipped elements are exact zeros, so every sum keeps its bits.
-#ifndef PQP_TRIL_SKIP
-#define PQP_TRIL_SKIP 1
-#endif
 template<int NT, bool COLS, bool GATHER, bool ROWS, int W, bool TRIL = false>
 __device__ __forceinline__ void
 gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lptr colout, lptr part,
@@ -691,7 +683,7 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
         const int rmax = base + u * 4 * NW + 4 * wid + 3; // last row of this wavefront's step (wave-uniform)
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          if (c0 + 16 * W * c < n && (!(TRIL && PQP_TRIL_SKIP) || c0 + 16 * W * c <= rmax)) { // stripe test is wave-uniform
+          if (c0 + 16 * W * c < n && (!TRIL || c0 + 16 * W * c <= rmax)) { // stripe test is wave-uniform
             if (W == 2) {
               const Pair t = load_pair(row + off[c]);
               m[u][c][0] = t.x;
@@ -764,126 +756,6 @@ gemv_dual_impl(cgptr M, int ld, int R, int n, clptr v, clptr w, lptr rowout, lpt
     }
   }
   __syncthreads();
-}
-
-// ---------------------------------------------------------------------------
-// symv_lower: out = S v for a SYMMETRIC row-major n x n matrix S of which only the lower triangle is read
-// (half the bytes of a full pass):  out[i] = sum_{j <= i} S[i][j] v[j]  +  sum_{r > i} S[r][i] v[r]  -- the row
-// sums over the triangle including the diagonal plus the column sums over the strict triangle, in ONE pass with
-// the lane layout of gemv_dual (16 lanes share a row, W doubles per lane and load).  A 16 W-column stripe of a
-// row step is loaded only if some row of that wavefront's step reaches it (wave-uniform test); elements beyond the
-// diagonal inside a loaded stripe are masked.  `part`: symv_lower_part_len() doubles.  v must not alias out.
-// ---------------------------------------------------------------------------
-template<int NT, int W>
-__device__ __forceinline__ void
-symv_lower_impl(cgptr M, int ld, int n, clptr v, lptr out, lptr part)
-{
-  constexpr int NW = NT / WAVE;
-  constexpr int CH = 8 / W;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wid = threadIdx.x / WAVE;
-  const int g = lane >> 4, s = lane & 15;
-  for (int c0 = 0; c0 < n; c0 += 128) {
-    double vv[CH][W], acc[CH][W];
-    int off[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int col = c0 + 16 * W * c + W * s;
-      off[c] = (col < n) ? col : (n - W);
-#pragma unroll
-      for (int e = 0; e < W; ++e) {
-        vv[c][e] = (col + e < n) ? v[off[c] + e] : 0.0;
-        acc[c][e] = 0.0;
-      }
-    }
-    constexpr int U = PQP_DUAL_U;
-    // rows below c0 have nothing in this column block
-    for (int base = (c0 / (U * 4 * NW)) * (U * 4 * NW); base < n; base += U * 4 * NW) {
-      int r[U];
-      bool valid[U];
-      double m[U][CH][W];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        r[u] = base + u * 4 * NW + 4 * wid + g;
-        valid[u] = r[u] < n;
-        const int rsrc = valid[u] ? r[u] : (n - 1);
-        const int rmax = base + u * 4 * NW + 4 * wid + 3; // last row of this wavefront's step (wave-uniform)
-        cgptr row = M + (long)rsrc * ld;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int cfirst = c0 + 16 * W * c;
-          if (cfirst < n && cfirst <= rmax) {
-            if (W == 2) {
-              const Pair t = load_pair(row + off[c]);
-              m[u][c][0] = t.x;
-              m[u][c][W - 1] = t.y;
-            } else {
-              m[u][c][0] = row[off[c]];
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < W; ++e)
-              m[u][c][e] = 0.0;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        double p0 = 0, p1 = 0;
-        const double wr = valid[u] ? v[valid[u] ? r[u] : 0] : 0.0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-          for (int e = 0; e < W; ++e) {
-            const int col = c0 + 16 * W * c + W * s + e;
-            const double low = (valid[u] && col <= r[u] && col < n) ? m[u][c][e] : 0.0;    // triangle incl. diagonal
-            const double strict = (col < r[u]) ? low : 0.0;                                  // strict triangle
-            if ((c * W + e) & 1)
-              p1 = fma(low, vv[c][e], p1);
-            else
-              p0 = fma(low, vv[c][e], p0);
-            acc[c][e] = fma(wr, strict, acc[c][e]);
-          }
-        const double pr = row16_sum(p0 + p1);
-        if (valid[u] && s == 15)
-          out[r[u]] = (c0 == 0) ? pr : out[r[u]] + pr;
-      }
-    }
-    // the column sums of this block meet across the wavefronts; the rows c0 .. c0 + 127 they are added to have all
-    // their row sums by now (columns <= row)
-    const int bw = (n - c0 < 128) ? (n - c0) : 128;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int e = 0; e < W; ++e) {
-        double a = acc[c][e];
-        a += __shfl_xor(a, 16);
-        a += __shfl_xor(a, 32);
-        const int cb = 16 * W * c + W * s + e;
-        if (g == 0 && cb < bw)
-          part[wid * bw + cb] = a;
-      }
-    __syncthreads();
-    for (int j = threadIdx.x; j < bw; j += NT) {
-      double a = part[j];
-#pragma unroll
-      for (int q = 1; q < NW; ++q)
-        a += part[q * bw + j];
-      out[c0 + j] += a;
-    }
-    __syncthreads();
-  }
-}
-
-template<int NT>
-__device__ PQP_CALL void
-symv_lower(cgptr M, int ld, int n, clptr v, lptr out, lptr part)
-{
-  const bool wide = (((ld | n) & 1) == 0) && ((reinterpret_cast<unsigned long long>(M) & 15ull) == 0);
-  if (wide)
-    symv_lower_impl<NT, 2>(M, ld, n, v, out, part);
-  else
-    symv_lower_impl<NT, 1>(M, ld, n, v, out, part);
 }
 
 // ROWS = false: column sums only (v / rowout unused).

@@ -317,19 +317,12 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
 #endif
   if (const char* e = std::getenv("PQP_SCHEDULE"))
     h->lpt = std::string(e) == "lpt";
-  if (const char* e = std::getenv("PQP_SPLIT_SOLVE"))
-    h->split_solve = e[0] == '1';
   h->dev.rep_phase = 0;
   h->dev.rep_count = 1;
   if (const char* e = std::getenv("PQP_REPEAT_PHASE")) // (only the instrumented build reads them: traffic attribution)
     h->dev.rep_phase = std::atoi(e);
   if (const char* e = std::getenv("PQP_REPEAT_COUNT"))
     h->dev.rep_count = std::atoi(e);
-  if (const char* e = std::getenv("PQP_FORCE_NT")) { // experiment hook: a wider workgroup per QP than the shape needs
-    const int f = std::atoi(e);
-    if ((f == 512 || f == 1024) && f > h->nt)
-      h->nt = f;
-  }
   h->lds_solve = pqp::lds_bytes(d, h->nt);
   h->lds_setup = pqp::setup_lds_bytes(d, h->nt);
   // per-QP vector state beyond the 160 KiB of LDS of one CU (e.g. n = 760 with 837 constraint rows): the
@@ -339,12 +332,6 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   const bool vectors_in_hbm = h->lds_solve > 160 * 1024 || (force_hbm && force_hbm[0] == '1');
   if (vectors_in_hbm)
     h->nt = 1024;
-  // PQP_LDS_PAD_BYTES=<n>: experiment hook -- the solve kernel is launched with n more bytes of LDS than it uses, i.e.
-  // with the residency it would have if a matrix of that size lived in LDS beside the vectors (DESIGN.md section 4:
-  // what an LDS-resident H_s would cost in occupancy, measured without writing that kernel)
-  if (const char* e = std::getenv("PQP_LDS_PAD_BYTES"))
-    if (!vectors_in_hbm && std::atol(e) > 0 && h->lds_solve + size_t(std::atol(e)) <= 160 * 1024)
-      h->lds_solve += size_t(std::atol(e));
   const size_t B = size_t(batch_size), n = size_t(dim), ne = size_t(n_eq), ni = size_t(n_in),
                nc = size_t(d.nc), nd = size_t(d.nd);
   pqp::Batch& D = h->dev;

@@ -71,7 +71,6 @@ struct pqp_batch
   pqp_info* m_info = nullptr;
   hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
   hipStream_t owned_stream = nullptr; // pqp_batch_own_stream: a non-blocking stream created for (and destroyed with) the handle
-  bool split_solve = false; // device-filling launches of the C2 kernel run as prepare + iterate kernels (PQP_SPLIT_SOLVE)
   double* vec_scratch = nullptr; // non-null: per-QP vectors live in HBM (B slices of lds_solve bytes), see pqp_kernels.hip TU 9
   long range_first = 0, range_count = 0;
   long setup_first = 0, setup_count = 0; // QPs with a queued init / update / cleanup command

@@ -1,5 +1,5 @@
 // The kernels of libproxqp_hip.so and their launchers.  Compiled once per kernel family
-// (-DPQP_TU=1..8, objects built in parallel by proxsuite_amd/_build.py); PQP_TU undefined or 0
+// (-DPQP_TU=1..9, objects built in parallel by proxsuite_amd/_build.py); PQP_TU undefined or 0
 // compiles everything in one translation unit (the CPU emulator build of tests/emu does that).
 //   1  pqp_solve_kernel<256, 4, 1>    no box constraints, dense Hessian (the C2 kernel): 128 VGPRs per
 //                                     lane, FOUR workgroups per CU -- launches that fill the device
@@ -25,12 +25,12 @@
 #define PQP_GLOBAL __attribute__((address_space(1)))
 #endif
 // 8 instead of 16 matrix loads in flight per lane in gemv for the 128-VGPR kernel (pqp_block.hpp)
-#if (PQP_TU == 1 || PQP_TU == 11) && !defined(PQP_GEMV_DEEP_256)
+#if PQP_TU == 1 && !defined(PQP_GEMV_DEEP_256)
 #define PQP_GEMV_DEEP_256 0
 #endif
 // the translation units whose kernels run at 128 VGPRs per lane keep 4 instead of 8 MFMA k-steps of
 // operand loads in flight in the Z / G build (+2 % at C2 and C4, profiles/r02_ab_compiler_flags.txt)
-#if (PQP_TU == 1 || PQP_TU == 4 || PQP_TU == 8 || PQP_TU == 9 || PQP_TU == 10) && !defined(PQP_ZG_DEPTH)
+#if (PQP_TU == 1 || PQP_TU == 4 || PQP_TU == 8 || PQP_TU == 9) && !defined(PQP_ZG_DEPTH)
 #define PQP_ZG_DEPTH 4
 #endif
 #include "pqp_host.hpp"
@@ -100,49 +100,6 @@ pqp_launch_solve_256_s1(pqp_batch* h)
 }
 #endif
 
-// The C2 solve as TWO kernels (Solver PART 1 / 2, see pqp_solver.hpp): the factorisation prologue, then the
-// iteration.  Same stream, back to back; the batch's events bracket both.
-#ifndef PQP_WPS_256_PREPARE
-#define PQP_WPS_256_PREPARE 4
-#endif
-template<int NT, int WPS, int SPEC, int PART>
-__global__ __launch_bounds__(NT, WPS) void
-pqp_solve_part_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
-{
-  HIP_DYNAMIC_SHARED(double, smem)
-  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
-  pqp::solve_body<NT, SPEC, PART>(batch, first + slot, (pqp::lptr)smem);
-}
-template<int NT, int WPS, int SPEC, int PART>
-static int
-launch_part(pqp_batch* h)
-{
-  if (h->lds_solve > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_part_kernel<NT, WPS, SPEC, PART>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
-  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
-  const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
-  hipLaunchKernelGGL((pqp_solve_part_kernel<NT, WPS, SPEC, PART>), dim3((unsigned)h->range_count), dim3(NT),
-                     h->lds_solve, h->stream, h->dev, h->range_first, order);
-  HIP_TRY(hipGetLastError());
-  return PQP_OK;
-}
-int pqp_launch_prepare_256_s1(pqp_batch* h);
-int pqp_launch_iterate_256_s1(pqp_batch* h);
-#if PQP_TU_HAS(10)
-int
-pqp_launch_prepare_256_s1(pqp_batch* h)
-{
-  return launch_part<256, PQP_WPS_256_PREPARE, 1, 1>(h);
-}
-#endif
-#if PQP_TU_HAS(11)
-int
-pqp_launch_iterate_256_s1(pqp_batch* h)
-{
-  return launch_part<256, PQP_WPS_256_DENSE, 1, 2>(h);
-}
-#endif
 #if PQP_TU_HAS(7)
 int
 pqp_launch_solve_256_s1_lat(pqp_batch* h)
@@ -378,17 +335,8 @@ pqp_launch_solve(pqp_batch* h)
         return pqp_launch_solve_256_s0(h);
       // more workgroups than three per CU can hold at once: the four-per-CU build; otherwise the
       // launch is latency-bound and the build with the larger register budget is faster per QP
-      if (h->range_count > 3L * h->n_cu && 4 * h->lds_solve <= 160 * 1024) {
-        if (!h->split_solve)
-          return pqp_launch_solve_256_s1(h);
-        HIP_TRY(hipEventRecord(h->ev0, h->stream));
-        if (int rc = pqp_launch_prepare_256_s1(h))
-          return rc;
-        if (int rc = pqp_launch_iterate_256_s1(h))
-          return rc;
-        HIP_TRY(hipEventRecord(h->ev1, h->stream));
-        return PQP_OK;
-      }
+      if (h->range_count > 3L * h->n_cu && 4 * h->lds_solve <= 160 * 1024)
+        return pqp_launch_solve_256_s1(h);
       return pqp_launch_solve_256_s1_lat(h);
     case 512:
       // (same rule as for 256 threads: the smaller register budget only when it buys a second resident workgroup)

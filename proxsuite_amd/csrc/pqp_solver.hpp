@@ -47,16 +47,10 @@ constexpr int ZG_DEPTH = PQP_ZG_DEPTH; // MFMA k-steps (of 4) whose operand load
 #ifndef PQP_LS_BRACKET
 #define PQP_LS_BRACKET 1
 #endif
-#ifndef PQP_LS_BRACKET_ALL
-#define PQP_LS_BRACKET_ALL 0
-#endif
 #ifndef PQP_ZG_BLOCK2
 #define PQP_ZG_BLOCK2 1
 #endif
-#ifndef PQP_ZG2_DEPTH
-#define PQP_ZG2_DEPTH 4
-#endif
-constexpr int ZG2_DEPTH = PQP_ZG2_DEPTH;
+constexpr int ZG2_DEPTH = 4; // the same for the 2 x 2 units
 constexpr int SCHUR_MB = 7; // register-resident Schur factorisation up to 16 * SCHUR_MB rows
 // `top`: LDS scratch of the factorisation routines (ldlt_factor_mfma: 2 * 256 + 32 doubles;
 // ldlt_factor_reg: 4 * 16 * MB; ldlt_inverse_reg: 6 * 16 * MB)
@@ -337,38 +331,15 @@ struct Lds
   __device__ __forceinline__ liptr chg() const { return ints(3 * nc + nd + nt / WAVE + 16); }
 };
 
-#ifndef PQP_HESS_LOWER
-#define PQP_HESS_LOWER 0 // 1: 256-thread kernels take H_s v from the lower triangle of H_s only (symv_lower, half the bytes
-                         // of a pass).  Measured SLOWER in round 2 and again in round 3 (profiles/r03_ab_hess_lower.txt: C2 8.32
-                         // -> 8.55 ms, C1 1.33 -> 1.40 ms, 8192 QPs 299 k -> 294 k QPs/s): the triangular rows unbalance the
-                         // wavefronts and the masked FMAs cost more than the 40 KB they save.  Off.
-#endif
-#ifndef PQP_HESS_LOWER_WIDE
-#define PQP_HESS_LOWER_WIDE 0 // the same switch for the 512- / 1024-thread kernels: also slower, although their matrices stream
-                              // from HBM (profiles/r03_ab_hess_lower_wide.txt: C4 -0.7 %, a 512-thread shape -9.5 %).  Off.
-#endif
-__host__ __device__ constexpr bool
-hess_lower(int nt)
-{
-  return nt == 256 ? (PQP_HESS_LOWER != 0) : (PQP_HESS_LOWER_WIDE != 0);
-}
-// One pass over A_s / C_s per product pair (gemv_dual) in the kernels of every width; 0 keeps the gemv pair over
-// the matrix and its transposed copy in the 512- / 1024-thread kernels (A/B switch).
-#ifndef PQP_DUAL_WIDE
-#define PQP_DUAL_WIDE 1
-#endif
-__host__ __device__ constexpr bool
-dual_pass(int nt)
-{
-  return nt == 256 || PQP_DUAL_WIDE;
-}
-
+// (Measured and removed: H_s v from the lower triangle of H_s only -- half the bytes of a pass, slower at every batch
+// size and kernel width, profiles/r03_ab_hess_lower*.txt -- and the gemv pair over A_s / C_s and their transposed
+// copies in the wide kernels, profiles/r03_ab_dual_pass_wide.txt: every kernel takes a product pair from ONE pass.)
 // `part`: cross-wavefront scratch of gemv and of gemv_dual (NW * min(n, 128) doubles)
 __host__ __device__ inline int
 part_doubles(int nt, int tmax, int n)
 {
   const int a = gemv_part_len(nt, tmax);
-  const int b = (dual_pass(nt) || hess_lower(nt)) ? gemv_dual_part_len(nt, n) : 0; // (= symv_lower_part_len)
+  const int b = gemv_dual_part_len(nt, n);
   return a > b ? a : b;
 }
 
@@ -1069,15 +1040,9 @@ schur_gather_blocked(cgptr G, gptr LS, int nd, int rr, int ne, double mu_eq, dou
 // SPEC = 1 compiles the solver for the commonest signature -- no box constraints, dense Hessian --
 // with those two switches as compile-time constants (the box / diagonal / zero-Hessian branches and
 // the scalars that feed them disappear from the hot kernel); SPEC = 0 keeps them at run time.
-// PART splits one solve over two kernels (pqp_kernels.hip: pqp_prepare_kernel / pqp_iterate_kernel):
-//   0  the whole of qp_solve in one kernel;
-//   1  only the model-dependent heavy work of the prologue -- re-application of the equilibration of a dirty
-//      re-solve, factorisation of the primal block, W = L^{-1}, Z and G (everything factor_primal_block leaves
-//      in HBM) -- decided by the same state machine, WITHOUT touching results, Info or the workspace flags;
-//   2  the rest: the same prologue logic with those phases skipped (D of the primal block reloaded from HBM),
-//      then the iteration.  Without the factorisation / matrix-core code inlined beside it, the iteration kernel
-//      spills half as many registers (profiles/r03_kernel_resources.json).
-template<int NT, int SPEC = 0, int PART = 0>
+// (A two-kernel form of the solve -- factorisation prologue / iteration -- was measured in round 3: the iteration kernel
+// alone spills half as many registers and runs at the same speed, profiles/r03_ab_split_solve.txt.  Removed.)
+template<int NT, int SPEC = 0>
 struct Solver
 {
   __device__ __forceinline__ bool has_box() const { return SPEC == 1 ? false : (d.box != 0); }
@@ -1238,20 +1203,16 @@ struct Solver
     const int v = L.act()[k < 0 ? 0 : k];
     return (k < 0) ? a : d.n_eq + v;
   }
-  // out = H_s v for the dense H_s (PQP_HESS_LOWER selects the triangle-only pass, see above)
+  // out = H_s v for the dense H_s
   // elements of H_s one hess_mv pass reads (engine byte counter)
   __device__ __forceinline__ long hess_pass_elems() const
   {
-    return hess_lower(NT) ? (long)d.n * (d.n + 1) / 2 : (long)d.n * d.n;
+    return (long)d.n * d.n;
   }
   __device__ __forceinline__ void hess_mv(clptr v, lptr out)
   {
-    if constexpr (hess_lower(NT)) // the lower triangle of the symmetric H_s only: half the bytes of a pass
-      symv_lower<NT>(P.Hs(), d.n, d.n, v, out, L.part());
-    else if constexpr (dual_pass(NT)) // column sums of the symmetric H_s = H_s v, with 16-byte loads
-      gemv_dual<NT, true, false, false>(P.Hs(), d.n, d.n, d.n, v, v, out, out, L.part());
-    else
-      mv(P.Hs(), d.n, d.n, d.n, v, out);
+    // column sums of the symmetric H_s = H_s v, with 16-byte loads
+    gemv_dual<NT, true, false, false>(P.Hs(), d.n, d.n, d.n, v, v, out, out, L.part());
   }
   // plain mat-vec through the shared routine
   __device__ __forceinline__ void mv(cgptr M, int ld, int K, int J, clptr v, lptr out)
@@ -2306,16 +2267,9 @@ struct Solver
       schur_apply(bd);
       toc(ST_CYC_SOLVE_LDLT);
       // t <- (t - sum_a z_a dvec_a) / D     (gather of the active rows of Zr)
-      if constexpr (dual_pass(NT)) {
-        // t1 <- (t1 - Z_J^T dvec) / D in the epilogue of the column sums
-        gemv_dual<NT, true, true, false>(P.Zr(), n, rr, n, bd, bd, L.t1(), L.t1(), L.part(), L.act(), d.n_eq,
-                                         EPI_COL_SUBDIV, L.t1(), L.dF());
-      } else {
-        gemv<NT>(P.Zr(), n, rr, n, bd, L.t2(), L.part(), L.act(), d.n_eq, nullptr, 0);
-        for (int k = threadIdx.x; k < n; k += NT)
-          L.t1()[k] = (L.t1()[k] - L.t2()[k]) / L.dF()[k];
-        __syncthreads();
-      }
+      // t1 <- (t1 - Z_J^T dvec) / D in the epilogue of the column sums
+      gemv_dual<NT, true, true, false>(P.Zr(), n, rr, n, bd, bd, L.t1(), L.t1(), L.part(), L.act(), d.n_eq,
+                                       EPI_COL_SUBDIV, L.t1(), L.dF());
     } else {
       vcopy(L.t1(), L.t2(), n);
       __syncthreads();
@@ -2342,13 +2296,8 @@ struct Solver
         L.Hdx()[k] = (hess() == PQP_HESSIAN_DIAGONAL) ? (dm() ? hd[k] : Hs[(long)k * n + k]) * L.dx()[k] : 0.0;
     }
     if (ne > 0) {
-      if constexpr (dual_pass(NT)) {
-        // A is read ONCE: row sums give A dx, column sums A^T dy
-        gemv_dual<NT>(P.As(), n, ne, n, L.dx(), L.sd(), L.Adx(), L.ATdy(), L.part());
-      } else {
-        mv(P.As(), n, ne, n, L.sd(), L.ATdy());
-        mv(P.ATs(), ne, n, ne, L.dx(), L.Adx());
-      }
+      // A is read ONCE: row sums give A dx, column sums A^T dy
+      gemv_dual<NT>(P.As(), n, ne, n, L.dx(), L.sd(), L.Adx(), L.ATdy(), L.part());
     } else {
       vzero(L.ATdy(), n);
     }
@@ -2360,12 +2309,7 @@ struct Solver
         L.CTdz()[k] = ck * L.zfull()[k];
       }
     } else if (ni > 0) {
-      if constexpr (dual_pass(NT)) {
-        gemv_dual<NT>(P.Cs(), n, ni, n, L.dx(), L.zfull(), L.Cdx(), L.CTdz(), L.part());
-      } else {
-        mv(P.Cs(), n, ni, n, L.zfull(), L.CTdz());
-        mv(P.CTs(), ni, n, ni, L.dx(), L.Cdx());
-      }
+      gemv_dual<NT>(P.Cs(), n, ni, n, L.dx(), L.zfull(), L.Cdx(), L.CTdz(), L.part());
     } else {
       vzero(L.CTdz(), n);
     }
@@ -2400,7 +2344,7 @@ struct Solver
     const double nrm = R.max(m);
     zero_holes(L.ed());
     {
-      const long mats = dual_pass(NT) ? 1 : 2; // one pass over A_s / C_s, or A_s and its transpose
+      const long mats = 1; // one pass over A_s / C_s
       bytes((((hess() == PQP_HESSIAN_DENSE) ? hess_pass_elems() : (long)n) +
              (dm() ? (long)ni : mats * ((long)ne * n + (long)ni * n))) * 8);
     }
@@ -2658,7 +2602,7 @@ struct Solver
       vzero(L.CTdz(), n);
       aty_fresh = true;
       __syncthreads();
-    } else if constexpr (dual_pass(NT)) {
+    } else {
       // one pass over A_s and C_s: the row sums are A x / C x; the column sums A^T y / C^T z are
       // what global_dual_residual needs at this same iterate, parked in the Newton by-product
       // vectors (idle between Newton loops) and flagged by `aty_fresh`
@@ -2671,11 +2615,6 @@ struct Solver
       else
         vzero(L.CTdz(), n);
       aty_fresh = true;
-    } else {
-      if (ne > 0)
-        mv(P.ATs(), ne, n, ne, L.x(), L.se());
-      if (ni > 0)
-        mv(P.CTs(), ni, n, ni, L.x(), L.rup());
     }
     {
       cgptr de = P.dlt_eq();
@@ -3313,10 +3252,10 @@ struct Solver
     // evaluations, then evaluate -- in the reference's order, bit for bit as below -- only the handful of breakpoints
     // around it.  Any doubt (an evaluation too close to zero to trust its sign, too many breakpoints left in the bracket,
     // an exact value that contradicts the bracket) falls back to the full evaluation.
-    // (the kernels that serve such shapes; the kernel of the common signature -- C2 -- stays as it is.  PQP_LS_BRACKET_ALL=1
-    // compiles the bracket into every kernel and takes it from 64 constraints on: -6.7 % at C2, profiles/r03_ab_linesearch_bracket.txt)
-    if constexpr (PQP_LS_BRACKET && ((SPEC == 0 && NT == 256) || PQP_LS_BRACKET_ALL))
-    if ((2 * nc > NT || (PQP_LS_BRACKET_ALL && nc >= 64)) && nc <= NT) { // (its per-thread lists hold two breakpoints)
+    // (the kernels that serve such shapes; in the kernel of the common signature -- C2, 200 breakpoints on 256 threads -- the bracket
+    // is 6.7 % SLOWER than one pass with every breakpoint on its own thread: profiles/r03_ab_linesearch_bracket.txt)
+    if constexpr (PQP_LS_BRACKET && SPEC == 0 && NT == 256)
+    if (2 * nc > NT && nc <= NT) { // (its per-thread lists hold two breakpoints)
       double alpha_b;
       sub_tic(ST_CYC_LS_EVAL);
       const bool ok = ls_bracket(a0, b0, alpha_b);
@@ -3935,7 +3874,7 @@ struct Solver
       }
     }
     __syncthreads();
-    if (PART != 2 && do_rescale) {
+    if (do_rescale) {
       // re-apply the stored equilibration (solver.hpp:1192-1214); u, l unclamped
       tic();
       lptr S = L.rd(); // scratch of ntot doubles: rd, ed, sd, dS, t2 (4 nd + max(n, nd)) are free here
@@ -3966,13 +3905,8 @@ struct Solver
         L.stat()[ST_CYC_FACTOR_H] -= clock64();
 #endif
       tic();
-      if constexpr (PART != 2) {
-        for (int rp = 0; rp < reps(6); ++rp)
-          factor_primal_block();
-      } else {
-        vload(L.dF(), P.dF(), n); // (the prepare kernel of this launch left F, W, Z, G and D in HBM)
-        __syncthreads();
-      }
+      for (int rp = 0; rp < reps(6); ++rp)
+        factor_primal_block();
 #ifdef PQP_STATS
       if (threadIdx.x == 0)
         L.stat()[ST_CYC_FACTOR_H] += clock64();
@@ -3983,8 +3917,6 @@ struct Solver
       r = ne;
       schur_dirty = true;
     }
-    if constexpr (PART == 1)
-      return; // prepare kernel: nothing of the QP's state (results, Info, flags) has been written
     if (do_restore) {
       // WARM_START_WITH_PREVIOUS_RESULT on an unchanged model: reuse the block
       // factorisation the previous solve left in HBM (solver.hpp:1173-1187, 1343-1375)
@@ -4563,11 +4495,11 @@ backward_body(const Batch& batch, const BackwardArgs& bw, long slot, lptr lds_ba
   S.backward(bw, slot);
 }
 
-template<int NT, int SPEC, int PART = 0>
+template<int NT, int SPEC>
 __device__ __forceinline__ void
 solve_body(const Batch& batch, long q, lptr lds_base)
 {
-  Solver<NT, SPEC, PART> S(batch, q, lds_base);
+  Solver<NT, SPEC> S(batch, q, lds_base);
   S.solve();
 }
 

@@ -224,12 +224,3 @@ def test_line_search_bracket_is_bit_identical_to_the_full_evaluation(randqp):
         assert a[3] == f[3], (n, ne, ni, box, hess, merit, a[3], f[3])
         for u, v in zip(a[:3], f[:3]):
             assert np.array_equal(u, v), (n, ne, ni, box, hess, merit, float(np.max(np.abs(u - v))))
-    # the same claim for the switch that takes the bracket in EVERY kernel (PQP_LS_BRACKET_ALL=1, off in the product: 6.7 %
-    # slower at C2): a C2-like shape of the common signature and a 512-thread shape
-    every = N.NativeLib(emu_build.build_variant("bracketall", ["PQP_LS_BRACKET_ALL=1"]))
-    for (n, ne, ni, box, hess, merit, seed) in [(80, 20, 90, False, 1, 0, 6), (40, 5, 300, False, 1, 0, 7)]:
-        a = run(every, n, ne, ni, box, hess, merit, seed)
-        f = run(full, n, ne, ni, box, hess, merit, seed)
-        assert a[3] == f[3], (n, ne, ni, a[3], f[3])
-        for u, v in zip(a[:3], f[:3]):
-            assert np.array_equal(u, v), (n, ne, ni, float(np.max(np.abs(u - v))))
