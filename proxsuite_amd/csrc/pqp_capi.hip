@@ -406,6 +406,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     pqp_settings_default(&s, h->backend);
   h->cmd.assign(B, pqp::Cmd{});
   h->is_initialized.assign(B, 0);
+  h->c_diag.assign(B, 0);
   {
     std::vector<pqp_info> info(B);
     for (auto& i : info)
@@ -602,6 +603,7 @@ pqp_batch_reset_qp(pqp_batch* h, int64_t idx)
   h->settings_uploaded.clear(); // (the slice of d_settings was zeroed above: force a re-upload)
   h->cmd[q] = pqp::Cmd{};
   h->is_initialized[q] = 0;
+  h->c_diag[q] = 0;
   h->order_valid = false;
   return PQP_OK;
 }
@@ -646,6 +648,16 @@ pqp_batch_flush(pqp_batch* h)
     if (int rc = pqp_launch_setup(h))
       return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    {
+      const pqp::Dims& dd = h->dev.d;
+      if (h->nt == 256 && pqp::diag_structure_signature(dd.hessian, dd.n_eq, dd.n_in, dd.box)) {
+        // which QPs have diagonal structure (decided by the kernel that just ran, from the model's data)
+        std::vector<pqp::State> stt(hi - lo);
+        HIP_TRY(hipMemcpy(stt.data(), h->dev.state + lo, (hi - lo) * sizeof(pqp::State), hipMemcpyDeviceToHost));
+        for (size_t q = lo; q < hi; ++q)
+          h->c_diag[q] = stt[q - lo].c_diag != 0;
+      }
+    }
     if (stale) // back to the live settings for the solve
       HIP_TRY(hipMemcpy(h->d_settings + lo, h->settings.data() + lo, (hi - lo) * sizeof(pqp_settings),
                         hipMemcpyHostToDevice));
@@ -1018,6 +1030,7 @@ pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_i
   }
   dst->settings[size_t(dst_idx)] = src->settings[size_t(src_idx)];
   dst->is_initialized[size_t(dst_idx)] = src->is_initialized[size_t(src_idx)];
+  dst->c_diag[size_t(dst_idx)] = src->c_diag[size_t(src_idx)];
   dst->settings_dirty = true;
   dst->settings_uploaded.clear(); // (d_settings was overwritten by the array copy: force a re-upload)
   return PQP_OK;

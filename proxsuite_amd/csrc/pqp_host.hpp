@@ -47,6 +47,9 @@ struct pqp_batch
   std::vector<pqp_settings> cmd_settings;
   std::vector<pqp::Cmd> cmd;
   std::vector<char> is_initialized;
+  // State::c_diag of every QP as the last set-up kernel left it (read back in pqp_batch_flush for signatures that can
+  // have diagonal structure): a launch whose QPs ALL have the structure runs the dedicated kernel (pqp_launch_solve)
+  std::vector<char> c_diag;
   bool settings_dirty = true;
   bool cmd_pending = false;
   pqp_settings* d_settings = nullptr;

@@ -14,6 +14,8 @@
 #ifndef PQP_TU
 #define PQP_TU 0
 #endif
+//  12  pqp_solve_kernel<256, 3, 2>    the diagonal-structure solver alone (H diagonal / zero, no equality, every inequality
+//                                     row on one variable: BASELINE.json configs[4]): launches whose QPs ALL have it
 //   9  pqp_solve_hbm_kernel<1024, .>  shapes whose per-QP vectors exceed the CU's 160 KiB of LDS: the
 //                                     SAME solver with its "LDS" pointers typed as global memory and
 //                                     carved out of a per-workgroup slice of an HBM scratch buffer (the
@@ -87,6 +89,7 @@ launch_solve(pqp_batch* h)
 int pqp_launch_solve_256_s1(pqp_batch* h);
 int pqp_launch_solve_256_s1_lat(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
+int pqp_launch_solve_256_s2(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
@@ -112,6 +115,16 @@ int
 pqp_launch_solve_256_s0(pqp_batch* h)
 {
   return launch_solve<256, PQP_WPS_256, 0>(h);
+}
+#endif
+#ifndef PQP_WPS_256_DIAG
+#define PQP_WPS_256_DIAG 2 // (two workgroups per CU at 256 VGPRs: 4.08 ms per 4096 C5 QPs against 4.29 ms with three at 168, profiles/r04_ab_diag_kernel.txt)
+#endif
+#if PQP_TU_HAS(12)
+int
+pqp_launch_solve_256_s2(pqp_batch* h)
+{
+  return launch_solve<256, PQP_WPS_256_DIAG, 2>(h);
 }
 #endif
 #if PQP_TU_HAS(3)
@@ -331,8 +344,14 @@ pqp_launch_solve(pqp_batch* h)
     return pqp_launch_solve_hbm(h, common);
   switch (h->nt) {
     case 256:
-      if (!common)
-        return pqp_launch_solve_256_s0(h);
+      if (!common) {
+        // every QP of the batch in diagonal structure (signature + the flags the set-up kernel left): the dedicated kernel
+        const pqp::Dims& dd = h->dev.d;
+        bool all_diag = pqp::diag_structure_signature(dd.hessian, dd.n_eq, dd.n_in, dd.box) && !h->c_diag.empty();
+        for (size_t q = 0; all_diag && q < h->c_diag.size(); ++q)
+          all_diag = h->c_diag[q] != 0;
+        return all_diag ? pqp_launch_solve_256_s2(h) : pqp_launch_solve_256_s0(h);
+      }
       // more workgroups than three per CU can hold at once: the four-per-CU build; otherwise the
       // launch is latency-bound and the build with the larger register budget is faster per QP
       if (h->range_count > 3L * h->n_cu && 4 * h->lds_solve <= 160 * 1024)

@@ -106,6 +106,13 @@ act_flags(int packed)
   return (packed >> 16) & 3;
 }
 
+// signature part of the diagonal-structure test (Solver::dm; the per-QP part is State::c_diag, set by the set-up kernel)
+__host__ __device__ inline bool
+diag_structure_signature(int hessian, int n_eq, int n_in, int box)
+{
+  return hessian != PQP_HESSIAN_DENSE && n_eq == 0 && !(n_in > 0 && box != 0);
+}
+
 struct Dims
 {
   int n, n_eq, n_in; // problem sizes
@@ -1040,13 +1047,24 @@ schur_gather_blocked(cgptr G, gptr LS, int nd, int rr, int ne, double mu_eq, dou
 // SPEC = 1 compiles the solver for the commonest signature -- no box constraints, dense Hessian --
 // with those two switches as compile-time constants (the box / diagonal / zero-Hessian branches and
 // the scalars that feed them disappear from the hot kernel); SPEC = 0 keeps them at run time.
+// SPEC = 2 is the diagonal-structure solver on its own (every QP of the launch has the structure `dm()` describes: the
+// host checks the flags the set-up kernel left, pqp_launch_solve): no dense matrix code, no factorisation code, no
+// PrimalLDLT engine in the kernel -- BASELINE.json configs[4] ("bandwidth-bound, no MFMA") gets a kernel that is
+// nothing but its element-wise path, whose registers no longer depend on what the general kernel has to hold.
 // (A two-kernel form of the solve -- factorisation prologue / iteration -- was measured in round 3: the iteration kernel
 // alone spills half as many registers and runs at the same speed, profiles/r03_ab_split_solve.txt.  Removed.)
 template<int NT, int SPEC = 0>
 struct Solver
 {
   __device__ __forceinline__ bool has_box() const { return SPEC == 1 ? false : (d.box != 0); }
-  __device__ __forceinline__ int hess() const { return SPEC == 1 ? (int)PQP_HESSIAN_DENSE : d.hessian; }
+  __device__ __forceinline__ int hess() const
+  {
+    if (SPEC == 1)
+      return (int)PQP_HESSIAN_DENSE;
+    if (SPEC == 2) // (never dense in diagonal structure)
+      return d.hessian == PQP_HESSIAN_ZERO ? (int)PQP_HESSIAN_ZERO : (int)PQP_HESSIAN_DIAGONAL;
+    return d.hessian;
+  }
   const Batch& batch;
   const long q;
   const Dims d;
@@ -1066,7 +1084,7 @@ struct Solver
   // diagonals: hd = diag(H_s) in the F buffer, cd = diag(C_s) in the C_s^T buffer, zd / gd (entry of
   // Z and of G per constraint) at the start of the Zr / G buffers.
   bool diag_mode;
-  __device__ __forceinline__ bool dm() const { return SPEC == 1 ? false : diag_mode; }
+  __device__ __forceinline__ bool dm() const { return SPEC == 1 ? false : (SPEC == 2 ? true : diag_mode); }
   // DenseBackend::PrimalLDLT (reference dense/solver.hpp:88-109, 171-227, 336-388; chosen by
   // dense_backend_choice when n_eq + n_c is large against dim): the DUAL block of the KKT matrix is
   // eliminated instead of the primal one,
@@ -1076,7 +1094,7 @@ struct Solver
   // same inverse-factor form as the dual Schur block of the default engine (W = L^{-1} in the WL
   // buffer, D in L.dF): two chain-free mat-vecs per solve; an active-set change or a mu update
   // re-assembles P_J on the matrix cores (syrk_mfma) and re-factorises it.
-  __device__ __forceinline__ bool pm() const { return SPEC == 1 ? false : (d.backend == PQP_BACKEND_PRIMAL_LDLT && !diag_mode); }
+  __device__ __forceinline__ bool pm() const { return SPEC != 0 ? false : (d.backend == PQP_BACKEND_PRIMAL_LDLT && !diag_mode); }
   __device__ __forceinline__ int dcol(int cid) const { return (cid < d.n_in) ? cid : cid - d.n_in; } // variable of constraint cid
   bool schur_dirty;       // the factor does not describe (active set, mu): re-factorise
   bool schur_incremental; // rows were appended / deleted since the last full factorisation
@@ -1107,8 +1125,8 @@ struct Solver
   }
   __device__ __forceinline__ void set_diag_mode(const State& W)
   {
-    diag_mode = (SPEC == 0) && d.hessian != PQP_HESSIAN_DENSE && d.n_eq == 0 && W.c_diag != 0 &&
-                !(d.n_in > 0 && d.box != 0);
+    diag_mode = (SPEC == 2) || ((SPEC == 0) && d.hessian != PQP_HESSIAN_DENSE && d.n_eq == 0 && W.c_diag != 0 &&
+                                !(d.n_in > 0 && d.box != 0));
   }
 
   // phase timers / event counters: thread 0 only, accumulated in LDS
@@ -3254,7 +3272,7 @@ struct Solver
     // an exact value that contradicts the bracket) falls back to the full evaluation.
     // (the kernels that serve such shapes; in the kernel of the common signature -- C2, 200 breakpoints on 256 threads -- the bracket
     // is 6.7 % SLOWER than one pass with every breakpoint on its own thread: profiles/r03_ab_linesearch_bracket.txt)
-    if constexpr (PQP_LS_BRACKET && SPEC == 0 && NT == 256)
+    if constexpr (PQP_LS_BRACKET && SPEC != 1 && NT == 256)
     if (2 * nc > NT && nc <= NT) { // (its per-thread lists hold two breakpoints)
       double alpha_b;
       sub_tic(ST_CYC_LS_EVAL);

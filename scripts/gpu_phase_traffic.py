@@ -2,7 +2,7 @@
 PQP_REPEAT_PHASE=<k> PQP_REPEAT_COUNT=2 under `rocprofv3 --pmc FETCH_SIZE` (or WRITE_SIZE) and compare with the
 plain run.  This script is the workload under the profiler: B QPs of the C2 shape, `reps` solves, and one JSON line
 with the engine-byte and event counters of the last solve (so that traffic delta / engine-byte delta is per phase).
-  python scripts/gpu_phase_traffic.py <libproxqp_hip_stats.so> [B] [reps]"""
+  python scripts/gpu_phase_traffic.py <libproxqp_hip_stats.so> [B] [reps]        (PQP_SHAPE=n,n_eq,n_in: another shape than C2's)"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ from proxsuite_amd.utils import random_qp as R
 lib = N.NativeLib(sys.argv[1])
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-n, ne, ni = 100, 50, 100
+n, ne, ni = (int(v) for v in os.environ.get("PQP_SHAPE", "100,50,100").split(","))
 m = R.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2, seed0=0)
 b = N.Batch(B, n, ne, ni, lib=lib)
 for i in range(B):

@@ -37,7 +37,7 @@ for ph in range(7):
         rec["traffic_over_engine"] = rec["delta_traffic"] / rec["delta_engine"] if rec["delta_engine"] else None
         rec["same_iterates"] = rec["iter_sum"] == base["iter_sum"]
     out[ph] = rec
-json.dump(out, open('%s/r04_pmc_c2_waste_by_phase.json' % O, 'w'), indent=1)
+json.dump(out, open('%s/waste_by_phase.json' % O, 'w'), indent=1)
 if base:
     print("plain: traffic %.2f MB/QP (read %.2f, write %.2f), engine %.2f MB/QP, ratio %.3f" % (
         base["traffic_per_qp"] / 1e6, base["read_bytes_per_qp"] / 1e6, base["write_bytes_per_qp"] / 1e6,
