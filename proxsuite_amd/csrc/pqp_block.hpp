@@ -1581,6 +1581,129 @@ tri_inverse_mfma_rows(cgptr F, int ld, int n, gptr WL, gptr WU)
 }
 
 // ---------------------------------------------------------------------------
+// LDS-tiled GEMMs of the Z / G build (Solver::build_ZG): the workgroup computes one TM x TN block of the result at a
+// time, every wavefront a 32 x 32 sub-block (2 x 2 MFMA tiles), and the operand rows of a slab of KS = 16 steps of the
+// reduction index are staged ONCE per block through LDS for all wavefronts -- the per-wavefront form (each wavefront
+// streaming its own operand panels from L2 / HBM) re-read every operand byte about twenty times at C4 and seven at C2
+// (profiles/r04_pmc_c4_waste_by_phase.txt: 139 MB of traffic for 20 MB of operands).  The next slab travels in
+// registers while the current one is multiplied (one staging buffer in LDS).  Both operands are "reduction-major":
+// element (j, i) of an operand is row j of a row-major matrix, so the staging loads are coalesced.
+//   NT = 256: 2 x 2 wavefronts, TM = TN = 64;   512: 2 x 4, TM = 64, TN = 128;   1024: 4 x 4, TM = TN = 128.
+// Accumulation order = ascending reduction index, four per MFMA, exactly as in the per-wavefront form: the results
+// are the same bits (terms that were skipped there are exact zeros here).
+// `stage`: zg_stage_doubles(NT) doubles of LDS.
+// ---------------------------------------------------------------------------
+constexpr int ZG_KS = 16; // reduction steps per slab
+template<int NT>
+struct ZgTile
+{
+  static constexpr int NWV = NT / WAVE;
+  static constexpr int WR = (NWV == 16) ? 4 : 2; // wavefront grid
+  static constexpr int WC = NWV / WR;
+  static constexpr int TM = 32 * WR, TN = 32 * WC;
+  static constexpr int TMP = TM + 8, TNP = TN + 8; // padded row strides (doubles) of the staged slabs
+  static constexpr int SLAB = ZG_KS * (TMP + TNP);
+  static constexpr int SCRATCH = NWV * 16 * 17; // per-wavefront 16 x 16 transposition tiles (stride 17)
+  static constexpr int STAGE = SLAB > SCRATCH ? SLAB : SCRATCH;
+  static constexpr int PER_A = (ZG_KS * TM + NT - 1) / NT; // staged elements per thread and operand
+  static constexpr int PER_B = (ZG_KS * TN + NT - 1) / NT;
+};
+__host__ __device__ inline int
+zg_stage_doubles(int nt)
+{
+  return nt == 256 ? ZgTile<256>::STAGE : (nt == 512 ? ZgTile<512>::STAGE : ZgTile<1024>::STAGE);
+}
+
+// one workgroup block: acc[h][g] += sum_j A(j, R0 + ...) B(j, C0 + ...) over j in [0, jend); the loaders return the
+// operand element (j, i) or 0 outside the matrix.  Leaves the 2 x 2 tiles of this wavefront in acc.
+template<int NT, typename LoadA, typename LoadB>
+__device__ __forceinline__ void
+zg_block(LoadA loadA, LoadB loadB, int R0, int C0, int jend, lptr stage, pqp_d4 (&acc)[2][2])
+{
+  using T = ZgTile<NT>;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int wr = w / T::WC, wc = w - wr * T::WC;
+  lptr As = stage, Bs = stage + ZG_KS * T::TMP;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      acc[h][g] = pqp_d4{ 0.0, 0.0, 0.0, 0.0 };
+  double ra[T::PER_A], rb[T::PER_B];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < T::PER_A; ++i) {
+      const int e = threadIdx.x + i * NT;
+      const int jj = e / T::TM, kk = e - jj * T::TM;
+      ra[i] = (e < ZG_KS * T::TM && j0 + jj < jend) ? loadA(j0 + jj, R0 + kk) : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < T::PER_B; ++i) {
+      const int e = threadIdx.x + i * NT;
+      const int jj = e / T::TN, cc = e - jj * T::TN;
+      rb[i] = (e < ZG_KS * T::TN && j0 + jj < jend) ? loadB(j0 + jj, C0 + cc) : 0.0;
+    }
+  };
+  fetch(0);
+  for (int j0 = 0; j0 < jend; j0 += ZG_KS) {
+    __syncthreads(); // the previous slab has been consumed by every wavefront
+#pragma unroll
+    for (int i = 0; i < T::PER_A; ++i) {
+      const int e = threadIdx.x + i * NT;
+      const int jj = e / T::TM, kk = e - jj * T::TM;
+      if (e < ZG_KS * T::TM)
+        As[jj * T::TMP + kk] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < T::PER_B; ++i) {
+      const int e = threadIdx.x + i * NT;
+      const int jj = e / T::TN, cc = e - jj * T::TN;
+      if (e < ZG_KS * T::TN)
+        Bs[jj * T::TNP + cc] = rb[i];
+    }
+    __syncthreads();
+    if (j0 + ZG_KS < jend)
+      fetch(j0 + ZG_KS); // in flight while this slab is multiplied
+#pragma unroll
+    for (int q = 0; q < ZG_KS / 4; ++q) {
+      double a[2], b[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        a[h] = As[(4 * q + lk) * T::TMP + wr * 32 + h * 16 + lr];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        b[g] = Bs[(4 * q + lk) * T::TNP + wc * 32 + g * 16 + lr];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          acc[h][g] = mfma_f64_16x16x4(a[h], b[g], acc[h][g]);
+    }
+  }
+  __syncthreads(); // the staging buffer is free again (the callers transpose through it)
+}
+
+// transposed copy of one 16 x 16 MFMA result tile through this wavefront's own LDS tile: returns t with
+// t[r] = element (row = lr, column = lk + 4 r) of the tile whose lane layout is  acc[r] = element (lk + 4 r, lr)
+__device__ __forceinline__ pqp_d4
+zg_transpose(const pqp_d4& acc, lptr sc)
+{
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int lr = lane & 15, lk = lane >> 4;
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    sc[(lk + 4 * r) * 17 + lr] = acc[r];
+  wave_sync();
+  pqp_d4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    t[r] = sc[lr * 17 + lk + 4 * r];
+  return t;
+}
+
+// ---------------------------------------------------------------------------
 // Symmetric rank-K accumulation on the FP64 matrix cores:
 //     out[i][j] = base[i][j] + alpha * sum_{k < K} M[row(k)][i] * M[row(k)][j]        i, j < m
 // M row-major (leading dimension ldm), rows optionally gathered through `rowmap` (LDS; row(k) =

@@ -23,6 +23,7 @@
 //                                     does LDS ones).  Slow per QP -- every vector access is an L1/L2 round
 //                                     trip -- but it removes the size ceiling below 1024 rows.
 #if PQP_TU == 9
+#define PQP_VECTORS_IN_HBM 1
 #define PQP_LDS __attribute__((address_space(1)))
 #define PQP_GLOBAL __attribute__((address_space(1)))
 #endif

@@ -262,8 +262,19 @@ struct BackwardArgs
 // whole layout and each pointer is rebuilt where it is used (two scalar instructions behind an
 // optimisation barrier).  Holding 45 hoisted pointers instead overflowed the scalar register
 // file: a fifth of the kernel's instructions were v_readlane reloads of spilled scalars.
+// The Z / G build of the 512- / 1024-thread kernels runs LDS-tiled (build_ZG); those kernels order their per-QP vectors and
+// their prologue for it.  The 256-thread kernels keep the layout and the prologue of rounds 1-3 (their per-wavefront Z / G
+// build is faster for their small, L2-resident operands, and a C1-size launch is sensitive to every instruction of the
+// prologue: profiles/r04_ab_zg_lds_tiled.txt).
+#ifndef PQP_VECTORS_IN_HBM
+#define PQP_VECTORS_IN_HBM 0 // 1 in the translation unit of pqp_solve_hbm_kernel: its "LDS" is an HBM slice, staging through it gains nothing
+#endif
+#define ZG_LDS_TILED(nt) ((nt) >= 512 && !PQP_VECTORS_IN_HBM)
+template<int NT>
 struct Lds
 {
+  static constexpr int SH = ZG_LDS_TILED(NT) ? 2 : 0;   // dF, t1 in front of the other n-vectors ...
+  static constexpr int DF = ZG_LDS_TILED(NT) ? 0 : 14;  // ... or behind them
   lptr base;
   int n, ne, nc, ni, nd, tmax, nt, plen;
   int o_ne, o_nc, o_ni, o_nd, o_t2; // class offsets in doubles (class n starts at 0)
@@ -276,22 +287,25 @@ struct Lds
   }
 #define PQP_LVEC(name, cls_off, len, slot) \
   __device__ __forceinline__ lptr name() const { return at((cls_off) + (slot) * (len)); }
-  PQP_LVEC(x, 0, n, 0)
-  PQP_LVEC(xp, 0, n, 1)
-  PQP_LVEC(gs, 0, n, 2)
-  PQP_LVEC(ubs, 0, n, 3)
-  PQP_LVEC(lbs, 0, n, 4)
-  PQP_LVEC(isc, 0, n, 5)
-  PQP_LVEC(dx, 0, n, 6)
-  PQP_LVEC(rx, 0, n, 7)
-  PQP_LVEC(ex, 0, n, 8)
-  PQP_LVEC(Hdx, 0, n, 9)
-  PQP_LVEC(ATdy, 0, n, 10)
-  PQP_LVEC(CTdz, 0, n, 11)
-  PQP_LVEC(CTzin, 0, n, 12)
-  PQP_LVEC(dres, 0, n, 13)
-  PQP_LVEC(dF, 0, n, 14)
-  PQP_LVEC(t1, 0, n, 15)
+  // (dF and t1 first: the factorisation of the primal block and the Z / G build own them, and everything behind
+  // them up to the end of `part` -- every other per-QP vector, none of which is loaded before that prologue has run
+  // -- is the staging area of the LDS-tiled GEMMs: stage())
+  PQP_LVEC(dF, 0, n, DF)
+  PQP_LVEC(t1, 0, n, DF + 1)
+  PQP_LVEC(x, 0, n, SH + 0)
+  PQP_LVEC(xp, 0, n, SH + 1)
+  PQP_LVEC(gs, 0, n, SH + 2)
+  PQP_LVEC(ubs, 0, n, SH + 3)
+  PQP_LVEC(lbs, 0, n, SH + 4)
+  PQP_LVEC(isc, 0, n, SH + 5)
+  PQP_LVEC(dx, 0, n, SH + 6)
+  PQP_LVEC(rx, 0, n, SH + 7)
+  PQP_LVEC(ex, 0, n, SH + 8)
+  PQP_LVEC(Hdx, 0, n, SH + 9)
+  PQP_LVEC(ATdy, 0, n, SH + 10)
+  PQP_LVEC(CTdz, 0, n, SH + 11)
+  PQP_LVEC(CTzin, 0, n, SH + 12)
+  PQP_LVEC(dres, 0, n, SH + 13)
   PQP_LVEC(y, o_ne, ne, 0)
   PQP_LVEC(yp, o_ne, ne, 1)
   PQP_LVEC(bs, o_ne, ne, 2)
@@ -312,6 +326,7 @@ struct Lds
   PQP_LVEC(sd, o_nd, nd, 2)
   PQP_LVEC(dS, o_nd, nd, 3)
 #undef PQP_LVEC
+  __device__ __forceinline__ lptr stage() const { return at(2 * n); } // (tiled layouts only) zg_stage_doubles(nt) doubles, see lds_part_len
   __device__ __forceinline__ int part_len() const { return plen; }
   __device__ __forceinline__ int red_len() const { return 2 * RED_VALS * (nt / WAVE) + 8; }
   __device__ __forceinline__ lptr t2() const { return at(o_t2); }
@@ -350,6 +365,18 @@ part_doubles(int nt, int tmax, int n)
   return a > b ? a : b;
 }
 
+// length of `part`: what gemv / gemv_dual need, padded so that the staging area of the Z / G build (from behind t1 to
+// the end of `part`) holds zg_stage_doubles(nt) doubles whatever the problem sizes
+__host__ __device__ inline int
+lds_part_len(int n, int ne, int nc, int ni, int nd, int nt)
+{
+  const int tmax = nd > n ? nd : n;
+  const int need = part_doubles(nt, tmax, n);
+  const int behind_t1 = 14 * n + 6 * ne + 7 * nc + 2 * ni + 4 * nd + tmax; // ... up to the start of `part`
+  const int pad = ZG_LDS_TILED(nt) ? zg_stage_doubles(nt) - behind_t1 : 0;
+  return need > pad ? need : pad;
+}
+
 __host__ __device__ inline size_t
 lds_doubles(const Dims& d, int nt)
 {
@@ -365,7 +392,7 @@ lds_doubles(const Dims& d, int nt)
   s += n + ne + 2 * nc;                  // dres se si rup
   s += n + nd;                           // dF dS
   s += n + tmax + nc;                    // t1 t2 zfull
-  s += part_doubles(nt, (int)tmax, (int)n); // part
+  s += lds_part_len(d.n, d.n_eq, d.nc, d.n_in, d.nd, nt); // part
   s += 2 * RED_VALS * (nt / WAVE) + 8;   // red
   s += TOP_DOUBLES;                      // top
   s += PARK_DOUBLES;                     // outer-loop scalars parked during the Newton loop
@@ -379,8 +406,9 @@ lds_bytes(const Dims& d, int nt)
   return lds_doubles(d, nt) * sizeof(double) + ints * sizeof(int) + 64;
 }
 
+template<int NT>
 __device__ __forceinline__ void
-lds_carve(Lds& L, lptr base, const Dims& d, int nt)
+lds_carve(Lds<NT>& L, lptr base, const Dims& d, int nt)
 {
   // every member goes through v_readfirstlane HERE, with all lanes active, so that the offsets
   // built from them later are scalar registers whatever the divergence at the point of use
@@ -392,7 +420,7 @@ lds_carve(Lds& L, lptr base, const Dims& d, int nt)
   L.nd = uni(d.nd);
   L.tmax = uni(d.nd > d.n ? d.nd : d.n);
   L.nt = nt;
-  L.plen = uni(part_doubles(nt, L.tmax, L.n));
+  L.plen = uni(lds_part_len(d.n, d.n_eq, d.nc, d.n_in, d.nd, nt));
   L.o_ne = uni(16 * L.n);
   L.o_nc = uni(L.o_ne + 6 * L.ne);
   L.o_ni = uni(L.o_nc + 7 * L.nc);
@@ -1069,7 +1097,7 @@ struct Solver
   const long q;
   const Dims d;
   const QpRef P;
-  Lds L;
+  Lds<NT> L;
   Reducer<NT> R;
   const pqp_settings& st;
   UInfo info; // working copy (scalar registers), written back at exit
@@ -1241,6 +1269,7 @@ struct Solver
   // ---- primal block ---------------------------------------------------------
   // H_s + rho I = L D L^T and the explicit L^{-1} (reference helpers.hpp:252-264 for
   // the assembled block, ldlt.hpp:718-744 for the factorisation it feeds)
+  template<bool STAGED = true>
   __device__ __forceinline__ void factor_primal_block()
   {
     const int n = d.n;
@@ -1294,7 +1323,7 @@ struct Solver
     vstore(P.dF(), L.dF(), n);
     if (hess() == PQP_HESSIAN_DENSE)
       bytes((long)n * n * 8 * 3); // H_s read (upper triangle) + W and W^T written (lower triangle each), ~1.5 n^2 + margin for F
-    build_ZG();
+    build_ZG<STAGED>();
   }
 
   // Z = L^{-1} B^T for EVERY constraint row (B = [A_s; C_s; diag(i_scaled)]) in both
@@ -1306,6 +1335,13 @@ struct Solver
   //   G[c][d]  = sum_k Zc[k][c] (1/D_k) Zc[k][d], lower tiles + their mirrors.
   // ~5 MFLOP per QP at C2, done once per factorisation as dense tiles (an earlier version validated
   // rows lazily, one latency-bound pass over W and Z per newly active batch of constraints).
+  // STAGED: the two GEMMs run LDS-tiled through L.stage() -- every per-QP vector behind dF / t1 is scratch then (the
+  // solve's prologue, which loads its vectors afterwards); false: operands straight from L2 / HBM per wavefront (the
+  // backward kernel, whose iterate is already in LDS).  Same results bit for bit.
+  // (LDS-tiled in the 512- / 1024-thread kernels: C4 -3 % time, -100 MB of HBM traffic per QP; in the 256-thread
+  // kernels, whose operands mostly sit in L2 and whose four wavefronts gain little from sharing, the per-wavefront form
+  // stays: the tiled one is 5 % slower at C2 and 8 % at C1 -- two barriers per slab -- profiles/r04_ab_zg_lds_tiled.txt)
+  template<bool STAGED = true>
   __device__ __forceinline__ void build_ZG()
   {
     const int n = d.n, ne = d.n_eq, ni = d.n_in, nd = d.nd, nb = ne + ni;
@@ -1316,9 +1352,10 @@ struct Solver
     if (dm()) {
       // zd[c] = the one entry of row c of Z = B^T (L = I), gd[c] = zd[c]^2 / D_col(c)
       cgptr cd = P.CTs();
+      cgptr isg = P.is(); // (i_scaled from HBM: the LDS copy is loaded after this prologue)
       gptr gd = P.G();
       for (int c = threadIdx.x; c < nd; c += NT) {
-        const double z = (c < ni) ? cd[c] : L.isc()[c - ni];
+        const double z = (c < ni) ? cd[c] : isg[c - ni];
         Zr[c] = z;
         gd[c] = z * z / L.dF()[dcol(c)];
       }
@@ -1333,7 +1370,46 @@ struct Solver
       // work unit = one 16-row block of Z times TWO adjacent 16-column blocks: the W operand is
       // loaded once for both, and every batch keeps 3 * ZG_DEPTH loads in flight per lane
       const int KT = (n + 15) / 16, CT = (nb + 15) / 16, CP = (CT + 1) / 2;
-      if constexpr (NT >= 512 && PQP_ZG_BLOCK2) {
+      if constexpr (STAGED && ZG_LDS_TILED(NT)) {
+        (void)KT;
+        (void)CP;
+        __syncthreads(); // (t1 complete; nothing else of the staging area is live)
+        using T = ZgTile<NT>;
+        lptr stage = L.stage();
+        const int wr = w / T::WC, wc = w - wr * T::WC;
+        lptr sc = stage + w * (16 * 17);
+        auto loadA = [&](int j, int k) -> double { return (k < n) ? WU[(long)j * n + k] : 0.0; }; // W[k][j]
+        auto loadB = [&](int j, int c) -> double {
+          return (c < ne) ? ATs[(long)j * ne + c] : ((c < nb) ? CTs[(long)j * ni + (c - ne)] : 0.0);
+        };
+        for (int R0 = 0; R0 < n; R0 += T::TM)
+          for (int C0 = 0; C0 < nb; C0 += T::TN) {
+            const int jend = (R0 + T::TM < n) ? (R0 + T::TM) : n; // W[k][j] = 0 for j > k
+            pqp_d4 acc[2][2];
+            zg_block<NT>(loadA, loadB, R0, C0, jend, stage, acc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int k0 = R0 + wr * 32 + h * 16, c0 = C0 + wc * 32 + g * 16;
+                if (k0 >= n || c0 >= nb) // (wave-uniform)
+                  continue;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                  const int kr = k0 + lk + 4 * rr;
+                  if (kr < n && c0 + lr < nb)
+                    Zc[(long)kr * nd + c0 + lr] = acc[h][g][rr];
+                }
+                const pqp_d4 t = zg_transpose(acc[h][g], sc);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                  const int cr = c0 + lk + 4 * rr;
+                  if (cr < nb && k0 + lr < n)
+                    Zr[(long)cr * n + k0 + lr] = t[rr];
+                }
+              }
+          }
+      } else if constexpr (NT >= 512 && PQP_ZG_BLOCK2) {
         // 2 x 2: two 16-row blocks of Z (k) times two 16-column blocks (c)
         const int KP = (KT + 1) / 2;
         for (int t = w; t < KP * CP; t += NWV) {
@@ -1474,10 +1550,11 @@ struct Solver
       }
       if (has_box()) {
         cgptr WL = P.WL();
+        cgptr isg = P.is(); // (i_scaled from HBM: the LDS copy is loaded after this prologue)
         for (int o = threadIdx.x; o < n * n; o += NT) {
           const int a = o / n, bcol = o - a * n;
-          Zc[(long)a * nd + nb + bcol] = WL[o] * L.isc()[bcol]; // Z[k=a][box bcol] = W[a][bcol] i_bcol
-          Zr[(long)(nb + a) * n + bcol] = WU[o] * L.isc()[a];   // Zr[box a][k=bcol] = W[bcol][a] i_a
+          Zc[(long)a * nd + nb + bcol] = WL[o] * isg[bcol]; // Z[k=a][box bcol] = W[a][bcol] i_bcol
+          Zr[(long)(nb + a) * n + bcol] = WU[o] * isg[a];   // Zr[box a][k=bcol] = W[bcol][a] i_a
         }
       }
     } else {
@@ -1491,7 +1568,7 @@ struct Solver
         else if (c < nb)
           v = Cs[(long)(c - ne) * n + k];
         else
-          v = (k == c - nb) ? L.isc()[k] : 0.0;
+          v = (k == c - nb) ? P.is()[k] : 0.0;
         Zr[o] = v;
       }
       for (int o = threadIdx.x; o < n * nd; o += NT) {
@@ -1502,7 +1579,7 @@ struct Solver
         else if (c < nb)
           v = CTs[(long)k * ni + (c - ne)];
         else
-          v = (k == c - nb) ? L.isc()[k] : 0.0;
+          v = (k == c - nb) ? P.is()[k] : 0.0;
         Zc[o] = v;
       }
     }
@@ -1513,7 +1590,53 @@ struct Solver
       // work unit = block row ct of G times TWO adjacent block columns dt, dt+1 <= ct (lower
       // tiles; each off-diagonal tile also yields its mirror from the swapped operands)
       const int DT = (nd + 15) / 16;
-      if constexpr (NT >= 512 && PQP_ZG_BLOCK2) {
+      if constexpr (STAGED && ZG_LDS_TILED(NT)) {
+        (void)DT;
+        using T = ZgTile<NT>;
+        lptr stage = L.stage();
+        const int wr = w / T::WC, wc = w - wr * T::WC;
+        lptr sc = stage + w * (16 * 17);
+        auto loadA = [&](int k, int c) -> double { return (c < nd) ? Zcc[(long)k * nd + c] * L.t1()[k] : 0.0; };
+        auto loadB = [&](int k, int dd) -> double { return (dd < nd) ? Zcc[(long)k * nd + dd] : 0.0; };
+        for (int R0 = 0; R0 < nd; R0 += T::TM)
+          for (int C0 = 0; C0 < nd && C0 <= R0 + T::TM - 1; C0 += T::TN) { // blocks that reach the lower triangle
+            pqp_d4 acc[2][2];
+            zg_block<NT>(loadA, loadB, R0, C0, n, stage, acc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int c0 = R0 + wr * 32 + h * 16, d0 = C0 + wc * 32 + g * 16; // tile rows c, columns d
+                if (d0 > c0 || c0 >= nd) // above G's diagonal (its mirror below writes it) or past the last row
+                  continue;
+                if (d0 != c0) {
+#pragma unroll
+                  for (int rr = 0; rr < 4; ++rr) {
+                    const int cr = c0 + lk + 4 * rr;
+                    if (cr < nd && d0 + lr < nd)
+                      G[(long)cr * nd + d0 + lr] = acc[h][g][rr];
+                  }
+                  const pqp_d4 t = zg_transpose(acc[h][g], sc);
+#pragma unroll
+                  for (int rr = 0; rr < 4; ++rr) {
+                    const int dr = d0 + lk + 4 * rr;
+                    if (dr < nd && c0 + lr < nd)
+                      G[(long)dr * nd + c0 + lr] = t[rr];
+                  }
+                } else {
+                  // diagonal tile: keep G exactly symmetric (lower part + its mirror)
+#pragma unroll
+                  for (int rr = 0; rr < 4; ++rr) {
+                    const int cr = c0 + lk + 4 * rr, dcol = d0 + lr;
+                    if (cr < nd && dcol < nd && cr >= dcol) {
+                      G[(long)cr * nd + dcol] = acc[h][g][rr];
+                      G[(long)dcol * nd + cr] = acc[h][g][rr];
+                    }
+                  }
+                }
+              }
+          }
+      } else if constexpr (NT >= 512 && PQP_ZG_BLOCK2) {
         // 2 x 2: block rows (2 sc, 2 sc + 1) of G times block columns (2 sd, 2 sd + 1), sd <= sc; on the diagonal
         // of this coarser grid the tile above G's diagonal is the mirror of the one below and is skipped
         const int ST = (DT + 1) / 2;
@@ -3820,10 +3943,15 @@ struct Solver
     if (threadIdx.x == 0)
       L.stat()[ST_CYC_TOTAL] = -clock64(); // (start time parked in its own counter: no register held)
 
-    // results -> LDS (the warm-start modes read them)
-    vload(L.x(), P.x(), n);
-    vload(L.y(), P.y(), ne);
-    vload(L.z(), P.z(), nc);
+    // (512- / 1024-thread kernels: the results and the model vectors go to LDS AFTER the factorisation prologue below,
+    // whose LDS-tiled Z / G build uses every per-QP vector behind dF / t1 as its staging area)
+    constexpr bool LATE_LOADS = ZG_LDS_TILED(NT);
+    if constexpr (!LATE_LOADS) {
+      // results -> LDS (the warm-start modes read them)
+      vload(L.x(), P.x(), n);
+      vload(L.y(), P.y(), ne);
+      vload(L.z(), P.z(), nc);
+    }
     {
       // active_set_up / active_set_low live as long as the QP object in the reference: neither
       // Workspace::cleanup (workspace.hpp:330-377) nor init / update touch them, so the duality-gap
@@ -3851,11 +3979,15 @@ struct Solver
     bool do_aset_from_z; // active set from z != 0
     bool do_eq_guess = false;
     bool do_restore = false;
+    bool zero_iterate = false; // results.cleanup of a dirty QP: x = y = z = 0 (applied when the vectors are loaded)
     if (dirty) {
       if (ig == PQP_EQUALITY_CONSTRAINED_INITIAL_GUESS || ig == PQP_NO_INITIAL_GUESS) {
-        vzero(L.x(), n); // results.cleanup
-        vzero(L.y(), ne);
-        vzero(L.z(), nc);
+        zero_iterate = true;
+        if constexpr (!LATE_LOADS) {
+          vzero(L.x(), n); // results.cleanup
+          vzero(L.y(), ne);
+          vzero(L.z(), nc);
+        }
         cold_start(info, st);
       } else if (wswpr) {
         cleanup_statistics(info);
@@ -3905,18 +4037,20 @@ struct Solver
         bytes(dm() ? ((long)n * 3 + (long)ni * 3) * 8 : ((long)n * n * 2 + 3L * ne * n + 3L * ni * n) * 8);
       toc(ST_CYC_SCALE);
     }
-    vload(L.gs(), P.gs(), n);
-    vload(L.bs(), P.bs(), ne);
-    vload(L.us(), P.us(), ni);
-    vload(L.ls(), P.ls(), ni);
-    if (has_box()) {
-      vload(L.ubs(), P.ubs(), n);
-      vload(L.lbs(), P.lbs(), n);
-      vload(L.isc(), P.is(), n);
+    if constexpr (!LATE_LOADS) {
+      vload(L.gs(), P.gs(), n);
+      vload(L.bs(), P.bs(), ne);
+      vload(L.us(), P.us(), ni);
+      vload(L.ls(), P.ls(), ni);
+      if (has_box()) {
+        vload(L.ubs(), P.ubs(), n);
+        vload(L.lbs(), P.lbs(), n);
+        vload(L.isc(), P.is(), n);
+      }
+      __syncthreads();
+      if (do_scale_ws)
+        scale_warm_start();
     }
-    __syncthreads();
-    if (do_scale_ws)
-      scale_warm_start();
     if (do_factor) {
 #ifdef PQP_STATS
       if (threadIdx.x == 0)
@@ -3934,6 +4068,30 @@ struct Solver
       n_slots = 0;
       r = ne;
       schur_dirty = true;
+    }
+    if constexpr (LATE_LOADS) {
+      // results -> LDS (the warm-start modes read them) and the equilibrated model vectors
+      if (zero_iterate) {
+        vzero(L.x(), n);
+        vzero(L.y(), ne);
+        vzero(L.z(), nc);
+      } else {
+        vload(L.x(), P.x(), n);
+        vload(L.y(), P.y(), ne);
+        vload(L.z(), P.z(), nc);
+      }
+      vload(L.gs(), P.gs(), n);
+      vload(L.bs(), P.bs(), ne);
+      vload(L.us(), P.us(), ni);
+      vload(L.ls(), P.ls(), ni);
+      if (has_box()) {
+        vload(L.ubs(), P.ubs(), n);
+        vload(L.lbs(), P.lbs(), n);
+        vload(L.isc(), P.is(), n);
+      }
+      __syncthreads();
+      if (do_scale_ws)
+        scale_warm_start();
     }
     if (do_restore) {
       // WARM_START_WITH_PREVIOUS_RESULT on an unchanged model: reuse the block
@@ -4404,7 +4562,7 @@ struct Solver
     info.mu_eq = bw.mu_new;
     info.mu_in = bw.mu_new;
     // setup_factorization + active_set_change from the empty set (:66-86)
-    factor_primal_block();
+    factor_primal_block<false>(); // (the iterate is in LDS already: no staging area)
     n_c = 0;
     n_slots = 0;
     r = ne;
