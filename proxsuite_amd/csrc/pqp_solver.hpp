@@ -4217,6 +4217,25 @@ struct Solver
         if (st.eps_rel != 0)
           rhs_dua += rhs_dua_rel;
         is_dual_feasible = dual_feasibility_lhs <= rhs_dua;
+        if (PQP_UNLIKELY(st.verbose != 0)) {
+          // solver.hpp:1469-1510: `verbose` is not only printing -- the reference unscales x, y, z for its report and
+          // scales them back, the identity up to rounding only: a verbose run perturbs the iterates in their last
+          // bits at every outer iteration (test/src/dense_qp_wrapper.cpp:7178 runs its closest-feasible family that
+          // way).  Same round trip here (the report itself is printed by the host from the final Info).
+          cgptr dx = P.dlt_x(), de = P.dlt_eq(), di = P.dlt_in();
+          for (int k = threadIdx.x; k < n; k += NT)
+            L.x()[k] = (L.x()[k] * dx[k]) / dx[k];
+          for (int k = threadIdx.x; k < ne; k += NT)
+            L.y()[k] = (L.y()[k] * de[k] / ruiz_c) / de[k] * ruiz_c;
+          for (int k = threadIdx.x; k < ni; k += NT)
+            L.z()[k] = (L.z()[k] * di[k] / ruiz_c) / di[k] * ruiz_c;
+          if (has_box()) {
+            cgptr db = P.dlt_box();
+            for (int k = threadIdx.x; k < n; k += NT)
+              L.z()[ni + k] = (db[k] * L.z()[ni + k] / ruiz_c) / db[k] * ruiz_c;
+          }
+          __syncthreads();
+        }
         if (is_primal_feasible && is_dual_feasible) {
           if (st.check_duality_gap) {
             if (fabs(info.duality_gap) <= st.eps_duality_gap_abs + st.eps_duality_gap_rel * rhs_duality_gap) {

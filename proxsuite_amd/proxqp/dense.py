@@ -476,9 +476,9 @@ def solve(*args, **kwargs):
 
     Python cannot overload on types.  A positional call is read as the box overload when its 8th and
     9th arguments can only be (l_box, u_box): both vectors of the primal dimension -- or None followed by
-    such a vector -- while n_eq != dim, so that the 9th cannot be `y`.  When n_eq == dim the two readings
-    cannot be told apart and the call raises TypeError: pass `l_box=` / `u_box=` (or `x=`, `y=`) by keyword,
-    which always works."""
+    such a vector -- while n_eq != dim, so that the 9th cannot be `y`.  When n_eq == dim the 11th argument decides
+    (an array: `y` of the box overload; a scalar: `eps_abs` of the plain one); a shorter call is read as the plain
+    overload (x, y).  Keywords (`l_box=`, `u_box=`, `x=`, `y=`) always work."""
     def is_vec(v, length):
         try:
             return v is not None and not np.isscalar(v) and np.asarray(v).ndim == 1 and np.asarray(v).shape[0] == length
@@ -496,9 +496,13 @@ def solve(*args, **kwargs):
         v8, v9 = is_vec(args[7], n0), is_vec(args[8], n0)
         if v9 and (v8 or args[7] is None):
             if ne0 == n0:
-                raise TypeError("solve(): with n_eq == dim the 8th and 9th positional arguments can be read as (x, y) "
-                                "or as (l_box, u_box); pass them by keyword")
-            names = box_names
+                # (x, y) and (l_box, u_box) have the same shapes: the 11th argument decides -- `y` of the box overload
+                # is an array there, `eps_abs` of the plain one a scalar.  Without it the call is read as the plain
+                # overload (x, y): the reference-style warm start; boxes of such a QP go by keyword.
+                if len(args) >= 11 and not np.isscalar(args[10]) and args[10] is not None:
+                    names = box_names
+            else:
+                names = box_names
     if len(args) > len(names):
         raise TypeError("solve() takes at most %d positional arguments" % len(names))
     bound = dict(zip(names, args))

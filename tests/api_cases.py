@@ -118,16 +118,22 @@ def case_box(dense, oracle, randqp):
     # a plain positional call with a warm start x and y = None stays the plain overload
     r6 = dense.solve(H, g, None, None, C, l, u, r.x, None, None, 1e-9)
     assert r6.z.shape == (ni,)
-    # n_eq == dim: (x, y) and (l_box, u_box) cannot be told apart positionally -> TypeError, keywords work
+    # n_eq == dim: (x, y) and (l_box, u_box) have the same shapes.  The 11th argument decides: an array there is `y` of
+    # the box overload, a scalar `eps_abs` of the plain one; a call that leaves it open is the plain overload (the
+    # reference-style warm start solve(..., u, x, y)); keywords always work
     A = np.eye(n)
     bvec = np.zeros(n)
-    import pytest
-    with pytest.raises(TypeError):
-        dense.solve(H, g, A, bvec, C, l, u, lb, ub, None, None, None, 1e-9)
-    with pytest.raises(TypeError):
-        dense.solve(H, g, A, bvec, C, l, u, None, ub, None, None, None, 1e-9)
-    r7 = dense.solve(H, g, A, bvec, C, l, u, x=np.zeros(n), y=np.zeros(n), eps_abs=1e-9)
+    x0, y0 = np.zeros(n), np.zeros(n)
+    r7 = dense.solve(H, g, A, bvec, C, l, u, x=x0, y=y0, eps_abs=1e-9)
     assert r7.z.shape == (ni,)
+    r8 = dense.solve(H, g, A, bvec, C, l, u, x0, y0, None, 1e-9)  # plain overload: (x, y, z, eps_abs)
+    assert r8.z.shape == (ni,) and np.array_equal(r8.x, r7.x)
+    r9 = dense.solve(H, g, A, bvec, C, l, u, x0, y0)              # plain overload, short form
+    assert r9.z.shape == (ni,)
+    r10 = dense.solve(H, g, A, bvec, C, l, u, lb, ub, x0, y0, None, 1e-9)  # box overload: an array in the 11th place
+    assert r10.z.shape == (ni + n,)
+    r11 = dense.solve(H, g, A, bvec, C, l, u, x=x0, y=y0, eps_abs=1e-9, l_box=lb, u_box=ub)
+    assert np.array_equal(r10.x, r11.x)
 
 
 def case_batch_and_parallel(dense, oracle, randqp, B=6):

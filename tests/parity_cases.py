@@ -121,6 +121,30 @@ def case_random_batch(lib, oracle, randqp, n, ne, ni, B, guess=InitialGuess.NO_I
     return x, y, z, info
 
 
+def case_verbose_round_trip(lib, oracle, randqp, n=20, ne=5, ni=8, B=3):
+    """settings.verbose is not only printing in the reference: its report block unscales x, y, z and scales them back
+    (dense/solver.hpp:1469-1510), which perturbs the iterates in their last bits at every outer iteration.  Oracle and
+    device both restate that round trip: a verbose run must agree like any other (solutions to 1e-10, Info counters)."""
+    m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2, seed0=40)
+    b = N.Batch(B, n, ne, ni, lib=lib)
+    settings_all(b, eps_abs=EPS, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS), verbose=1)
+    b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
+    b.solve()
+    x, y, z, se, si, info = b.results()
+    for i in range(B):
+        q = oracle.QP(n, ne, ni)
+        q.settings.eps_abs, q.settings.eps_rel = EPS, 0
+        q.settings.initial_guess = InitialGuess.NO_INITIAL_GUESS
+        q.settings.verbose = 1
+        q.init(m.H[i], m.g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i])
+        q.solve()
+        assert info[i].status == QPSolverOutput.PROXQP_SOLVED
+        assert close(x[i], q.results.x) and close(y[i], q.results.y) and close(z[i], q.results.z), i
+        bad = info_close(info[i], q.results.info)
+        assert bad is None, (i, bad)
+    b.close()
+
+
 def oracle_solve_many(oracle, models, n, ne, ni, guess=InitialGuess.NO_INITIAL_GUESS, eps=EPS, **qpkw):
     """init + solve_in_parallel of the oracle on a list of (H, g, A, b, C, l, u[, l_box, u_box])."""
     qs = []

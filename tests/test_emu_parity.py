@@ -120,6 +120,11 @@ def test_seed14_mechanism_on_the_emulated_device(lib, randqp):
     assert n == 3
 
 
+def test_verbose_round_trip(lib, oracle, randqp, capfd):
+    pc.case_verbose_round_trip(lib, oracle, randqp)
+    capfd.readouterr()  # (the host-side report of the verbose QPs)
+
+
 def test_closest_feasible(lib, oracle, randqp):
     """seeds whose oracle run is short enough for the emulator (the GPU test runs all 20)"""
     seen = pc.case_closest_feasible(lib, oracle, randqp, seeds=range(6), max_oracle_iter_ext=60)

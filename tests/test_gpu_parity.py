@@ -185,6 +185,11 @@ def test_seed14_mechanism_on_the_device(lib, randqp):
     assert n == 15 and 1 <= n_ok < n, (n_ok, n)
 
 
+def test_verbose_round_trip(lib, oracle, randqp, capfd):
+    pc.case_verbose_round_trip(lib, oracle, randqp)
+    capfd.readouterr()  # (the host-side report of the verbose QPs)
+
+
 def test_closest_feasible(lib, oracle, randqp):
     """reference test/src/dense_qp_wrapper.cpp:7153-7215, all 20 seeds, with and without
     primal_infeasibility_solving"""
