@@ -42,7 +42,7 @@ enum pqp_error
 };
 
 /* number of entries of the per-QP statistics record, see pqp_batch_get_stats */
-#define PQP_STATS_COUNT 32
+#define PQP_STATS_COUNT 33
 
 const char* pqp_last_error(void);
 int pqp_device_count(void);

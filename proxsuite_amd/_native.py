@@ -14,12 +14,12 @@ import numpy as np
 
 from ._ctypes_defs import pqp_info, pqp_settings
 
-PQP_STATS_COUNT = 32
+PQP_STATS_COUNT = 33
 STAT_NAMES = ("cyc_total", "cyc_scale", "cyc_factor_h", "cyc_zg", "cyc_schur", "cyc_kkt_solve",
               "cyc_residual", "cyc_linesearch", "cyc_global_res", "cyc_newton_misc", "n_newton",
               "n_schur_fact", "n_new_rows", "n_kkt_solves", "n_ls_breakpoints", "n_active_final",
               "cyc_f_load", "cyc_f_update", "cyc_f_panel", "cyc_f_writeback", "cyc_f_tinv", "cyc_s_gather",
-              "cyc_solve_ldlt", "n_schur_blocked", "n_append", "n_delete", "bytes_engine", "n_refactorize", "cyc_ls_eval", "cyc_cert", "cyc_update", "wall_ticks")
+              "cyc_solve_ldlt", "n_schur_blocked", "n_append", "n_delete", "bytes_engine", "n_refactorize", "cyc_ls_eval", "cyc_cert", "cyc_update", "wall_ticks", "flops_fact")
 
 _DP = C.POINTER(C.c_double)
 NAN = float("nan")

@@ -198,6 +198,7 @@ enum
   ST_CYC_CERT,        // infeasibility certificates (sub-phase of ST_CYC_NEWTON_MISC)
   ST_CYC_UPDATE,      // iterate update + inner stopping criterion (sub-phase of ST_CYC_NEWTON_MISC)
   ST_WALL_TICKS,      // residency of the QP's workgroup in constant-rate ticks (wall_clock64): info.solve_time
+  ST_FLOPS_FACT,      // sum over the LDL^T factorisations of the solve (primal block, dual Schur block / P_J) of m_f^3 / 3
   ST_COUNT
 };
 
@@ -1321,8 +1322,10 @@ struct Solver
       __syncthreads();
     }
     vstore(P.dF(), L.dF(), n);
-    if (hess() == PQP_HESSIAN_DENSE)
+    if (hess() == PQP_HESSIAN_DENSE) {
       bytes((long)n * n * 8 * 3); // H_s read (upper triangle) + W and W^T written (lower triangle each), ~1.5 n^2 + margin for F
+      count(ST_FLOPS_FACT, (long long)n * n * n / 3);
+    }
     build_ZG<STAGED>();
   }
 
@@ -1999,6 +2002,7 @@ struct Solver
     schur_dirty = false;
     schur_incremental = false;
     count(ST_N_SCHUR_FACT);
+    count(ST_FLOPS_FACT, (long long)rr * rr * rr / 3);
   }
 
   // PrimalLDLT: assemble P_J = H_s + rho I + A^T A / mu_eq + C_J^T C_J / mu_in (+ box rows) in the F
@@ -2062,6 +2066,7 @@ struct Solver
     schur_dirty = false;
     schur_incremental = false;
     count(ST_N_SCHUR_FACT);
+    count(ST_FLOPS_FACT, (long long)n * n * n / 3);
   }
 
   // v <- S_J^{-1} v = W^T D^{-1} W v for an LDS vector over the r slots (zero at the holes, and
