@@ -311,6 +311,12 @@ class Batch:
     def wait(self):
         self.lib.check(self.lib.L.pqp_batch_wait(self._h))
 
+    def solve_subset(self, idx, asynchronous=False):
+        """QP::solve() on the listed QPs in ONE launch (dense::solve_in_parallel(std::vector<QP>&))"""
+        ii = np.ascontiguousarray(idx, dtype=np.int64)
+        fn = self.lib.L.pqp_batch_solve_subset_async if asynchronous else self.lib.L.pqp_batch_solve_subset
+        self.lib.check(fn(self._h, ii.ctypes.data_as(C.POINTER(C.c_int64)), len(ii)))
+
     def enable_host_results(self, on=True):
         """pinned host mirrors of (x, y, z, se, si, Info) written by the epilogue of the solve kernel: the results are
         on the host when solve() / wait() returns, with no device-to-host copy (include/proxqp_hip.h)"""

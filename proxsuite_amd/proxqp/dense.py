@@ -143,6 +143,11 @@ class _Pool:
     def __init__(self, capacity, n, n_eq, n_in, box, hessian_type, dense_backend, device):
         self.batch = _native.Batch(capacity, n, n_eq, n_in, box_constraints=box, hessian_type=int(hessian_type),
                                    dense_backend=int(dense_backend), device=device)
+        # results are host members when a solve returns (reference parallel/qp_solve.hpp:33-37): the solve kernel writes
+        # them into pinned host mirrors; a stream of its own lets this pool overlap with the others
+        self.batch.enable_host_results(True)
+        self.batch.own_stream()
+        self.device = device
         self.capacity = capacity
         self.used = 0
         self._epoch = 0
@@ -154,7 +159,16 @@ class _Pool:
 
     def fetch(self):
         if self._cache_epoch != self._epoch:
-            self._cache = self.batch.results(-1)
+            if self.batch.host_results_fresh():
+                # one host copy out of the pinned mirrors (a snapshot: a Results object handed out earlier must not change
+                # under a later solve); the Info records as a ctypes array like results() returns
+                hx, hy, hz, hse, hsi, hinfo = self.batch.host_results()
+                info = (_native.pqp_info * self.capacity)()
+                if self.capacity:
+                    _native.C.memmove(info, hinfo.ctypes.data, self.capacity * _native.C.sizeof(_native.pqp_info))
+                self._cache = (hx.copy(), hy.copy(), hz.copy(), hse.copy(), hsi.copy(), info)
+            else:
+                self._cache = self.batch.results(-1)
             self._cache_epoch = self._epoch
         return self._cache
 
@@ -164,6 +178,18 @@ class _Pool:
         if count:
             self.batch.solve(first, count)
         self.touch()
+
+    def solve_async(self, slots=None):
+        """every used slot (or the listed ones, one launch) enqueued; `wait()` completes it"""
+        if slots is None:
+            if self.used:
+                self.batch.solve_async(0, self.used)
+        elif len(slots):
+            self.batch.solve_subset(slots, asynchronous=True)
+        self.touch()
+
+    def wait(self):
+        self.batch.wait()
 
 
 _INF_BOUND = 1.0e20
@@ -293,9 +319,20 @@ class BatchQP:
     `batch_size` is the capacity of each device pool (the reference reserves a vector of that
     size).  QPs of different sizes may share a BatchQP: each signature gets its own pool."""
 
-    def __init__(self, batch_size=0, *, device=0):
+    def __init__(self, batch_size=0, *, device=None, devices=None):
+        """`device`: a HIP device ordinal; `devices`: a list of them.  Default: every visible device -- with more than one
+        the batch is spread over all of them in ONE process: every signature gets one pool per device holding a
+        contiguous range of `batch_size` QPs, and solve_in_parallel launches every pool before it waits for any (the
+        reference's solve_in_parallel uses every core of the host, parallel/qp_solve.hpp:41-59)."""
         self._capacity = max(int(batch_size), 1)
-        self._device = device
+        if devices is None:
+            if device is None:
+                nd = _native.load().L.pqp_device_count()
+                devices = list(range(nd)) if nd > 1 else [0]
+            else:
+                devices = [int(device)]
+        self._devices = [int(d) for d in devices]
+        self._device = self._devices[0]
         self._pools = {}   # signature -> [pools]
         self._qps = []
 
@@ -305,9 +342,14 @@ class BatchQP:
         if key[0] <= 0:
             raise ValueError("wrong argument size: the dimension wrt the primal variable x should be strictly positive.")
         chain = self._pools.setdefault(key, [])
-        if not chain or chain[-1].used == chain[-1].capacity:
-            chain.append(_Pool(self._capacity, key[0], key[1], key[2], key[3], key[4], key[5], self._device))
-        pool = chain[-1]
+        if not chain or all(p.used == p.capacity for p in chain):
+            # one pool per device, each with a contiguous share of `batch_size` slots (the first B % G one more)
+            G = len(self._devices)
+            for g, dev in enumerate(self._devices):
+                cap = self._capacity // G + (1 if g < self._capacity % G else 0)
+                if cap > 0:
+                    chain.append(_Pool(cap, key[0], key[1], key[2], key[3], key[4], key[5], dev))
+        pool = next(p for p in chain if p.used < p.capacity)
         qp = QP(key[0], key[1], key[2], key[3], HessianType(key[4]), DenseBackend(key[5]), _pool=pool,
                 _slot=pool.used)
         pool.used += 1
@@ -359,23 +401,22 @@ def solve_in_parallel(qps, num_threads=None):
     """dense::solve_in_parallel (reference parallel/qp_solve.hpp:17-59; python
     expose-parallel.hpp:33-46).  `num_threads` is accepted for compatibility; the degree of
     parallelism is one workgroup per QP over the whole device."""
+    # every pool is launched before any is waited for (own streams; the pools of a multi-device BatchQP sit on different
+    # devices); the results are then in the pools' pinned host mirrors
     if isinstance(qps, BatchQP):
-        for pool in qps._all_pools():
-            pool.solve()
+        pools = qps._all_pools()
+        for pool in pools:
+            pool.solve_async()
+        for pool in pools:
+            pool.wait()
         return
     pools = {}
     for qp in qps:
         pools.setdefault(id(qp._pool), (qp._pool, []))[1].append(qp._slot)
     for pool, slots in pools.values():
-        slots.sort()
-        # contiguous runs become one launch each
-        start = prev = slots[0]
-        for s in slots[1:] + [None]:
-            if s is not None and s == prev + 1:
-                prev = s
-                continue
-            pool.solve(start, prev - start + 1)
-            start = prev = s
+        pool.solve_async(sorted(slots))  # the listed slots of a pool in ONE launch
+    for pool, _ in pools.values():
+        pool.wait()
 
 
 def estimate_minimal_eigen_value_of_symmetric_matrix(H, estimate_method_option=EigenValueEstimateMethodOption.ExactMethod,

@@ -136,6 +136,55 @@ def case_box(dense, oracle, randqp):
     assert np.array_equal(r10.x, r11.x)
 
 
+def case_multi_device_batch(dense, randqp, devices, B=7):
+    """BatchQP spread over several devices from ONE process (one pool per device with a contiguous share of the batch,
+    every pool launched before any is waited for): same answers bit for bit as QP-by-QP solves, QPs land on the
+    devices in contiguous ranges, a second signature rides along, per-QP methods reach the right pool."""
+    n, ne, ni = 10, 3, 4
+    qps = dense.BatchQP(B, devices=devices)
+    datas = [_qp_data(randqp, n, ne, ni, i) for i in range(B)]
+    args = lambda d: (d["H"], d["g"], d["A"], d["b"], d["C"], d["l"], d["u"])
+    for d in datas:
+        qp = qps.init_qp_in_place(n, ne, ni)
+        qp.settings.eps_abs = 1e-9
+        qp.settings.initial_guess = dense.InitialGuess.NO_INITIAL_GUESS
+        qp.init(*args(d))
+    other = _qp_data(randqp, 6, 0, 5, 50)
+    qo = qps.init_qp_in_place(6, 0, 5)
+    qo.settings.eps_abs = 1e-9
+    qo.init(other["H"], other["g"], None, None, other["C"], other["l"], other["u"])
+    pools = qps._all_pools()
+    G = len(devices)
+    first_sig = [p for p in pools if p.batch.n == n]
+    assert len(first_sig) == min(G, B) and sum(p.used for p in first_sig) == B
+    assert [p.device for p in first_sig] == list(devices)[:len(first_sig)]
+    assert max(p.capacity for p in first_sig) - min(p.capacity for p in first_sig) <= 1
+    dense.solve_in_parallel(qps)
+    for i, d in enumerate(datas):
+        ref = dense.QP(n, ne, ni)
+        ref.settings.eps_abs = 1e-9
+        ref.settings.initial_guess = dense.InitialGuess.NO_INITIAL_GUESS
+        ref.init(*args(d))
+        ref.solve()
+        r = qps.get(i).results
+        assert r.info.status == dense.QPSolverOutput.PROXQP_SOLVED
+        assert np.array_equal(r.x, ref.results.x) and np.array_equal(r.z, ref.results.z)
+        assert r.info.iter == ref.results.info.iter
+    assert qo.results.info.status == dense.QPSolverOutput.PROXQP_SOLVED
+    # a Results object is a snapshot: a later solve of the batch does not change it
+    keep = qps.get(B - 1).results
+    x_before = keep.x.copy()
+    qps.get(B - 1).update(g=datas[B - 1]["g"] * 2.0)
+    dense.solve_in_parallel(qps)
+    assert np.array_equal(keep.x, x_before) and not np.array_equal(qps.get(B - 1).results.x, x_before)
+    # the vector form: QPs of several pools, one launch per pool
+    vec = dense.VectorQP()
+    for i in (0, B - 1, B // 2):
+        vec.append(qps.get(i))
+    dense.solve_in_parallel(vec)
+    assert all(q.results.info.status == dense.QPSolverOutput.PROXQP_SOLVED for q in vec)
+
+
 def case_batch_and_parallel(dense, oracle, randqp, B=6):
     """reference test/src/parallel_qp_solve.py / examples/python/solve_dense_qp_in_parallel.py:
     BatchQP.init_qp_in_place + solve_in_parallel == QP-by-QP solves; mixed sizes allowed."""

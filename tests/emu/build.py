@@ -28,10 +28,11 @@ def build_variant(tag, defines):
     cmd = ["g++", "-std=gnu++17", "-fPIC", "-shared", "-O2", "-pthread", "-fno-strict-aliasing", "-DPQP_STATS",
            *["-D" + d for d in defines], "-Wno-unknown-pragmas", "-Wno-attributes",
            "-I", str(HERE / "include"), "-I", str(ROOT / "include"), "-I", str(csrc),
-           "-x", "c++", *map(str, srcs), "-o", str(out)]
+           "-x", "c++", *map(str, srcs), "-o", str(out) + ".tmp%d" % os.getpid()]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulator variant build failed:\n" + r.stdout + r.stderr)
+    os.replace(str(out) + ".tmp%d" % os.getpid(), out)  # (atomic: parallel test workers may build at the same time)
     return out
 
 
@@ -47,10 +48,11 @@ def build(force=False, debug=False):
     cmd = ["g++", "-std=gnu++17", "-fPIC", "-shared", *opt, "-pthread", "-fno-strict-aliasing", "-DPQP_STATS",
            "-Wno-unknown-pragmas", "-Wno-attributes",
            "-I", str(HERE / "include"), "-I", str(ROOT / "include"), "-I", str(csrc),
-           "-x", "c++", *map(str, srcs), "-o", str(LIB)]
+           "-x", "c++", *map(str, srcs), "-o", str(LIB) + ".tmp%d" % os.getpid()]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulator build failed:\n" + r.stdout + r.stderr)
+    os.replace(str(LIB) + ".tmp%d" % os.getpid(), LIB)  # (atomic: parallel test workers may build at the same time)
     return LIB
 
 

@@ -31,6 +31,12 @@ def test_batch_and_parallel(dense, oracle, randqp):
     ac.case_batch_and_parallel(dense, oracle, randqp)
 
 
+@pytest.mark.parametrize("devices", [[0, 0, 0], [0, 0]])
+def test_multi_device_batch(dense, randqp, devices):
+    """BatchQP over several devices from one process (logical shards: every ordinal is the same GPU here)"""
+    ac.case_multi_device_batch(dense, randqp, devices)
+
+
 def test_one_shot_solve(dense, oracle, randqp):
     ac.case_one_shot_solve(dense, oracle, randqp)
 
