@@ -984,13 +984,14 @@ def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1
     on them through cold restarts (same mechanism as seed 14 of the closest-feasible family,
     tests/test_oracle_known_answers.py) and where the cycle stands when the certificate test fires depends on the
     last bits: counted as `forks`, bounded by the caller.
-    Returns dict(failures, unsolved_alike, forks, solved, info_mismatch)."""
+    PDAL shapes (every third): see the two-tier gate below.
+    Returns dict(failures, unsolved_alike, forks, solved, info_mismatch, pdal_same_path, pdal_forked)."""
     import time
     from proxsuite_amd._ctypes_defs import DenseBackend
     O, R = oracle, randqp
     rng = np.random.default_rng(int(seed))
     t0 = time.time()
-    bad = notes = forks = solved = info_bad = 0
+    bad = notes = forks = solved = info_bad = pdal_tight = pdal_forked = 0
     for it in range(count):
         n = int(rng.integers(n_range[0], n_range[1]))
         ne = int(rng.integers(0, max(1, n // 2) + 1))
@@ -1075,8 +1076,15 @@ def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1
                     # constraint), and the reference evaluates it exactly AT the breakpoints, where the activity test
                     # fl(r_i + alpha (C dx)_i) > 0 is decided by the last bit of its inputs.  Two summation orders take
                     # different steps from the first Newton iteration on (traced: same alpha, phi' = 5.60 vs 2.89) and
-                    # meet again only at the solution: statuses and the solution are compared, not the path.
-                    xtol = 1e-5
+                    # meet again only at the solution.  Two tiers: a QP on which both sides took the SAME path (equal Info
+                    # counters) gets the full gate of the GPDAL shapes -- x to XYZ_TOL, Info equal --, one whose path
+                    # forked is compared by status and solution and counted (`pdal_forked`, bounded by the caller).
+                    same_path = info_close(info[i], r.info, residuals=False) is None
+                    if same_path:
+                        pdal_tight += 1
+                    else:
+                        pdal_forked += 1
+                        xtol = 1e-5
                 if not (pri <= 1e-9 and dua <= 1e-9 and close(x[i], r.x, xtol)):
                     bad += 1; print("FAIL", tag, pri, dua, float(np.max(np.abs(x[i] - r.x))),
                                     "info", info_close(info[i], r.info, residuals=False), "iter", info[i].iter, r.info.iter,
@@ -1090,4 +1098,4 @@ def case_random_sweep(lib, oracle, randqp, seed, count, verbose=True, n_range=(1
                             print("INFO", tag, why, flush=True)
         b.close()
     return dict(failures=bad, unsolved_alike=notes, forks=forks, solved=solved, info_mismatch=info_bad,
-                seconds=time.time() - t0)
+                pdal_same_path=pdal_tight, pdal_forked=pdal_forked, seconds=time.time() - t0)

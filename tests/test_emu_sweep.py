@@ -37,3 +37,4 @@ def test_random_sweep_small(oracle, randqp, monkeypatch, seed):
     r = pc.case_random_sweep(lib, oracle, randqp, seed, 7, verbose=True)
     assert r["failures"] == 0 and r["info_mismatch"] == 0, r
     assert r["solved"] + r["unsolved_alike"] + r["forks"] == 7 * 3 * 2, r
+    assert r["pdal_forked"] <= 2, r  # (PDAL shapes: the full gate on every QP whose two sides walk the same path)
