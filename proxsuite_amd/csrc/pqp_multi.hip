@@ -121,6 +121,11 @@ pqp_multi_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
       const std::string msg = pqp_last_error();
       if (h)
         pqp_batch_destroy(h);
+      if (st) { // (not yet owned by m)
+        DeviceGuard guard(devices[g]);
+        if (guard.ok())
+          (void)hipStreamDestroy(st);
+      }
       pqp_multi_destroy(m);
       return fail(rc, msg);
     }
