@@ -210,6 +210,18 @@ int pqp_batch_get_schur_factor(pqp_batch* h, int64_t idx, double* WS, double* dS
  * (cycles per phase and event counters, see proxsuite_amd/csrc/pqp_solver.hpp ST_*) */
 int pqp_batch_get_stats(pqp_batch* h, int64_t* stats);
 
+/* settings.verbose: the per-iteration lines the reference prints while it solves (dense/solver.hpp:1478-1485
+ * "[outer iteration k] | primal residual= | dual residual= | duality gap= | mu_in= | rho=", and :1021-1027
+ * "[inner iteration k] | inner residual= | alpha=").  The whole solve of a QP is one kernel here: the kernel records
+ * the lines of every QP whose settings have verbose set, and the library prints them (same text, between the
+ * header and the statistics block) when the launch has finished.  This accessor hands out the records of QP `idx`
+ * from the last launch, 8 doubles each, in printing order:
+ *   { 1, k, pri_res, dua_res, duality_gap, mu_in, rho, 0 }   outer iteration k
+ *   { 2, k, inner residual, alpha, 0, 0, 0, 0 }              inner iteration k of the current outer one
+ * *n_records = number of lines recorded (0: the QP was not verbose); at most `capacity` are copied (records may
+ * be NULL).  4095 lines are kept per QP and launch. */
+int pqp_batch_get_trace(pqp_batch* h, int64_t idx, double* records, int64_t capacity, int64_t* n_records);
+
 /* device time of the last solve kernel in milliseconds (HIP events on the launch stream) */
 double pqp_batch_last_solve_ms(const pqp_batch* h);
 /* bytes of dynamic LDS and threads per workgroup chosen for this batch */

@@ -55,6 +55,8 @@ def lib():
         L.pqo_settings.argtypes = [vp]
         L.pqo_info.restype = C.POINTER(pqp_info)
         L.pqo_info.argtypes = [vp]
+        L.pqo_trace.restype = C.c_int64
+        L.pqo_trace.argtypes = [vp, C.c_void_p, C.c_int64]
         L.pqo_dense_backend.argtypes = [vp]
         L.pqo_init.argtypes = [vp] + [dp] * 9 + [C.c_int] + [C.c_double] * 4
         L.pqo_update.argtypes = [vp] + [dp] * 9 + [C.c_int] + [C.c_double] * 4
@@ -146,6 +148,16 @@ class QP:
         keep = [_arr(x, (self.n,)), _arr(y, (self.n_eq,)), _arr(z, (self.n_c,))]
         self._L.pqo_solve(self._h, *map(_ptr, keep))
         self._sync()
+
+    def trace(self):
+        """settings.verbose: the per-iteration lines of the last solve as an (N, 8) array -- outer iterations
+        [1, k, pri_res, dua_res, duality_gap, mu_in, rho, 0] (reference solver.hpp:1478-1485), inner ones
+        [2, k, inner residual, alpha, 0, 0, 0, 0] (solver.hpp:1021-1027), in the order the reference prints them."""
+        n = int(self._L.pqo_trace(self._h, None, 0))
+        out = np.zeros((n, 8))
+        if n:
+            self._L.pqo_trace(self._h, out.ctypes.data, n)
+        return out
 
     def compute_backward(self, loss_derivative, eps=1e-4, rho_backward=1e-6, mu_backward=1e-6):
         """dense::compute_backward (reference dense/compute_ECJ.hpp:29-189).  Returns a dict with

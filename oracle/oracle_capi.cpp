@@ -3,6 +3,7 @@
 // product path may link or load this library.
 #include "proxqp_oracle.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #ifdef _OPENMP
@@ -58,6 +59,18 @@ pqp_info*
 pqo_info(void* h)
 {
   return &static_cast<QP*>(h)->results.info;
+}
+
+// settings.verbose: the per-iteration records of the last solve (proxqp_oracle.hpp, QP::trace), 8 doubles each;
+// returns their number, copies at most `cap` of them
+int64_t
+pqo_trace(void* h, double* out, int64_t cap)
+{
+  const std::vector<double>& t = static_cast<QP*>(h)->trace;
+  const int64_t n = int64_t(t.size() / 8);
+  if (out)
+    std::copy(t.begin(), t.begin() + std::min(n, cap) * 8, out);
+  return n;
 }
 
 int

@@ -1528,6 +1528,10 @@ primal_dual_newton_semi_smooth(QP& qp, double eps_int)
           alpha * (r.info.rho * dx[k] + Hdx[k] + ATdy[k] + CTdz[size_t(k)]);
     }
     err_in = compute_inner_loop_saddle_point(qp);
+    if (s.verbose) { // solver.hpp:1021-1027
+      const double rec[8] = { 2.0, double(iter + 1), err_in, alpha, 0.0, 0.0, 0.0, 0.0 };
+      qp.trace.insert(qp.trace.end(), rec, rec + 8);
+    }
     if (iter % s.frequence_infeasibility_check == 0 || s.primal_infeasibility_solving) {
       bool is_primal_infeasible =
         global_primal_residual_infeasibility(qp, ATdy, CTdz.data(), dy, dz);
@@ -1606,6 +1610,7 @@ qp_solve(QP& qp)
   const isize nc = qp.n_constraints();
   auto t0 = std::chrono::steady_clock::now();
   qp.counters.reset();
+  qp.trace.clear();
   w.ldl.ctr = &qp.counters;
 
   if (w.dirty) {
@@ -1717,6 +1722,10 @@ qp_solve(QP& qp)
       r.info.objValue = objective_value(qp);
       if (qp.verbose_sink)
         qp.verbose_sink(iter + 1, r.info);
+      {
+        const double rec[8] = { 1.0, double(iter + 1), r.info.pri_res, r.info.dua_res, r.info.duality_gap, r.info.mu_in, r.info.rho, 0.0 };
+        qp.trace.insert(qp.trace.end(), rec, rec + 8);
+      }
       sc.scale_primal(r.x.data());
       sc.scale_dual_eq(r.y.data());
       sc.scale_dual_in(r.z.data());

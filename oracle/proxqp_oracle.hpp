@@ -125,6 +125,11 @@ struct QP
   // settings.verbose: called once per outer iteration with the unscaled-iterate statistics the reference
   // prints (solver.hpp:1469-1499); null = the round trip of the iterates happens, nothing is printed
   void (*verbose_sink)(long long outer_iteration, const pqp_info& info) = nullptr;
+  // settings.verbose: the lines the reference prints per iteration, as records of 8 doubles
+  //   outer (solver.hpp:1478-1485): { 1, iter + 1, pri_res, dua_res, duality_gap, mu_in, rho, 0 }
+  //   inner (solver.hpp:1021-1027): { 2, iter + 1, inner residual, alpha, 0, 0, 0, 0 }
+  // cleared at the start of every solve (test infrastructure: the device's per-iteration trace is compared with it)
+  std::vector<double> trace;
 
   QP(isize dim, isize n_eq, isize n_in, bool box, int hessian, int backend);
 

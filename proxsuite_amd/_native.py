@@ -53,7 +53,7 @@ class NativeLib:
                "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_reset_qp", "pqp_batch_flush",
                "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_solve_subset", "pqp_batch_copy_qp", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
                "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs", "pqp_batch_pack_results",
-               "pqp_batch_get_scaled", "pqp_batch_get_schur_factor", "pqp_batch_get_stats", "pqp_batch_last_solve_ms",
+               "pqp_batch_get_scaled", "pqp_batch_get_schur_factor", "pqp_batch_get_stats", "pqp_batch_get_trace", "pqp_batch_last_solve_ms",
                "pqp_batch_launch_config", "pqp_batch_solve_async", "pqp_batch_solve_range_async",
                "pqp_batch_solve_subset_async", "pqp_batch_wait", "pqp_batch_enable_host_results",
                "pqp_batch_host_results", "pqp_batch_host_results_fresh", "pqp_batch_own_stream", "pqp_batch_backward_subset",
@@ -100,6 +100,7 @@ class NativeLib:
         L.pqp_batch_pack_results.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
         L.pqp_batch_get_scaled.argtypes = [vp, C.c_int64] + [_DP] * 9
         L.pqp_batch_get_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.pqp_batch_get_trace.argtypes = [vp, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pqp_batch_get_schur_factor.argtypes = [vp, C.c_int64] + [_DP] * 3 + [C.POINTER(C.c_int32), C.POINTER(C.c_int64), _DP]
         L.pqp_batch_last_solve_ms.argtypes = [vp]
         L.pqp_batch_last_solve_ms.restype = C.c_double
@@ -481,6 +482,17 @@ class Batch:
         a = np.zeros((self.B, PQP_STATS_COUNT), dtype=np.int64)
         self.lib.check(self.lib.L.pqp_batch_get_stats(self._h, a.ctypes.data_as(C.POINTER(C.c_int64))))
         return a
+
+    def trace(self, idx):
+        """settings.verbose: the per-iteration lines of QP idx from the last launch as an (N, 8) array -- rows
+        [1, k, pri_res, dua_res, duality_gap, mu_in, rho, 0] (outer iteration k) and [2, k, inner residual, alpha,
+        0, 0, 0, 0] (inner iteration k), in the order the reference prints them (pqp_batch_get_trace)."""
+        n = C.c_int64(0)
+        self.lib.check(self.lib.L.pqp_batch_get_trace(self._h, int(idx), None, 0, C.byref(n)))
+        out = np.zeros((n.value, 8))
+        if n.value:
+            self.lib.check(self.lib.L.pqp_batch_get_trace(self._h, int(idx), out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def launch_config(self):
         t = C.c_int(0)

@@ -319,6 +319,9 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
     h->lpt = std::string(e) == "lpt";
   h->dev.rep_phase = 0;
   h->dev.rep_count = 1;
+  h->dev.trace = nullptr;
+  h->dev.trace_slot = nullptr;
+  h->dev.trace_cap = 0;
   if (const char* e = std::getenv("PQP_REPEAT_PHASE")) // (only the instrumented build reads them: traffic attribution)
     h->dev.rep_phase = std::atoi(e);
   if (const char* e = std::getenv("PQP_REPEAT_COUNT"))
@@ -455,6 +458,10 @@ pqp_batch_destroy(pqp_batch* h)
     (void)hipStreamDestroy(h->owned_stream);
   for (void* p : h->allocs)
     (void)hipFree(p);
+  if (h->trace_dev)
+    (void)hipFree(h->trace_dev);
+  if (h->trace_slot_dev)
+    (void)hipFree(h->trace_slot_dev);
   if (h->ev0)
     (void)hipEventDestroy(h->ev0);
   if (h->ev1)
@@ -716,9 +723,73 @@ pqp_batch_solve(pqp_batch* h)
   return pqp_batch_solve_range(h, 0, h->dev.B);
 }
 
+constexpr int PQP_TRACE_RECORDS = 4096; // per verbose QP and launch, the header record included (256 KB)
+
+// settings.verbose: the slab of per-iteration records for the verbose QPs of the launch about to be enqueued
+// (pqp::Batch::trace); no verbose QP: the kernel gets a null pointer and the previous trace is dropped
+static int
+prepare_trace(pqp_batch* h, const int64_t* idx, int64_t first, int64_t count)
+{
+  h->dev.trace = nullptr;
+  h->dev.trace_slot = nullptr;
+  h->dev.trace_cap = 0;
+  h->trace_host.clear();
+  int64_t nv = 0;
+  for (int64_t i = 0; i < count; ++i)
+    nv += h->settings[size_t(idx ? idx[i] : first + i)].verbose != 0;
+  if (nv == 0) {
+    h->trace_slot.clear();
+    return PQP_OK;
+  }
+  h->trace_slot.assign(size_t(h->dev.B), -1);
+  int slot = 0;
+  for (int64_t i = 0; i < count; ++i) {
+    const size_t q = size_t(idx ? idx[i] : first + i);
+    if (h->settings[q].verbose != 0)
+      h->trace_slot[q] = slot++;
+  }
+  const size_t slot_bytes = size_t(PQP_TRACE_RECORDS) * 8 * sizeof(double);
+  if (nv > h->trace_slots) {
+    if (h->trace_dev)
+      (void)hipFree(h->trace_dev);
+    h->trace_dev = nullptr;
+    h->trace_slots = 0;
+    HIP_TRY(hipMalloc((void**)&h->trace_dev, size_t(nv) * slot_bytes));
+    h->trace_slots = nv;
+  }
+  if (!h->trace_slot_dev)
+    HIP_TRY(hipMalloc((void**)&h->trace_slot_dev, size_t(h->dev.B) * sizeof(int)));
+  // (synchronous copies: a verbose solve is a debugging run)
+  HIP_TRY(hipMemcpy(h->trace_slot_dev, h->trace_slot.data(), size_t(h->dev.B) * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(h->trace_dev, 0, size_t(nv) * slot_bytes));
+  h->dev.trace = h->trace_dev;
+  h->dev.trace_slot = h->trace_slot_dev;
+  h->dev.trace_cap = PQP_TRACE_RECORDS;
+  return PQP_OK;
+}
+
+// the lines of one traced QP, in the reference's format (dense/solver.hpp:1478-1485 and :1021-1027)
+static void
+print_trace(const double* slot)
+{
+  const int64_t n = int64_t(slot[0]);
+  for (int64_t k = 1; k <= n; ++k) {
+    const double* r = slot + k * 8;
+    if (r[0] == 1.0)
+      std::printf("\033[1;32m[outer iteration %lld]\033[0m\n| primal residual=%.2e | dual residual=%.2e | duality gap=%.2e | "
+                  "mu_in=%.2e | rho=%.2e\n",
+                  (long long)r[1], r[2], r[3], r[4], r[5], r[6]);
+    else
+      std::printf("\033[1;34m[inner iteration %lld]\033[0m\n| inner residual=%.2e | alpha=%.2e\n", (long long)r[1], r[2], r[3]);
+  }
+  if (slot[1] > 0)
+    std::printf("(%lld more iteration lines not recorded: the trace holds %d)\n", (long long)slot[1], PQP_TRACE_RECORDS - 1);
+}
+
 // settings.verbose (reference dense/utils.hpp:33-131 header, dense/solver.hpp:1789-1830 statistics): the
-// whole solve of a QP runs inside one kernel, so there are no per-iteration lines to print; the header and
-// the final statistics block are printed from the returned Info, one block per verbose QP, in index order.
+// whole solve of a QP runs inside one kernel, which records the per-iteration lines of the reference's report
+// (pqp::Batch::trace); the header, those lines and the final statistics block are printed here once the launch has
+// finished, one block per verbose QP, in index order.
 static int
 verbose_report(pqp_batch* h, const int64_t* idx, int64_t first, int64_t count)
 {
@@ -727,6 +798,13 @@ verbose_report(pqp_batch* h, const int64_t* idx, int64_t first, int64_t count)
     any = h->settings[size_t(idx ? idx[i] : first + i)].verbose != 0;
   if (!any)
     return PQP_OK;
+  if (h->dev.trace) {
+    int nv = 0;
+    for (int s : h->trace_slot)
+      nv = std::max(nv, s + 1);
+    h->trace_host.resize(size_t(nv) * PQP_TRACE_RECORDS * 8);
+    HIP_TRY(hipMemcpy(h->trace_host.data(), h->trace_dev, h->trace_host.size() * sizeof(double), hipMemcpyDeviceToHost));
+  }
   const pqp::Dims& d = h->dev.d;
   static const char* const status_name[] = { "Solved", "Maximum number of iterations reached", "Primal infeasible",
                                              "Solved closest primal feasible", "Dual infeasible", "Solver not run" };
@@ -753,6 +831,8 @@ verbose_report(pqp_batch* h, const int64_t* idx, int64_t first, int64_t count)
                   ? "Quadratic Program"
                   : (d.hessian == PQP_HESSIAN_ZERO ? "Linear Program" : "Quadratic Program with diagonal Hessian"),
                 st.compute_preconditioner ? "on" : "off", st.compute_timings ? "on" : "off");
+    if (!h->trace_host.empty() && h->trace_slot[size_t(q)] >= 0)
+      print_trace(h->trace_host.data() + size_t(h->trace_slot[size_t(q)]) * PQP_TRACE_RECORDS * 8);
     std::printf("-------------------SOLVER STATISTICS-------------------\n"
                 "outer iter:     %lld\ntotal iter:     %lld\nmu updates:     %lld\nrho updates:    %lld\n"
                 "objective:      %g\nstatus:         %s\n",
@@ -818,6 +898,8 @@ solve_impl(pqp_batch* h, int64_t first, int64_t count, const int64_t* idx, bool 
   if (int rc = pqp_batch_flush(h))
     return rc;
   if (int rc = upload_settings(h))
+    return rc;
+  if (int rc = prepare_trace(h, idx, first, count))
     return rc;
   int rc = 0;
   if (idx) {
@@ -1335,6 +1417,26 @@ pqp_batch_get_stats(pqp_batch* h, int64_t* stats)
     return rc;
   PQP_ON_DEVICE(h->device);
   HIP_TRY(hipMemcpy(stats, h->dev.stats, size_t(h->dev.B) * pqp::ST_COUNT * sizeof(int64_t), hipMemcpyDefault));
+  return PQP_OK;
+}
+
+int
+pqp_batch_get_trace(pqp_batch* h, int64_t idx, double* records, int64_t capacity, int64_t* n_records)
+{
+  if (!h || !n_records)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
+  if (idx < 0 || idx >= h->dev.B)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+  if (int rc = settle(h))
+    return rc;
+  *n_records = 0;
+  if (h->trace_host.empty() || h->trace_slot.empty() || h->trace_slot[size_t(idx)] < 0)
+    return PQP_OK; // the last launch did not trace this QP (settings.verbose was off)
+  const double* slot = h->trace_host.data() + size_t(h->trace_slot[size_t(idx)]) * PQP_TRACE_RECORDS * 8;
+  const int64_t n = int64_t(slot[0]);
+  *n_records = n;
+  if (records && capacity > 0)
+    std::memcpy(records, slot + 8, size_t(std::min(n, capacity)) * 8 * sizeof(double));
   return PQP_OK;
 }
 

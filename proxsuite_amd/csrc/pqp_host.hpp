@@ -72,6 +72,14 @@ struct pqp_batch
   std::vector<void*> host_allocs;
   double *m_x = nullptr, *m_y = nullptr, *m_z = nullptr, *m_se = nullptr, *m_si = nullptr; // host addresses of the mirrors
   pqp_info* m_info = nullptr;
+  // settings.verbose: per-iteration trace of the last launch (pqp::Batch::trace).  The slab holds one slot of
+  // PQP_TRACE_RECORDS records per verbose QP of the launch and grows on demand; trace_host is its copy on the host,
+  // fetched when the solve is settled (verbose_report) and served by pqp_batch_get_trace.
+  double* trace_dev = nullptr;
+  int64_t trace_slots = 0; // capacity of the slab, in slots
+  int* trace_slot_dev = nullptr;
+  std::vector<int> trace_slot;   // [B], -1 = QP not traced by the last launch
+  std::vector<double> trace_host;
   hipStream_t stream = nullptr; // launch stream (pqp_batch_set_stream); null = default stream
   hipStream_t owned_stream = nullptr; // pqp_batch_own_stream: a non-blocking stream created for (and destroyed with) the handle
   double* vec_scratch = nullptr; // non-null: per-QP vectors live in HBM (B slices of lds_solve bytes), see pqp_kernels.hip TU 9

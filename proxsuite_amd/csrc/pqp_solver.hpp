@@ -243,6 +243,13 @@ struct Batch
   // solve_in_parallel returns).  Null = off.
   double *hx, *hy, *hz, *hse, *hsi;
   pqp_info* hinfo;
+  // settings.verbose: the per-iteration lines of the reference's report (solver.hpp:1478-1485 outer, :1021-1027
+  // inner) as records of 8 doubles, written by thread 0 of the QP's workgroup and printed / handed out by the host
+  // after the launch (pqp_batch_get_trace).  trace_slot[q] = slab slot of QP q (-1: not verbose); slot layout:
+  // record 0 = { records written, records dropped, ... }, then the lines.  Null = no verbose QP in this launch.
+  double* trace;
+  const int* trace_slot;
+  int trace_cap;
 };
 
 // QPLayer backward (reference dense/compute_ECJ.hpp): inputs and outputs of one launch.
@@ -1204,6 +1211,30 @@ struct Solver
     if (threadIdx.x == 0)
       L.stat()[which] += v;
 #endif
+  }
+  // settings.verbose: one record per line the reference prints (Batch::trace)
+  __device__ __forceinline__ void trace_line(double kind, double idx, double a, double b, double c, double d4, double e)
+  {
+    if (batch.trace == nullptr || threadIdx.x != 0)
+      return;
+    const int slot = batch.trace_slot[q];
+    if (slot < 0)
+      return;
+    gptr t = (gptr)(batch.trace + (long)slot * batch.trace_cap * 8);
+    const int k = (int)t[0];
+    if (k + 1 >= batch.trace_cap) {
+      t[1] += 1.0;
+      return;
+    }
+    gptr r = t + (long)(k + 1) * 8;
+    r[0] = kind;
+    r[1] = idx;
+    r[2] = a;
+    r[3] = b;
+    r[4] = c;
+    r[5] = d4;
+    r[6] = e;
+    t[0] = double(k + 1);
   }
   // compulsory HBM bytes of the engine (one pass over a matrix = its size; no reuse assumed)
   __device__ __forceinline__ void bytes(long long b) { count(ST_BYTES_ENGINE, b); }
@@ -3884,6 +3915,8 @@ struct Solver
         double e;
         saddle_point_and_certificates(do_cert, e, is_primal_infeasible, is_dual_infeasible);
         err_in = e;
+        if (PQP_UNLIKELY(st.verbose != 0))
+          trace_line(2.0, double(iter + 1), e, alpha, 0.0, 0.0, 0.0);
         sub_toc(ST_CYC_CERT);
         if (PQP_UNLIKELY(is_primal_infeasible)) {
           info.status = PQP_PRIMAL_INFEASIBLE;
@@ -4226,7 +4259,8 @@ struct Solver
           // solver.hpp:1469-1510: `verbose` is not only printing -- the reference unscales x, y, z for its report and
           // scales them back, the identity up to rounding only: a verbose run perturbs the iterates in their last
           // bits at every outer iteration (test/src/dense_qp_wrapper.cpp:7178 runs its closest-feasible family that
-          // way).  Same round trip here (the report itself is printed by the host from the final Info).
+          // way).  Same round trip here; the line the reference prints goes to the trace (the host prints it).
+          trace_line(1.0, double(info.iter_ext + 1), info.pri_res, info.dua_res, info.duality_gap, info.mu_in, info.rho);
           cgptr dx = P.dlt_x(), de = P.dlt_eq(), di = P.dlt_in();
           for (int k = threadIdx.x; k < n; k += NT)
             L.x()[k] = (L.x()[k] * dx[k]) / dx[k];

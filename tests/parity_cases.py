@@ -145,6 +145,101 @@ def case_verbose_round_trip(lib, oracle, randqp, n=20, ne=5, ni=8, B=3):
     b.close()
 
 
+def case_verbose_trace(lib, oracle, randqp, capfd=None, n=20, ne=5, ni=8, B=4, box=False):
+    """settings.verbose: the per-iteration lines of the reference's report (dense/solver.hpp:1478-1485 outer,
+    :1021-1027 inner).  The device records them inside the solve kernel (pqp_batch_get_trace) and the library prints
+    them when the launch has finished; the oracle records the same lines where the reference prints them.  Line by
+    line: same sequence of outer / inner iterations with the same numbers k, residuals within the gate of the final Info
+    (INFO_RES + 1e-6 relative), step lengths to 1e-6, mu_in and rho EQUAL -- the device follows the reference's path at every iteration, not only
+    to the same end.  QP 1 is left non-verbose: no trace, no lines.  A second, warm-started solve replaces the trace."""
+    m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2, seed0=77)
+    lb = ub = None
+    if box:
+        # a box around the solution of the QP without it: feasible by construction, for the second solve (other g) too,
+        # where some of its sides become active.  (On an infeasible instance the two sides stagnate at the rounding
+        # floor and leave their inner loops after different numbers of iterations: nothing to compare line by line.)
+        rng = np.random.default_rng(5)
+        xs = np.stack([q.results.x for q in oracle_solve_many(oracle, [(m.H[i], m.g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i])
+                                                                        for i in range(B)], n, ne, ni)])
+        sh = rng.uniform(0.02, 0.5, (B, n))
+        lb, ub = xs - sh, xs + sh
+    b = N.Batch(B, n, ne, ni, box_constraints=box, lib=lib)
+    settings_all(b, eps_abs=EPS, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS), verbose=1)
+    b.settings(1).verbose = 0
+    kw = dict(l_box=lb, u_box=ub) if box else {}
+    b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u, **kw)
+    qs = []
+    for i in range(B):
+        q = oracle.QP(n, ne, ni, box_constraints=box)
+        q.settings.eps_abs, q.settings.eps_rel = EPS, 0
+        q.settings.initial_guess = InitialGuess.NO_INITIAL_GUESS
+        q.settings.verbose = 0 if i == 1 else 1
+        q.init(m.H[i], m.g[i], m.A[i], m.b[i], m.C[i], m.l[i], m.u[i], **(dict(l_box=lb[i], u_box=ub[i]) if box else {}))
+        qs.append(q)
+    lines = truncated = 0
+    for phase in (0, 1):
+        if phase == 1:
+            g2 = m.g * 1.25
+            for i in range(B):
+                b.settings(i).initial_guess = int(InitialGuess.WARM_START_WITH_PREVIOUS_RESULT)
+                qs[i].settings.initial_guess = InitialGuess.WARM_START_WITH_PREVIOUS_RESULT
+                qs[i].update(g=g2[i])
+            b.update(-1, g=g2)
+        if capfd is not None:
+            capfd.readouterr()
+        b.solve()
+        out = capfd.readouterr().out if capfd is not None else None
+        x, y, z, se, si, info = b.results()
+        for i, q in enumerate(qs):
+            q.solve()
+            t, to = b.trace(i), q.trace()
+            if i == 1:
+                assert t.shape[0] == 0 and to.shape[0] == 0
+                continue
+            if t.shape[0] == 4095 and to.shape[0] > 4095:
+                to = to[:4095]  # (an instance that runs long: the device keeps the first 4095 lines and counts the rest)
+                truncated += 1
+            assert t.shape == to.shape and t.shape[0] > 0, (phase, i, t.shape, to.shape)
+            assert q.results.info.status == QPSolverOutput.PROXQP_SOLVED, (phase, i)
+            assert np.array_equal(t[:, :2], to[:, :2]), (phase, i)  # same kinds, same iteration numbers
+            outer = t[:, 0] == 1
+            assert np.array_equal(t[outer, 5:7], to[outer, 5:7]), (phase, i)  # mu_in, rho
+            tol = INFO_RES + 1e-6 * np.abs(to[:, 2:5])  # (the gate of the final Info residuals, info_close)
+            # (the step length of an inner iteration is a ratio of two sums that both vanish at the solution: on the
+            # last steps, with |dw| ~ 1e-9, two orders of summation give alpha = 1 +- 1e-8)
+            tol[~outer, 1] = 1e-6 * (1 + np.abs(to[~outer, 3]))
+            # (the inner residual of the last steps of a Newton loop sits at the rounding floor of sums of magnitude
+            # |H| |x|: 1.3e-8 against 2.6e-9 on a C2-sized QP whose first inner residual is ~1e1; the floor scales with it)
+            tol[~outer, 0] += 1e-8 * max(1.0, float(np.max(to[~outer, 2], initial=0.0)))
+            err = np.abs(t[:, 2:5] - to[:, 2:5]) / tol
+            k = np.unravel_index(int(np.argmax(err)), err.shape)
+            assert np.max(err) <= 1.0, (phase, i, k, t[k[0]].tolist(), to[k[0]].tolist())
+            # the trace is the solve: an outer line per outer iteration Info counts (+ the one that found the solution),
+            # an inner line per inner iteration -- less the iterations the reference leaves before its print (the
+            # |alpha dw| < 1e-11 exit of solver.hpp:944-951, an infeasibility exit)
+            n_out, n_inn = int(outer.sum()), int((~outer).sum())
+            assert 1 <= n_out <= info[i].iter_ext + 1 and n_inn <= info[i].iter, (phase, i, n_out, n_inn, info[i].iter_ext, info[i].iter)
+            if info[i].status == QPSolverOutput.PROXQP_SOLVED:
+                assert n_out == info[i].iter_ext + 1, (phase, i)
+            ri = q.results.info
+            assert (info[i].status, info[i].iter, info[i].iter_ext, info[i].mu_updates) == (ri.status, ri.iter, ri.iter_ext, ri.mu_updates)
+            assert abs(info[i].objValue - ri.objValue) <= 1e-7 * (1 + abs(ri.objValue)), (phase, i)
+            lines += t.shape[0]
+        if out is not None:
+            # the library printed exactly these lines, in the reference's wording, for the three verbose QPs
+            n_outer = sum(int((b.trace(i)[:, 0] == 1).sum()) for i in range(B))
+            n_inner = sum(int((b.trace(i)[:, 0] == 2).sum()) for i in range(B))
+            assert out.count("[outer iteration ") == n_outer and out.count("| primal residual=") == n_outer
+            assert out.count("[inner iteration ") == n_inner and out.count("| inner residual=") == n_inner
+            assert out.count("SOLVER STATISTICS") == B - 1
+            assert out.count("more iteration lines not recorded") == sum(1 for i in range(B) if b.trace(i).shape[0] == 4095)
+            t0 = b.trace(0)
+            first = "| primal residual=%.2e | dual residual=%.2e | duality gap=%.2e | mu_in=%.2e | rho=%.2e" % tuple(t0[0, 2:7])
+            assert first in out, first
+    b.close()
+    return lines
+
+
 def oracle_solve_many(oracle, models, n, ne, ni, guess=InitialGuess.NO_INITIAL_GUESS, eps=EPS, **qpkw):
     """init + solve_in_parallel of the oracle on a list of (H, g, A, b, C, l, u[, l_box, u_box])."""
     qs = []

@@ -125,6 +125,11 @@ def test_verbose_round_trip(lib, oracle, randqp, capfd):
     capfd.readouterr()  # (the host-side report of the verbose QPs)
 
 
+def test_verbose_trace(lib, oracle, randqp, capfd):
+    """per-iteration lines of settings.verbose: recorded by the kernel, equal to the oracle's line by line, printed"""
+    assert pc.case_verbose_trace(lib, oracle, randqp, capfd) > 20
+
+
 def test_closest_feasible(lib, oracle, randqp):
     """seeds whose oracle run is short enough for the emulator (the GPU test runs all 20)"""
     seen = pc.case_closest_feasible(lib, oracle, randqp, seeds=range(6), max_oracle_iter_ext=60)

@@ -190,6 +190,14 @@ def test_verbose_round_trip(lib, oracle, randqp, capfd):
     capfd.readouterr()  # (the host-side report of the verbose QPs)
 
 
+def test_verbose_trace(lib, oracle, randqp, capfd):
+    """per-iteration lines of settings.verbose: recorded by the kernel, equal to the oracle's line by line, printed"""
+    assert pc.case_verbose_trace(lib, oracle, randqp, capfd) > 20
+    # C2-sized QPs, and box constraints through the 512-thread kernel
+    assert pc.case_verbose_trace(lib, oracle, randqp, capfd, n=100, ne=50, ni=100, B=4) > 40
+    assert pc.case_verbose_trace(lib, oracle, randqp, capfd, n=60, ne=10, ni=40, B=4, box=True) > 20
+
+
 def test_closest_feasible(lib, oracle, randqp):
     """reference test/src/dense_qp_wrapper.cpp:7153-7215, all 20 seeds, with and without
     primal_infeasibility_solving"""
