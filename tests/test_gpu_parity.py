@@ -194,7 +194,7 @@ def test_verbose_trace(lib, oracle, randqp, capfd):
     """per-iteration lines of settings.verbose: recorded by the kernel, equal to the oracle's line by line, printed"""
     assert pc.case_verbose_trace(lib, oracle, randqp, capfd) > 20
     # C2-sized QPs, and box constraints through the 512-thread kernel
-    assert pc.case_verbose_trace(lib, oracle, randqp, capfd, n=100, ne=50, ni=100, B=4) > 40
+    assert pc.case_verbose_trace(lib, oracle, randqp, capfd, n=100, ne=50, ni=100, B=16) > 400
     assert pc.case_verbose_trace(lib, oracle, randqp, capfd, n=60, ne=10, ni=40, B=4, box=True) > 20
 
 
