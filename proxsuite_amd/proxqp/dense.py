@@ -35,6 +35,12 @@ __all__ = ["QP", "BatchQP", "VectorQP", "VectorLossDerivatives", "solve_in_paral
            "EigenValueEstimateMethodOption", "DenseBackend", "HessianType", "InitialGuess",
            "QPSolverOutput", "MeritFunctionType", "Settings", "Results", "Info", "Model", "BackwardData"]
 
+# (nanobind `.export_values()`, bindings/python/src/expose-qpobject.hpp:28-38: proxsuite.proxqp.dense.PrimalDualLDLT,
+# proxsuite.proxqp.dense.Diagonal, ... exist beside the enum classes)
+for _e in (DenseBackend, HessianType):
+    globals().update(_e.__members__)
+del _e
+
 _BOOL_SETTINGS = ("verbose", "update_preconditioner", "compute_preconditioner", "compute_timings",
                   "check_duality_gap", "bcl_update", "primal_infeasibility_solving")
 _ENUM_SETTINGS = {"initial_guess": InitialGuess, "merit_function_type": MeritFunctionType}
