@@ -3,15 +3,16 @@ from .._ctypes_defs import (DenseBackend, EigenValueEstimateMethodOption, Hessia
                             MeritFunctionType, QPSolverOutput)
 from . import dense
 
+__all__ = ["dense", "DenseBackend", "EigenValueEstimateMethodOption", "HessianType", "InitialGuess", "MeritFunctionType", "QPSolverOutput",
+           "omp_get_max_threads"]
+
 # the reference's bindings export the members of these enums into the module scope as well (nanobind
 # `.export_values()`, bindings/python/src/expose-results.hpp:23-31, expose-settings.hpp:22-47):
 # proxsuite.proxqp.PROXQP_SOLVED, proxsuite.proxqp.NO_INITIAL_GUESS, ...
 for _e in (QPSolverOutput, InitialGuess, MeritFunctionType, EigenValueEstimateMethodOption):
     globals().update(_e.__members__)
+    __all__ += list(_e.__members__)
 del _e
-
-__all__ = ["dense", "DenseBackend", "EigenValueEstimateMethodOption", "HessianType", "InitialGuess", "MeritFunctionType", "QPSolverOutput",
-           "omp_get_max_threads"]
 
 
 def omp_get_max_threads() -> int:
