@@ -759,9 +759,9 @@ prepare_trace(pqp_batch* h, const int64_t* idx, int64_t first, int64_t count)
   }
   if (!h->trace_slot_dev)
     HIP_TRY(hipMalloc((void**)&h->trace_slot_dev, size_t(h->dev.B) * sizeof(int)));
-  // (synchronous copies: a verbose solve is a debugging run)
+  // (a synchronous copy: a verbose solve is a debugging run)
   HIP_TRY(hipMemcpy(h->trace_slot_dev, h->trace_slot.data(), size_t(h->dev.B) * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(h->trace_dev, 0, size_t(nv) * slot_bytes));
+  HIP_TRY(hipMemsetAsync(h->trace_dev, 0, size_t(nv) * slot_bytes, h->stream)); // (on the launch stream: ordered in front of the kernel)
   h->dev.trace = h->trace_dev;
   h->dev.trace_slot = h->trace_slot_dev;
   h->dev.trace_cap = PQP_TRACE_RECORDS;

@@ -115,9 +115,9 @@ def test_rows_beyond_the_workgroup(oracle, randqp):
 
 
 def test_seed14_mechanism_on_the_emulated_device(lib, randqp):
-    """(three phases of the cycle here -- the emulator is slow; the MI355X run sweeps the full period)"""
-    n_ok, n = pc.case_seed14_mechanism(lib, randqp, guards=(41, 46, 52), max_iter=2500)
-    assert n == 3
+    """(two phases of the cycle here -- the emulator is slow; the MI355X run sweeps the full period)"""
+    n_ok, n = pc.case_seed14_mechanism(lib, randqp, guards=(41, 52), max_iter=2500)
+    assert n == 2
 
 
 def test_verbose_round_trip(lib, oracle, randqp, capfd):
