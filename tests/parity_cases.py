@@ -501,6 +501,55 @@ def case_maros_meszaros(lib, P, q, A, l, u):
     bt.close()
 
 
+def case_maros_meszaros_path(lib, oracle, problems):
+    """The PATH on the Maros-Meszaros problems (settings of reference test/src/dense_maros_meszaros.cpp:85-169, plus
+    verbose): the device's per-iteration trace against the oracle's.  Returns (names whose traces have the same
+    sequence of outer / inner iterations with equal mu_in / rho on every outer line, {name: (first differing line,
+    lines)} of the others).  Every problem must end SOLVED on both sides with the same number of mu updates; where
+    the paths fork (the degenerate LP-like Q* problems: their first KKT system is ill-conditioned -- QAFIRO starts with a
+    primal residual of 8e6 -- and the block-elimination engine of the device and the LDL^T of the assembled KKT matrix
+    of the oracle solve it to the refinement tolerance, 1e-7 relative apart, not to the same bits), the iteration counts
+    stay within 10 % of each other."""
+    from conftest import split_maros
+    import os
+    same, forks = [], {}
+    devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)  # (the library prints the lines it recorded)
+    try:
+        for name, (P, q, A, l, u) in problems.items():
+            H, g, Aeq, b, C, lin, uin = split_maros(P, q, A, l, u)
+            n, ne, ni = H.shape[0], Aeq.shape[0], C.shape[0]
+            bt = N.Batch(1, n, ne, ni, lib=lib)
+            bt.init(0, H, g, Aeq, b, C, lin, uin)
+            qo = oracle.QP(n, ne, ni)
+            for st in (bt.settings(0), qo.settings):
+                st.eps_abs, st.eps_rel, st.eps_primal_inf, st.eps_dual_inf, st.max_iter, st.verbose = 2e-8, 0, 1e-12, 1e-12, 1000, 1
+            qo.init(H, g, Aeq, b, C, lin, uin)
+            os.dup2(devnull, 1)
+            try:
+                bt.solve()
+            finally:
+                os.dup2(saved, 1)
+            qo.solve()
+            t, to = bt.trace(0), qo.trace()
+            info, ri = bt.results(0)[5], qo.results.info
+            assert info.status == ri.status == QPSolverOutput.PROXQP_SOLVED, (name, info.status, ri.status)
+            m = min(len(t), len(to))
+            eq = np.all(t[:m, :2] == to[:m, :2], axis=1)
+            if len(t) == len(to) and eq.all():
+                outer = t[:, 0] == 1
+                assert np.array_equal(t[outer, 5:7], to[outer, 5:7]), name
+                assert (info.iter, info.iter_ext, info.mu_updates) == (ri.iter, ri.iter_ext, ri.mu_updates), name
+                same.append(name)
+            else:
+                forks[name] = (int(np.argmin(eq)) if not eq.all() else m, len(to))
+                assert abs(info.iter - ri.iter) <= max(2, 0.1 * ri.iter), (name, info.iter, ri.iter)
+            bt.close()
+    finally:
+        os.close(devnull)
+        os.close(saved)
+    return same, forks
+
+
 def case_errors(lib):
     """reference error convention (SURVEY.md 8b): std::invalid_argument -> ValueError."""
     import pytest

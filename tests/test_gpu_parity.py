@@ -84,6 +84,17 @@ def test_maros_meszaros_small(lib):
         pc.case_maros_meszaros(lib, *(d["%s/%s" % (name, k)] for k in "PqAlu"))
 
 
+def test_maros_meszaros_small_path(lib, oracle):
+    """the same 33 problems, iteration by iteration against the oracle (settings.verbose trace): 27 walk the oracle's
+    path line for line; QADLITTL, QAFIRO, QISRAEL, QPCBOEI2, QSCAGR7, QSHARE2B (ill-conditioned LP-like problems, see
+    the case) leave it and end SOLVED within a few iterations of it"""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maros_meszaros_small.npz"))
+    probs = {str(name): tuple(d["%s/%s" % (name, k)] for k in "PqAlu") for name in d["names"]}
+    same, forks = pc.case_maros_meszaros_path(lib, oracle, probs)
+    print("same path:", len(same), "forks:", forks)
+    assert len(same) + len(forks) == len(probs) and len(same) >= 24, (len(same), forks)
+
+
 def _medium_names():
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maros_meszaros_medium.npz"))
     return [str(s) for s in d["names"]]
