@@ -89,6 +89,7 @@ launch_solve(pqp_batch* h)
 // SPEC = 1: no box constraints and a dense Hessian, both known at compile time
 int pqp_launch_solve_256_s1(pqp_batch* h);
 int pqp_launch_solve_256_s1_lat(pqp_batch* h);
+int pqp_launch_solve_256_s1_one(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_256_s2(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
@@ -109,6 +110,16 @@ int
 pqp_launch_solve_256_s1_lat(pqp_batch* h)
 {
   return launch_solve<256, PQP_WPS_256, 1>(h);
+}
+#endif
+// One workgroup per CU: a launch of no more workgroups than the device has CUs (C1: 128 QPs, a single QP::solve())
+// leaves every QP a CU of its own, so the whole register file of a SIMD may go to its wavefront -- no spills at all
+// (100 spilled VGPRs at three per CU).  C1: 1.318 -> 1.245 ms (profiles/r04_ab_small_launch_budget.txt).
+#if PQP_TU_HAS(13)
+int
+pqp_launch_solve_256_s1_one(pqp_batch* h)
+{
+  return launch_solve<256, 1, 1>(h);
 }
 #endif
 #if PQP_TU_HAS(2)
@@ -357,6 +368,8 @@ pqp_launch_solve(pqp_batch* h)
       // launch is latency-bound and the build with the larger register budget is faster per QP
       if (h->range_count > 3L * h->n_cu && 4 * h->lds_solve <= 160 * 1024)
         return pqp_launch_solve_256_s1(h);
+      if (h->range_count <= (long)h->n_cu)
+        return pqp_launch_solve_256_s1_one(h); // a CU per QP: the whole register file
       return pqp_launch_solve_256_s1_lat(h);
     case 512:
       // (same rule as for 256 threads: the smaller register budget only when it buys a second resident workgroup)

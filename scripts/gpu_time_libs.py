@@ -1,6 +1,6 @@
 """Kernel time of the solve (HIP events, pqp_batch_last_solve_ms) for several builds of the library on one box,
 interleaved -- uses only the entries every build since round 1 has, so old and new libraries can be compared:
-  python scripts/gpu_time_libs.py <workload> <rounds> lib1.so lib2.so ..."""
+  python scripts/gpu_time_libs.py <workload> <rounds> lib1.so lib2.so ...        (B=<n> in the environment: other batch size)"""
 import os
 import sys
 import numpy as np
@@ -10,6 +10,7 @@ from proxsuite_amd import _native as N
 
 wl, rounds, libs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
 B, n, ne, ni, kind = bench.WORKLOADS[wl]
+B = int(os.environ.get("B", B))
 w = bench.Workload(kind, B, n, ne, ni)
 args, kw = w.init_args()
 res = {l: [] for l in libs}
