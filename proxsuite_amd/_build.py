@@ -52,7 +52,7 @@ def build_randqp(force: bool = False) -> Path:
 # pqp_kernels.hip is compiled once per kernel family (see its header): every solve kernel is
 # ~350 KB of inlined code and takes about a minute of hipcc time, so the objects are built in
 # parallel and linked into one shared library.
-KERNEL_TUS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13)
+KERNEL_TUS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 14)
 OBJ_DIR = ROOT / "build" / "obj"
 
 

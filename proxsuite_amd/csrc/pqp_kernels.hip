@@ -90,6 +90,7 @@ launch_solve(pqp_batch* h)
 int pqp_launch_solve_256_s1(pqp_batch* h);
 int pqp_launch_solve_256_s1_lat(pqp_batch* h);
 int pqp_launch_solve_256_s1_one(pqp_batch* h);
+int pqp_launch_solve_256_s0_one(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_256_s2(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
@@ -120,6 +121,13 @@ int
 pqp_launch_solve_256_s1_one(pqp_batch* h)
 {
   return launch_solve<256, 1, 1>(h);
+}
+#endif
+#if PQP_TU_HAS(14)
+int
+pqp_launch_solve_256_s0_one(pqp_batch* h) // (the same for the general kernel: boxes, sparse Hessian types, PrimalLDLT)
+{
+  return launch_solve<256, 1, 0>(h);
 }
 #endif
 #if PQP_TU_HAS(2)
@@ -362,7 +370,9 @@ pqp_launch_solve(pqp_batch* h)
         bool all_diag = pqp::diag_structure_signature(dd.hessian, dd.n_eq, dd.n_in, dd.box) && !h->c_diag.empty();
         for (size_t q = 0; all_diag && q < h->c_diag.size(); ++q)
           all_diag = h->c_diag[q] != 0;
-        return all_diag ? pqp_launch_solve_256_s2(h) : pqp_launch_solve_256_s0(h);
+        if (all_diag)
+          return pqp_launch_solve_256_s2(h);
+        return (h->range_count <= (long)h->n_cu) ? pqp_launch_solve_256_s0_one(h) : pqp_launch_solve_256_s0(h);
       }
       // more workgroups than three per CU can hold at once: the four-per-CU build; otherwise the
       // launch is latency-bound and the build with the larger register budget is faster per QP
