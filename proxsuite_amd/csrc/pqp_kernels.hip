@@ -91,6 +91,7 @@ int pqp_launch_solve_256_s1(pqp_batch* h);
 int pqp_launch_solve_256_s1_lat(pqp_batch* h);
 int pqp_launch_solve_256_s1_one(pqp_batch* h);
 int pqp_launch_solve_256_s0_one(pqp_batch* h);
+int pqp_launch_solve_256_s1_two(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_256_s2(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
@@ -121,6 +122,13 @@ int
 pqp_launch_solve_256_s1_one(pqp_batch* h)
 {
   return launch_solve<256, 1, 1>(h);
+}
+#endif
+#if PQP_TU_HAS(15)
+int
+pqp_launch_solve_256_s1_two(pqp_batch* h) // (up to two workgroups per CU: 256 VGPRs; 384 / 512 QPs of the C2 shape -3 %)
+{
+  return launch_solve<256, 2, 1>(h);
 }
 #endif
 #if PQP_TU_HAS(14)
@@ -380,6 +388,8 @@ pqp_launch_solve(pqp_batch* h)
         return pqp_launch_solve_256_s1(h);
       if (h->range_count <= (long)h->n_cu)
         return pqp_launch_solve_256_s1_one(h); // a CU per QP: the whole register file
+      if (h->range_count <= 2L * h->n_cu)
+        return pqp_launch_solve_256_s1_two(h);
       return pqp_launch_solve_256_s1_lat(h);
     case 512:
       // (same rule as for 256 threads: the smaller register budget only when it buys a second resident workgroup)

@@ -118,10 +118,12 @@ def test_determinism(lib, randqp):
 
 
 @pytest.mark.parametrize("shape", [(100, 50, 100, 1024, 256, False), (100, 50, 100, 1024, 512, False),
+                                   (100, 50, 100, 1024, 768, False),
                                    (40, 5, 300, 320, 64, False), (100, 200, 200, 320, 64, True)])
 def test_launch_size_invariance(lib, randqp, shape):
     """1024 QPs in one launch (four workgroups per CU, pqp_solve_kernel<256,4,1>) against the same QPs in
-    launches of 256 (a CU per QP: <256,1,1>, the whole register file) and of 512 (<256,3,1>); 320 QPs of two
+    launches of 256 (a CU per QP: <256,1,1>, the whole register file), of 512 (two per CU: <256,2,1>) and of 768
+    (<256,3,1>); 320 QPs of two
     512-thread shapes in one launch (<512,4,.>) against launches of 64 (<512,2,.>), the boxed one on the PrimalLDLT
     engine: bit-identical."""
     n, ne, ni, B, chunk, box = shape
