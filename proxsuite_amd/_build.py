@@ -154,7 +154,10 @@ def kernel_resources(tag: str = "default") -> dict:
     """what the last build of `tag` recorded (see parse_kernel_resources)"""
     import json
     p = OBJ_DIR / tag / "kernel_resources.json"
-    return json.loads(p.read_text()) if p.exists() else {}
+    rec = json.loads(p.read_text()) if p.exists() else {}
+    # (the record accumulates over builds: entries of translation units that no longer exist are dropped)
+    live = {"kernels_%d.o" % k for k in KERNEL_TUS}
+    return {k: v for k, v in rec.items() if v.get("object") in live}
 
 
 def build_hip_stats(force: bool = False) -> Path:
