@@ -743,18 +743,27 @@ write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool dia
 // ---------------------------------------------------------------------------
 // Ruiz equilibration, reference preconditioner/ruiz.hpp:29-311.  The cumulative
 // scaling S stays in LDS and every sweep takes its norms from the UNSCALED model
-// with S applied on the fly: two read-only coalesced passes per sweep instead of
-// a read-modify-write of H, A and C.
+// with S applied on the fly (read-only coalesced passes instead of a read-modify-write
+// of H, A and C).  One pass per sweep over each matrix:
+//   * A and C: a wavefront per row gives the row norm, and the same loads feed per-lane column maxima that meet
+//     across the wavefronts in LDS (`cpart`, NT / 64 x 256 doubles; columns in blocks of 256);
+//   * H: a thread per column; with a dense H the cost scaling gamma of a sweep (ruiz.hpp:256-303) is a function of
+//     the column maxima of H under the UPDATED scaling -- exactly what the next sweep's column pass computes first --
+//     so it is taken there, one sweep late (c is not used inside the loop for a dense H), and by a pass of its own
+//     only after the last sweep.
+// (Round 3 read A and C twice and H twice per sweep: 3.5 ms per 2048 C2 QPs; the maxima are exact and the sums keep
+// their order, so S and c are the same bits.)
 // ---------------------------------------------------------------------------
 template<int NT>
 __device__ __forceinline__ double
-ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl, Reducer<NT>& R)
+ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl, Reducer<NT>& R, lptr cpart)
 {
   const QpRef P(batch, q);
   const Dims& d = batch.d;
   const int n = d.n, ne = d.n_eq, ni = d.n_in, ntot = d.ntot;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   constexpr int NW = NT / WAVE;
+  constexpr int CB = 4 * WAVE; // columns per block of the A / C pass
   double c = 1, gamma = 1;
   for (int k = threadIdx.x; k < ntot; k += NT) {
     S[k] = 1.0;
@@ -769,6 +778,8 @@ ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl
   cgptr A = P.A();
   cgptr C = P.C();
   const bool infeas = st.primal_infeasibility_solving != 0;
+  const bool dense = d.hessian == PQP_HESSIAN_DENSE;
+  bool gamma_owed = false; // dense H: the cost scaling of the last sweep has not been taken yet
   long iter = 1;
   while (true) {
     double e = 0;
@@ -780,48 +791,81 @@ ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl
     if (iter == st.preconditioner_max_iter)
       break;
     ++iter;
-    // column norms of [H; A; C] under the current scaling: thread per column
+    __syncthreads(); // (dl is rewritten below: everybody has read it)
+    // A and C, once: row norms (raw maxima in dl[n + r] for now) and column maxima max_r S_r |M_rk| (in dl[k], k < n)
+    for (int c0 = 0; c0 < n; c0 += CB) {
+      double cm[4] = { 0.0, 0.0, 0.0, 0.0 };
+      for (int r = wid; r < ne + ni; r += NW) {
+        cgptr row = (r < ne) ? (A + (long)r * n) : (C + (long)(r - ne) * n);
+        const double sr = (r < ne) ? Se[r] : Si[r - ne];
+        double m = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = c0 + lane + WAVE * u;
+          if (k < n) {
+            const double v = fabs(row[k]);
+            m = fmax(m, v * Sx[k]);
+            cm[u] = fmax(cm[u], sr * v);
+          }
+        }
+        if (!infeas) {
+          m = wave_max(m);
+          if (lane == 0)
+            dl[n + r] = (c0 == 0) ? m : fmax(dl[n + r], m);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        cpart[wid * CB + lane + WAVE * u] = cm[u];
+      __syncthreads();
+      for (int j = threadIdx.x; j < CB && c0 + j < n; j += NT) {
+        double a = cpart[j];
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+          a = fmax(a, cpart[w * CB + j]);
+        dl[c0 + j] = a;
+      }
+      __syncthreads();
+    }
+    if (ne + ni == 0) {
+      for (int k = threadIdx.x; k < n; k += NT)
+        dl[k] = 0.0;
+      __syncthreads();
+    }
+    // columns: H (thread per column) joined with the maxima of A and C
+    double acc = 0;
     for (int k = threadIdx.x; k < n; k += NT) {
       double m = 0;
-      if (d.hessian == PQP_HESSIAN_DENSE) {
+      if (dense) {
         double hm = 0;
         for (int i = 0; i < n; ++i)
           hm = fmax(hm, Sx[i] * fabs(H[(long)i * n + k]));
         m = hm * Sx[k];
+        acc += m; // = hm * Sx[k]: the term of the owed gamma
       } else if (d.hessian == PQP_HESSIAN_DIAGONAL) {
         m = fabs(H[(long)k * n + k]) * Sx[k] * Sx[k] * c;
       }
-      double am = 0;
-      for (int i = 0; i < ne; ++i)
-        am = fmax(am, Se[i] * fabs(A[(long)i * n + k]));
-      if (ne > 0)
-        m = fmax(m, am * Sx[k]);
-      double cm = 0;
-      for (int i = 0; i < ni; ++i)
-        cm = fmax(cm, Si[i] * fabs(C[(long)i * n + k]));
-      if (ni > 0)
-        m = fmax(m, cm * Sx[k]);
+      if (ne + ni > 0)
+        m = fmax(m, dl[k] * Sx[k]); // max(am, cm) * Sx[k] = max(am * Sx[k], cm * Sx[k]): rounding is monotone
       if (d.box)
         m = fmax(m, Sx[k] * Sb[k]);
       double aux = sqrt(m);
       dl[k] = (aux == 0.0) ? 1.0 : 1.0 / (aux + MACHINE_EPS);
     }
-    // row norms of A and C: one wavefront per row, lanes along the row
+    if (dense && gamma_owed) { // the cost scaling of the PREVIOUS sweep (same S as this sweep's column pass)
+      acc = R.sum(acc);
+      gamma = 1 / fmax(1.0, acc / (double)n);
+      c *= gamma;
+    }
+    // rows
     if (infeas) {
       for (int k = n + threadIdx.x; k < ntot; k += NT)
         dl[k] = 1.0;
     } else {
-      for (int r = wid; r < ne + ni; r += NW) {
-        cgptr row = (r < ne) ? (A + (long)r * n) : (C + (long)(r - ne) * n);
-        double m = 0;
-        for (int k = lane; k < n; k += WAVE)
-          m = fmax(m, fabs(row[k]) * Sx[k]);
-        m = wave_max(m);
-        if (lane == 0) {
-          double sr = (r < ne) ? Se[r] : Si[r - ne];
-          double aux = sqrt(m * sr);
-          dl[n + r] = (aux == 0.0) ? 1.0 : 1.0 / (aux + MACHINE_EPS);
-        }
+      for (int r = threadIdx.x; r < ne + ni; r += NT) {
+        const double sr = (r < ne) ? Se[r] : Si[r - ne];
+        const double aux = sqrt(dl[n + r] * sr);
+        dl[n + r] = (aux == 0.0) ? 1.0 : 1.0 / (aux + MACHINE_EPS);
       }
       if (d.box)
         for (int k = threadIdx.x; k < n; k += NT)
@@ -832,23 +876,29 @@ ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl
       S[k] *= dl[k];
     __syncthreads();
     // cost scaling gamma (ruiz.hpp:256-303); NB: not applied to a Dense H
-    if (d.hessian == PQP_HESSIAN_DENSE) {
-      double acc = 0;
-      for (int k = threadIdx.x; k < n; k += NT) {
-        double hm = 0;
-        for (int i = 0; i < n; ++i)
-          hm = fmax(hm, Sx[i] * fabs(H[(long)i * n + k]));
-        acc += hm * Sx[k];
-      }
-      acc = R.sum(acc);
-      gamma = 1 / fmax(1.0, acc / (double)n);
+    if (dense) {
+      gamma_owed = true;
     } else if (d.hessian == PQP_HESSIAN_DIAGONAL) {
       double mx = 0;
       for (int k = threadIdx.x; k < n; k += NT)
         mx = fmax(mx, fabs(H[(long)k * n + k]) * Sx[k] * Sx[k] * c);
       mx = R.max(mx);
       gamma = 1 / fmax(1.0, mx / (double)n);
+      c *= gamma;
+    } else {
+      c *= gamma;
     }
+  }
+  if (dense && gamma_owed) {
+    double acc = 0;
+    for (int k = threadIdx.x; k < n; k += NT) {
+      double hm = 0;
+      for (int i = 0; i < n; ++i)
+        hm = fmax(hm, Sx[i] * fabs(H[(long)i * n + k]));
+      acc += hm * Sx[k];
+    }
+    acc = R.sum(acc);
+    gamma = 1 / fmax(1.0, acc / (double)n);
     c *= gamma;
   }
   return c;
@@ -863,7 +913,7 @@ ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl
 __host__ __device__ inline size_t
 setup_lds_bytes(const Dims& d, int nt)
 {
-  return (size_t)(2 * d.ntot + 2 * RED_VALS * (nt / WAVE) + 16) * sizeof(double);
+  return (size_t)(2 * d.ntot + 2 * RED_VALS * (nt / WAVE) + 16 + (nt / WAVE) * 4 * WAVE) * sizeof(double); // S, dl, red, cpart (ruiz_execute)
 }
 
 template<int NT>
@@ -995,7 +1045,7 @@ setup_body(const Batch& batch, long q, lptr lds_base)
   // helpers.hpp:652-666 -> setup_equilibration (:298-329)
   double c;
   if (precond == 0) {
-    c = ruiz_execute<NT>(batch, q, st, S, dl, R);
+    c = ruiz_execute<NT>(batch, q, st, S, dl, R, red + (2 * RED_VALS * (NT / WAVE) + 16));
   } else {
     c = W.ruiz_c;
     for (int k = threadIdx.x; k < d.ntot; k += NT)
