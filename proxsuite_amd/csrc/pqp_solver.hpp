@@ -636,9 +636,13 @@ work_cleanup_flags(State& w)
 // scaling S (LDS, ntot) and c:  H_s = c S_x H S_x, A_s = S_eq A S_x, ...; both
 // orientations of A_s and C_s are written for the solve kernel.
 // ---------------------------------------------------------------------------
-template<int NT>
+// `tile` (TILED = true, the set-up kernel): 32 x 33 doubles of LDS through which the transposed copies A_s^T / C_s^T
+// are written in coalesced rows -- a thread per element of A_s writes its transposed position 8 bytes at a time, one
+// memory transaction each.  The solve kernels keep the plain form (their call rewrites the vectors only).
+template<int NT, bool TILED = false>
 __device__ PQP_CALL void
-write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool diag_only = false, bool matrices = true)
+write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool diag_only = false, bool matrices = true,
+             lptr tile = nullptr)
 {
   const QpRef P(batch, q);
   const Dims& d = batch.d;
@@ -691,6 +695,36 @@ write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool dia
       }
     }
   }
+  if constexpr (TILED) {
+    constexpr int T = 32;
+    for (int which = 0; which < 2; ++which) {
+      const int R = which ? ni : ne;
+      cgptr M = which ? P.C() : P.A();
+      gptr Ms = which ? P.Cs() : P.As(), MTs = which ? P.CTs() : P.ATs();
+      clptr Sr = which ? Si : Se;
+      for (int r0 = 0; r0 < R; r0 += T)
+        for (int k0 = 0; k0 < n; k0 += T) {
+          for (int e = threadIdx.x; e < T * T; e += NT) {
+            const int rr = e / T, kk = e - rr * T;
+            const int r = r0 + rr, k = k0 + kk;
+            if (r < R && k < n) {
+              const long o = (long)r * n + k;
+              const double v = Sr[r] * M[o] * Sx[k];
+              Ms[o] = v;
+              tile[rr * (T + 1) + kk] = v;
+            }
+          }
+          __syncthreads();
+          for (int e = threadIdx.x; e < T * T; e += NT) {
+            const int kk = e / T, rr = e - kk * T;
+            const int r = r0 + rr, k = k0 + kk;
+            if (r < R && k < n)
+              MTs[(long)k * R + r] = tile[rr * (T + 1) + kk];
+          }
+          __syncthreads();
+        }
+    }
+  } else {
   {
     cgptr A = P.A();
     gptr As = P.As(), ATs = P.ATs();
@@ -710,6 +744,7 @@ write_scaled(const Batch& batch, long q, clptr S, double c, bool clamp, bool dia
       Cs[o] = v;
       CTs[(long)k * ni + r] = v;
     }
+  }
   }
   }
   for (int k = threadIdx.x; k < n; k += NT)
@@ -913,7 +948,8 @@ ruiz_execute(const Batch& batch, long q, const pqp_settings& st, lptr S, lptr dl
 __host__ __device__ inline size_t
 setup_lds_bytes(const Dims& d, int nt)
 {
-  return (size_t)(2 * d.ntot + 2 * RED_VALS * (nt / WAVE) + 16 + (nt / WAVE) * 4 * WAVE) * sizeof(double); // S, dl, red, cpart (ruiz_execute)
+  const int cpart = (nt / WAVE) * 4 * WAVE; // ruiz_execute's column partials; write_scaled's 32 x 33 transposition tile
+  return (size_t)(2 * d.ntot + 2 * RED_VALS * (nt / WAVE) + 16 + (cpart > 33 * 32 ? cpart : 33 * 32)) * sizeof(double);
 }
 
 template<int NT>
@@ -1052,7 +1088,7 @@ setup_body(const Batch& batch, long q, lptr lds_base)
       S[k] = P.delta()[k];
     __syncthreads();
   }
-  write_scaled<NT>(batch, q, S, c, true);
+  write_scaled<NT, true>(batch, q, S, c, true, false, true, red + (2 * RED_VALS * (NT / WAVE) + 16));
   {
     // structure detection for the diagonal fast path of the solve kernel (Solver::dm): no
     // off-diagonal entry in C with n_in == dim (bounds handed over as C = I, reference
