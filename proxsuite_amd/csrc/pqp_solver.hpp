@@ -3124,8 +3124,10 @@ struct Solver
   // phi'(alpha) at three step lengths with the inequality sums spread over the workgroup (thread order: NOT the
   // reference's order of summation -- these values only steer the bracket), plus the number of this thread's breakpoints
   // in (lo, al[p]] and in (lo, hi], all in ONE fused reduction.  `mag` bounds the size of the terms of each value.
-  __device__ __forceinline__ void ls_grad3(const double (&al)[3], double a0, double b0, const double (&mine)[2], double lo,
-                                           double hi, double (&g)[3], double (&mag)[3], double (&cle)[3], double& ctot)
+  // `bmag`: an alpha-independent bound on the sum of the MAGNITUDES of the terms of the b-sums (they cancel; the a-sums
+  // are sums of squares), see primal_dual_ls.
+  __device__ __forceinline__ void ls_grad3(const double (&al)[3], double a0, double b0, double bmag, const double (&mine)[2],
+                                           double lo, double hi, double (&g)[3], double (&mag)[3], double (&cle)[3], double& ctot)
   {
     const int nc = d.nc;
     const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
@@ -3189,7 +3191,7 @@ struct Solver
         bi = info.mu_in_inv * sv[4 * p + 1] + info.nu * info.mu_in_inv * sv[4 * p + 3];
       }
       g[p] = (a0 + ai) * al[p] + (b0 + bi);
-      mag[p] = fabs((a0 + ai) * al[p]) + fabs(b0) + fabs(bi);
+      mag[p] = fabs((a0 + ai) * al[p]) + fabs(b0) + bmag; // (bmag >= |bi|)
       cle[p] = sv[12 + p];
     }
     ctot = sv[15];
@@ -3198,12 +3200,15 @@ struct Solver
   // The exact line search through a bracket of its zero (see primal_dual_ls).  Returns false when the full evaluation
   // has to decide; true with the step length otherwise -- the SAME floating-point value the full evaluation returns,
   // because the two breakpoints it interpolates between and their phi' are found and evaluated identically.
-  __device__ __forceinline__ bool ls_bracket(double a0, double b0, double& result)
+  __device__ __forceinline__ bool ls_bracket(double a0, double b0, double bmag, double& result)
   {
     const int nc = d.nc;
     const double INF = __builtin_inf();
     constexpr int WCAP = 32;          // breakpoints evaluated exactly at most (one lane each, one wavefront)
-    constexpr double SURE = 1.0e-10;  // |phi'| above this fraction of the size of its terms: the sign is trusted
+    // |phi'| above this fraction of the size of its terms: the sign is trusted.  Two orders of summation of N terms differ
+    // by at most 2 N u sum|terms| (u = 1.1e-16); `mag` carries that sum of magnitudes -- bmag for the b-terms, which cancel
+    // (|b_in| itself underestimates it) -- and the factor below is sixteen times the bound
+    const double SURE = 3.6e-15 * (double)(nc + d.n + d.n_eq);
     // this thread's breakpoints (as in the full evaluation below)
     double mine[2] = { -1.0, -1.0 };
     double cnt = 0, amax = 0, amin_neg = -INF;
@@ -3245,7 +3250,7 @@ struct Solver
     {
       const double al[3] = { 0.0, sqrt(floor_) * sqrt(amax), amax };
       double g[3], mag[3], cle[3], ctot;
-      ls_grad3(al, a0, b0, mine, 0.0, amax, g, mag, cle, ctot);
+      ls_grad3(al, a0, b0, bmag, mine, 0.0, amax, g, mag, cle, ctot);
       if (!(g[0] < -SURE * mag[0]))
         return false;
       if (g[2] < -SURE * mag[2]) {
@@ -3266,7 +3271,7 @@ struct Solver
         const double r4 = sqrt(sqrt(hi / base)); // quarter steps of the logarithm
         const double al[3] = { base * r4, base * r4 * r4, base * r4 * r4 * r4 };
         double g[3], mag[3], cle[3], ctot;
-        ls_grad3(al, a0, b0, mine, lo, hi, g, mag, cle, ctot);
+        ls_grad3(al, a0, b0, bmag, mine, lo, hi, g, mag, cle, ctot);
         // the leftmost sure positive closes the bracket, the rightmost sure negative to its left opens it; a value too small
         // to trust (the zero is next to that point) tightens nothing -- a wrong bracket is caught by the exact values below
         double nlo = lo, nhi = hi, below = 0.0, upto = ctot;
@@ -3479,16 +3484,30 @@ struct Solver
       s_adxres += adx * (L.se()[k] + L.y()[k] * info.mu_eq);
       s_eres += e * L.se()[k];
     }
+    // (kernels with the bracket line search: an alpha-independent bound on sum_i |term_i| of the inequality b-sums --
+    // apz_i is 0, rup_i, si_i or their sum, e_i is 0 or Cdx_i; PDAL adds (e_i - mu dz_i)(apz_i - mu z_i) -- ls_bracket)
+    constexpr bool BRACKET = PQP_LS_BRACKET && SPEC != 1 && NT == 256;
+    double s_bmag = 0;
     for (int k = threadIdx.x; k < nc; k += NT) {
       dwm = fmax(dwm, fabs(L.dz()[k]));
       s_dz2 += L.dz()[k] * L.dz()[k];
       s_dzz += L.dz()[k] * L.z()[k];
+      if constexpr (BRACKET) {
+        const double ac = fabs(L.Cdx()[k]), ar = fabs(L.rup()[k]) + fabs(L.si()[k]);
+        s_bmag = fma(ar, ac, s_bmag);
+        if (!gpdal)
+          s_bmag = fma(double(info.nu) * (ar + fabs(L.z()[k]) * info.mu_in), ac + fabs(L.dz()[k]) * info.mu_in, s_bmag);
+      }
     }
     {
-      // the ten coefficient sums in one barrier interval
-      double sv[10] = { s_dxHdx, s_adx2, s_dx2, s_e2, s_xHdx, s_errdx, s_adxres, s_eres, s_dz2, s_dzz };
+      // the ten coefficient sums in one barrier interval (+ the bound above where the bracket exists)
+      double sv[BRACKET ? 11 : 10] = { s_dxHdx, s_adx2, s_dx2, s_e2, s_xHdx, s_errdx, s_adxres, s_eres, s_dz2, s_dzz };
+      if constexpr (BRACKET)
+        sv[10] = s_bmag;
       double mx[1] = { dwm };
-      R.template mixed<10, 1>(sv, mx);
+      R.template mixed<(BRACKET ? 11 : 10), 1>(sv, mx);
+      if constexpr (BRACKET)
+        s_bmag = sv[10];
       dw_max = mx[0];
       s_dxHdx = sv[0];
       s_adx2 = sv[1];
@@ -3521,7 +3540,7 @@ struct Solver
     if (2 * nc > NT && nc <= NT) { // (its per-thread lists hold two breakpoints)
       double alpha_b;
       sub_tic(ST_CYC_LS_EVAL);
-      const bool ok = ls_bracket(a0, b0, alpha_b);
+      const bool ok = ls_bracket(a0, b0, gpdal ? info.mu_in_inv * s_bmag / st.alpha_gpdal : info.mu_in_inv * s_bmag, alpha_b);
       sub_toc(ST_CYC_LS_EVAL);
       if (ok)
         return alpha_b;
