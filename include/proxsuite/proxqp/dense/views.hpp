@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <ostream>
 #include <type_traits>
 #include <vector>
 
@@ -23,6 +24,44 @@
 namespace proxsuite {
 namespace proxqp {
 namespace dense {
+
+using proxsuite::proxqp::isize; // (the reference re-exports veg's isize / usize in this namespace: dense/fwd.hpp)
+using proxsuite::proxqp::usize;
+
+namespace detail {
+// `v.array() += c` and friends: the coefficient-wise view the reference's examples use on Eigen objects
+// (examples/cpp/init_dense_qp_with_box.cpp:24-25)
+template<typename T>
+struct ArrayProxy
+{
+  T* p;
+  isize n;
+  ArrayProxy& operator+=(T c)
+  {
+    for (isize i = 0; i < n; ++i)
+      p[i] += c;
+    return *this;
+  }
+  ArrayProxy& operator-=(T c)
+  {
+    for (isize i = 0; i < n; ++i)
+      p[i] -= c;
+    return *this;
+  }
+  ArrayProxy& operator*=(T c)
+  {
+    for (isize i = 0; i < n; ++i)
+      p[i] *= c;
+    return *this;
+  }
+  ArrayProxy& operator/=(T c)
+  {
+    for (isize i = 0; i < n; ++i)
+      p[i] /= c;
+    return *this;
+  }
+};
+} // namespace detail
 
 template<typename T>
 class Vec
@@ -49,6 +88,8 @@ public:
   void resize(isize n) { v_.assign(usize(n), T(0)); }
   void setZero() { std::fill(v_.begin(), v_.end(), T(0)); }
   void setConstant(T c) { std::fill(v_.begin(), v_.end(), c); }
+  void setOnes() { setConstant(T(1)); }
+  detail::ArrayProxy<T> array() { return { v_.data(), size() }; }
   T* begin() { return v_.data(); }
   T* end() { return v_.data() + v_.size(); }
   const T* begin() const { return v_.data(); }
@@ -83,6 +124,13 @@ public:
     v_.assign(usize(rows * cols), T(0));
   }
   void setZero() { std::fill(v_.begin(), v_.end(), T(0)); }
+  void setIdentity()
+  {
+    setZero();
+    for (isize i = 0; i < std::min(r_, c_); ++i)
+      (*this)(i, i) = T(1);
+  }
+  detail::ArrayProxy<T> array() { return { v_.data(), size() }; }
 
 private:
   isize r_ = 0, c_ = 0;
@@ -184,6 +232,64 @@ struct MatRef
   const T& operator()(isize i, isize j) const { return ptr[i * row_stride + j * col_stride]; }
   bool is_packed_row_major() const { return col_stride == 1 && (row_stride == c || r <= 1); }
 };
+
+// the little vector arithmetic the reference's examples do on model data (examples/cpp/update_dense_qp_ws_previous_result.cpp:36:
+// `qp_random.g * 0.95`)
+template<typename T>
+Vec<T>
+operator*(const Vec<T>& v, T c)
+{
+  Vec<T> r(v.size());
+  for (isize i = 0; i < v.size(); ++i)
+    r[i] = v[i] * c;
+  return r;
+}
+template<typename T>
+Vec<T>
+operator*(T c, const Vec<T>& v)
+{
+  return v * c;
+}
+template<typename T>
+Vec<T>
+operator+(const Vec<T>& a, const Vec<T>& b)
+{
+  Vec<T> r(a.size());
+  for (isize i = 0; i < a.size(); ++i)
+    r[i] = a[i] + b[i];
+  return r;
+}
+template<typename T>
+Vec<T>
+operator-(const Vec<T>& a, const Vec<T>& b)
+{
+  Vec<T> r(a.size());
+  for (isize i = 0; i < a.size(); ++i)
+    r[i] = a[i] - b[i];
+  return r;
+}
+
+// printing (the examples stream results.x / y / z): one coefficient per line for a vector, one row per line for a matrix
+template<typename T>
+std::ostream&
+operator<<(std::ostream& os, const Vec<T>& v)
+{
+  for (isize i = 0; i < v.size(); ++i)
+    os << (i ? "\n" : "") << v[i];
+  return os;
+}
+template<typename T>
+std::ostream&
+operator<<(std::ostream& os, const Mat<T>& m)
+{
+  for (isize i = 0; i < m.rows(); ++i) {
+    for (isize j = 0; j < m.cols(); ++j)
+      os << (j ? " " : "") << m(i, j);
+    if (i + 1 < m.rows())
+      os << "\n";
+  }
+  return os;
+}
 
 // |v|_inf, the norm every acceptance test of the reference uses
 template<typename T>

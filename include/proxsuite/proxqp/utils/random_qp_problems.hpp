@@ -42,6 +42,26 @@ normal_rand()
 {
   return pqp_rand_normal();
 }
+// reference utils/random_qp_problems.hpp:150-175: normal draws, in index order
+template<typename Scalar>
+dense::Vec<Scalar>
+vector_rand(isize nrows)
+{
+  dense::Vec<Scalar> v(nrows);
+  for (isize i = 0; i < nrows; ++i)
+    v(i) = Scalar(normal_rand());
+  return v;
+}
+template<typename Scalar>
+dense::Mat<Scalar>
+matrix_rand(isize nrows, isize ncols)
+{
+  dense::Mat<Scalar> m(nrows, ncols);
+  for (isize i = 0; i < nrows; ++i)
+    for (isize j = 0; j < ncols; ++j)
+      m(i, j) = Scalar(normal_rand());
+  return m;
+}
 } // namespace rand
 
 template<typename T = double>
