@@ -5,5 +5,6 @@
 
 #include "proxsuite/proxqp/dense/compute_ECJ.hpp"
 #include "proxsuite/proxqp/dense/wrapper.hpp"
+#include "proxsuite/proxqp/timings.hpp"
 
 #endif
