@@ -274,6 +274,8 @@ int pqp_multi_get_results(pqp_multi* m, int64_t idx, double* x, double* y, doubl
  * asynchronous peer copies into place; returns when the buffer is complete. */
 int pqp_multi_gather_device(pqp_multi* m, int root_shard, double* out);
 /* device time of the last solve: the slowest shard (the job's time), milliseconds */
+/* pqp_batch_get_trace of the shard that holds QP idx (settings.verbose: the per-iteration lines of the last launch) */
+int pqp_multi_get_trace(pqp_multi* m, int64_t idx, double* records, int64_t capacity, int64_t* n_records);
 double pqp_multi_last_solve_ms(const pqp_multi* m);
 
 #ifdef __cplusplus

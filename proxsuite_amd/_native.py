@@ -61,7 +61,7 @@ class NativeLib:
                "pqp_multi_locate", "pqp_multi_settings", "pqp_multi_init", "pqp_multi_update", "pqp_multi_warm_start",
                "pqp_multi_cleanup", "pqp_multi_flush", "pqp_multi_solve", "pqp_multi_solve_range",
                "pqp_multi_solve_async", "pqp_multi_solve_range_async", "pqp_multi_wait", "pqp_multi_get_results",
-               "pqp_multi_gather_device", "pqp_multi_last_solve_ms")
+               "pqp_multi_gather_device", "pqp_multi_get_trace", "pqp_multi_last_solve_ms")
 
     def __init__(self, path, legacy=False):
         """legacy=True (A/B scripts only): an older build of the library that lacks the newer entries can still be
@@ -136,6 +136,7 @@ class NativeLib:
         L.pqp_multi_gather_device.argtypes = [vp, C.c_int, vp]
         L.pqp_multi_last_solve_ms.argtypes = [vp]
         L.pqp_multi_last_solve_ms.restype = C.c_double
+        L.pqp_multi_get_trace.argtypes = [vp, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         self.L = real
 
     def check(self, rc):
@@ -595,6 +596,15 @@ class MultiBatch:
     @property
     def last_solve_ms(self):
         return self.lib.L.pqp_multi_last_solve_ms(self._h)
+
+    def trace(self, idx):
+        """settings.verbose: the per-iteration lines of QP idx from the last launch (Batch.trace, pqp_multi_get_trace)"""
+        n = C.c_int64(0)
+        self.lib.check(self.lib.L.pqp_multi_get_trace(self._h, int(idx), None, 0, C.byref(n)))
+        out = np.zeros((n.value, 8))
+        if n.value:
+            self.lib.check(self.lib.L.pqp_multi_get_trace(self._h, int(idx), out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def results(self, idx=-1):
         pre = (self.B,) if idx < 0 else ()

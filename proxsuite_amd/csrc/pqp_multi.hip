@@ -360,6 +360,21 @@ pqp_multi_get_results(pqp_multi* m, int64_t idx, double* x, double* y, double* z
 }
 
 int
+pqp_multi_get_trace(pqp_multi* m, int64_t idx, double* records, int64_t capacity, int64_t* n_records)
+{
+  if (!m || !n_records)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "null argument");
+  if (idx < 0)
+    return fail(PQP_ERR_INVALID_ARGUMENT, "QP index out of range");
+  if (int rc = check_multi_idx(m, idx))
+    return rc;
+  if (int rc = pqp_multi_wait(m))
+    return rc;
+  const int s = shard_of(m, idx);
+  return pqp_batch_get_trace(m->shard[size_t(s)], idx - m->first[size_t(s)], records, capacity, n_records);
+}
+
+int
 pqp_multi_gather_device(pqp_multi* m, int root_shard, double* out)
 {
   if (!m || !out)

@@ -164,6 +164,36 @@ def case_multi(lib, randqp, devices, n=20, ne=5, ni=8, B=7, gather_alloc=None):
     mb.close()
 
 
+def case_multi_verbose_trace(lib, randqp, devices, n=16, ne=4, ni=6, B=5):
+    """settings.verbose across shards: the per-iteration trace of a QP is the one its single-handle solve records
+    (pqp_multi_get_trace reaches into the shard that holds it); a QP that is not verbose has none"""
+    import os
+    m = _model(randqp, B, n, ne, ni)
+    out = []
+    devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)  # (the library prints the lines)
+    try:
+        for multi in (False, True):
+            b = N.MultiBatch(B, n, ne, ni, devices, lib=lib) if multi else N.Batch(B, n, ne, ni, lib=lib)
+            for i in range(B):
+                s = b.settings(i)
+                s.eps_abs, s.eps_rel, s.initial_guess = EPS, 0.0, int(InitialGuess.NO_INITIAL_GUESS)
+                s.verbose = 0 if i == 1 else 1
+            b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
+            os.dup2(devnull, 1)
+            try:
+                b.solve()
+            finally:
+                os.dup2(saved, 1)
+            out.append([b.trace(i) for i in range(B)])
+            b.close()
+    finally:
+        os.close(devnull)
+        os.close(saved)
+    for i in range(B):
+        assert np.array_equal(out[0][i], out[1][i]), i
+        assert (out[0][i].shape[0] == 0) == (i == 1)
+
+
 def case_multi_errors(lib):
     import pytest
     with pytest.raises(ValueError):

@@ -35,5 +35,9 @@ def test_multi_more_shards_than_qps(lib, randqp):
     mc.case_multi(lib, randqp, [0, 1, 2, 3], B=3)
 
 
+def test_multi_verbose_trace(lib, randqp):
+    mc.case_multi_verbose_trace(lib, randqp, [0, 1, 2])
+
+
 def test_multi_errors(lib):
     mc.case_multi_errors(lib)

@@ -42,6 +42,10 @@ def test_multi_device_batch_is_bit_exact(lib, randqp, G):
     mc.case_multi(lib, randqp, [0] * G, n=100, ne=50, ni=100, B=64 + G - 1, gather_alloc=_dev_alloc)
 
 
+def test_multi_verbose_trace(lib, randqp):
+    mc.case_multi_verbose_trace(lib, randqp, [0, 0, 0])
+
+
 def test_multi_errors(lib):
     mc.case_multi_errors(lib)
 
