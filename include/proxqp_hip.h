@@ -278,6 +278,15 @@ int pqp_multi_gather_device(pqp_multi* m, int root_shard, double* out);
 int pqp_multi_get_trace(pqp_multi* m, int64_t idx, double* records, int64_t capacity, int64_t* n_records);
 double pqp_multi_last_solve_ms(const pqp_multi* m);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Diagnostic: what the box delivers right now (no counterpart in the reference; bench.py's `box` record and the
+ * performance guard of the GPU tests read timings of the solve kernels against it).  Three fixed kernels, ~60 ms:
+ *   out[0] HBM streaming read GB/s (2 GiB, 16 B per lane), out[1] milliseconds of a fixed latency-chain kernel at the
+ *   C2 kernel's residency (dependent row reads + wavefront reduction + LDS exchange + barrier), out[2] milliseconds of a
+ *   fixed chain of dependent fp64 FMAs (shader-clock proxy), out[3] the shader clock in MHz that implies, out[4] the
+ *   number of compute units.  n_out >= 5. */
+int pqp_box_calibrate(int device, double* out, int n_out);
+
 #ifdef __cplusplus
 }
 #endif

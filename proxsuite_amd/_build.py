@@ -52,12 +52,12 @@ def build_randqp(force: bool = False) -> Path:
 # pqp_kernels.hip is compiled once per kernel family (see its header): every solve kernel is
 # ~350 KB of inlined code and takes about a minute of hipcc time, so the objects are built in
 # parallel and linked into one shared library.
-KERNEL_TUS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 14, 15)
+KERNEL_TUS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 14, 15, 16)
 OBJ_DIR = ROOT / "build" / "obj"
 
 
 def hip_sources():
-    return [CSRC / "pqp_capi.hip", CSRC / "pqp_multi.hip", CSRC / "pqp_kernels.hip"]
+    return [CSRC / "pqp_capi.hip", CSRC / "pqp_multi.hip", CSRC / "pqp_kernels.hip", CSRC / "pqp_calib.hip"]
 
 
 def hip_headers():
@@ -130,7 +130,8 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
     odir.mkdir(parents=True, exist_ok=True)
     flags = hip_flags(extra_flags)
     jobs = [([hipcc, *flags, "-c", str(CSRC / "pqp_capi.hip"), "-o", str(odir / "capi.o")], odir / "capi.o"),
-            ([hipcc, *flags, "-c", str(CSRC / "pqp_multi.hip"), "-o", str(odir / "multi.o")], odir / "multi.o")]
+            ([hipcc, *flags, "-c", str(CSRC / "pqp_multi.hip"), "-o", str(odir / "multi.o")], odir / "multi.o"),
+            ([hipcc, *flags, "-c", str(CSRC / "pqp_calib.hip"), "-o", str(odir / "calib.o")], odir / "calib.o")]
     for k in tus:
         o = odir / ("kernels_%d.o" % k)
         jobs.append(([hipcc, *flags, *TU_FLAGS.get(k, []), "-DPQP_TU=%d" % k, "-c", str(CSRC / "pqp_kernels.hip"),
@@ -189,7 +190,7 @@ def build_hip_variants(force: bool = False):
             _run([hipcc, *hip_flags(("-DPQP_WPS_512=%d" % w,)), *TU_FLAGS.get(3, []), "-DPQP_TU=3", "-c",
                   str(CSRC / "pqp_kernels.hip"),
                   "-o", str(o3)])
-            objs = [base / "capi.o", base / "multi.o"] + [o3 if k == 3 else base / ("kernels_%d.o" % k) for k in KERNEL_TUS]
+            objs = [base / "capi.o", base / "multi.o", base / "calib.o"] + [o3 if k == 3 else base / ("kernels_%d.o" % k) for k in KERNEL_TUS]
             _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)])
         out.append(lib)
     return out
@@ -206,3 +207,22 @@ def build_oracle(force: bool = False) -> Path:
         os.remove(lib)
     _run(["make", "-C", str(odir), "-B" if force else "-s", "liboracle.so"])
     return lib
+
+
+def freeze_kernel_resources():
+    """tests/golden/kernel_resources_expected.json <- the record of the current product build (run after a kernel
+    change has been measured on the GPU and accepted: tests/test_kernel_resources.py then guards it)"""
+    import json
+    build_hip()
+    rec = kernel_resources()
+    keep = ("VGPRs", "AGPRs", "VGPRs_Spill", "SGPRs_Spill", "ScratchSize", "Occupancy")
+    out = {k: {f: v[f] for f in keep if f in v} for k, v in sorted(rec.items()) if k.startswith("pqp_")}
+    p = ROOT / "tests" / "golden" / "kernel_resources_expected.json"
+    p.write_text(json.dumps(out, indent=1, sort_keys=True))
+    return p
+
+
+if __name__ == "__main__":
+    import sys
+    if "--freeze" in sys.argv:
+        print(freeze_kernel_resources())

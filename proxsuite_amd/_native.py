@@ -61,7 +61,7 @@ class NativeLib:
                "pqp_multi_locate", "pqp_multi_settings", "pqp_multi_init", "pqp_multi_update", "pqp_multi_warm_start",
                "pqp_multi_cleanup", "pqp_multi_flush", "pqp_multi_solve", "pqp_multi_solve_range",
                "pqp_multi_solve_async", "pqp_multi_solve_range_async", "pqp_multi_wait", "pqp_multi_get_results",
-               "pqp_multi_gather_device", "pqp_multi_get_trace", "pqp_multi_last_solve_ms")
+               "pqp_multi_gather_device", "pqp_multi_get_trace", "pqp_multi_last_solve_ms", "pqp_box_calibrate")
 
     def __init__(self, path, legacy=False):
         """legacy=True (A/B scripts only): an older build of the library that lacks the newer entries can still be
@@ -137,6 +137,7 @@ class NativeLib:
         L.pqp_multi_last_solve_ms.argtypes = [vp]
         L.pqp_multi_last_solve_ms.restype = C.c_double
         L.pqp_multi_get_trace.argtypes = [vp, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.pqp_box_calibrate.argtypes = [C.c_int, _DP, C.c_int]
         self.L = real
 
     def check(self, rc):
@@ -179,6 +180,17 @@ def load() -> NativeLib:
             raise NativeError("no HIP device visible: proxsuite_amd runs on MI355X only (no CPU fallback)")
         _lib = lib
     return _lib
+
+
+def box_calibration(device: int = 0, lib: NativeLib = None) -> dict:
+    """pqp_box_calibrate (include/proxqp_hip.h): what the box delivers right now -- HBM read rate, the time of a fixed
+    latency-chain kernel at the C2 kernel's residency, the shader clock a fixed FMA chain implies.  ~60 ms of GPU time."""
+    lib = lib or load()
+    out = (C.c_double * 8)()
+    rc = lib.L.pqp_box_calibrate(int(device), out, 8)
+    if rc != 0:
+        raise NativeError("pqp_box_calibrate: %s" % (lib.L.pqp_last_error() or b"").decode())
+    return {"hbm_read_gbs": out[0], "chain_ms": out[1], "valu_ms": out[2], "sclk_mhz_est": out[3], "n_cu": int(out[4])}
 
 
 def _as_array(a, shape, name):

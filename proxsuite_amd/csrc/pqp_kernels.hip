@@ -73,13 +73,15 @@ template<int NT, int WPS, int SPEC>
 static int
 launch_solve(pqp_batch* h)
 {
-  if (h->lds_solve > 64 * 1024)
+  // (a kernel narrower than the handle's default width carves its own, smaller, LDS layout)
+  const size_t lds = (NT == h->nt) ? h->lds_solve : pqp::lds_bytes(h->dev.d, NT);
+  if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_solve_kernel<NT, WPS, SPEC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
   const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
-  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS, SPEC>), dim3((unsigned)h->range_count), dim3(NT), h->lds_solve,
+  hipLaunchKernelGGL((pqp_solve_kernel<NT, WPS, SPEC>), dim3((unsigned)h->range_count), dim3(NT), lds,
                      h->stream, h->dev, h->range_first, order);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
@@ -94,6 +96,7 @@ int pqp_launch_solve_256_s0_one(pqp_batch* h);
 int pqp_launch_solve_256_s1_two(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_256_s2(pqp_batch* h);
+int pqp_launch_solve_64_s2(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
@@ -153,6 +156,15 @@ int
 pqp_launch_solve_256_s2(pqp_batch* h)
 {
   return launch_solve<256, PQP_WPS_256_DIAG, 2>(h);
+}
+#endif
+// One WAVEFRONT per QP for the diagonal-structure solver: every barrier of the solver is a no-op in a workgroup of
+// one wavefront (the compiler drops s_barrier when the flat workgroup size is the wave size).
+#if PQP_TU_HAS(16)
+int
+pqp_launch_solve_64_s2(pqp_batch* h)
+{
+  return launch_solve<64, 1, 2>(h);
 }
 #endif
 #if PQP_TU_HAS(3)
@@ -378,8 +390,10 @@ pqp_launch_solve(pqp_batch* h)
         bool all_diag = pqp::diag_structure_signature(dd.hessian, dd.n_eq, dd.n_in, dd.box) && !h->c_diag.empty();
         for (size_t q = 0; all_diag && q < h->c_diag.size(); ++q)
           all_diag = h->c_diag[q] != 0;
-        if (all_diag)
-          return pqp_launch_solve_256_s2(h);
+        if (all_diag) {
+          static const int diag_nt = [] { const char* e = std::getenv("PQP_DIAG_NT"); return e ? std::atoi(e) : 256; }();
+          return diag_nt == 64 ? pqp_launch_solve_64_s2(h) : pqp_launch_solve_256_s2(h);
+        }
         return (h->range_count <= (long)h->n_cu) ? pqp_launch_solve_256_s0_one(h) : pqp_launch_solve_256_s0(h);
       }
       // more workgroups than three per CU can hold at once: the four-per-CU build; otherwise the

@@ -1,8 +1,11 @@
-"""`-m gpu`: regression guard on the headline kernel.  A fifth of its throughput hangs on three internal
-`-mllvm` code-generation switches (proxsuite_amd/_build.py) that a toolchain change could alter silently:
-the C2 solve (2048 random dense QPs, n=100 n_eq=50 n_in=100, index order) must stay within the margin (7 %) of the
-kernel time recorded in profiles/perf_guard.json -- the median box of the pool --, so must C4 and C5, and the build's
-own record of the kernels' registers (profiles/r04_kernel_resources.json, written by __graft_entry__.build) must be there."""
+"""`-m gpu`: regression guard on the solve kernels, RELATIVE TO THE BOX IT RUNS ON.  A fifth of the headline kernel's
+throughput hangs on three internal `-mllvm` code-generation switches (proxsuite_amd/_build.py) that a toolchain change could
+alter silently, so the C2 / C4 / C5 kernel times are guarded -- but the boxes of the pool differ by up to 10 % on one
+binary (8.05 ms on the builder's boxes, 8.87 ms on the driver's), and an absolute limit in milliseconds goes
+red, or stays green, because of the lease.  Each limit is therefore the time recorded on the REFERENCE box
+(profiles/perf_guard.json: kernel times + that box's pqp_box_calibrate figures) scaled by how much slower THIS box runs
+the fixed latency-chain kernel of the calibration (C4, which is bandwidth-bound on real traffic: the larger of that and
+the HBM read-rate ratio), plus the margin (7 %)."""
 import json
 import os
 
@@ -15,8 +18,30 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_c2_kernel_time_within_margin(randqp):
+@pytest.fixture(scope="module")
+def box():
+    """(guard record, latency factor, bandwidth factor) of this box against the guard's reference box"""
     guard = json.load(open(os.path.join(ROOT, "profiles", "perf_guard.json")))
+    cal = [N.box_calibration(0), N.box_calibration(0)]
+    chain = min(c["chain_ms"] for c in cal)
+    hbm = max(c["hbm_read_gbs"] for c in cal)
+    ref = guard["reference_box"]
+    f_lat = chain / ref["chain_ms"]
+    f_bw = ref["hbm_read_gbs"] / hbm
+    print("\nbox: chain %.3f ms (reference %.3f), HBM read %.0f GB/s (reference %.0f), sclk ~%.0f MHz -> latency factor %.3f, "
+          "bandwidth factor %.3f" % (chain, ref["chain_ms"], hbm, ref["hbm_read_gbs"], cal[0]["sclk_mhz_est"], f_lat, f_bw))
+    return guard, f_lat, f_bw
+
+
+def _check(what, best, ref_ms, factor, guard, source):
+    limit = (1.0 + guard["margin"]) * ref_ms * factor
+    print("%s: %.3f ms, limit %.3f ms = %.3f ms (reference box) x %.3f (this box) x %.2f" % (what, best, limit, ref_ms, factor, 1 + guard["margin"]))
+    assert best <= limit, "%s solve kernel %.3f ms > %.3f ms (%.3f ms on the reference box x box factor %.3f + %.0f %%): %s" % (
+        what, best, limit, ref_ms, factor, 100 * guard["margin"], source)
+
+
+def test_c2_kernel_time_within_margin(randqp, box):
+    guard, f_lat, f_bw = box
     lib = N.load()
     B, n, ne, ni = 2048, 100, 50, 100
     m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2)
@@ -31,15 +56,12 @@ def test_c2_kernel_time_within_margin(randqp):
     x, y, z, se, si, info = b.results()
     assert all(info[i].status == 0 for i in range(B))
     b.close()
-    best = min(ms)
-    limit = (1.0 + guard["margin"]) * guard["c2_kernel_ms"]
-    assert best <= limit, "C2 solve kernel %.3f ms > %.3f ms (recorded %.3f ms + %.0f %%): %s" % (
-        best, limit, guard["c2_kernel_ms"], 100 * guard["margin"], guard["source"])
+    _check("C2", min(ms), guard["c2_kernel_ms"], f_lat, guard, guard["source"])
 
 
-def test_c4_kernel_time_within_margin(randqp):
+def test_c4_kernel_time_within_margin(randqp, box):
     """BASELINE.json configs[3] (512 x (512, 200, 400)): the LDS-tiled Z / G build of the wide kernels must stay in place"""
-    guard = json.load(open(os.path.join(ROOT, "profiles", "perf_guard.json")))
+    guard, f_lat, f_bw = box
     B, n, ne, ni = 512, 512, 200, 400
     m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2)
     b = N.Batch(B, n, ne, ni, lib=N.load())
@@ -53,17 +75,15 @@ def test_c4_kernel_time_within_margin(randqp):
     infos = b.infos()
     assert all(infos[i].status == 0 for i in range(B))
     b.close()
-    best = min(ms)
-    limit = (1.0 + guard["margin"]) * guard["c4_kernel_ms"]
-    assert best <= limit, "C4 solve kernel %.3f ms > %.3f ms (recorded %.3f ms): %s" % (best, limit, guard["c4_kernel_ms"], guard["c4_source"])
+    _check("C4", min(ms), guard["c4_kernel_ms"], max(f_lat, f_bw), guard, guard["c4_source"])
 
 
-def test_c5_kernel_time_within_margin(randqp):
+def test_c5_kernel_time_within_margin(randqp, box):
     """the structured configuration (BASELINE.json configs[4]: 4096 x (200, 0, 200), diagonal Hessian, C = I), whose time is
     the line search's: the bracketing evaluation and the dedicated kernel must stay in place"""
     import parity_cases as pc
     from proxsuite_amd._ctypes_defs import HessianType
-    guard = json.load(open(os.path.join(ROOT, "profiles", "perf_guard.json")))
+    guard, f_lat, f_bw = box
     B, dim = 4096, 200
     H, g, Cm, l, u = pc.c5_models(randqp, B, dim)
     b = N.Batch(B, dim, 0, dim, hessian_type=int(HessianType.Diagonal), lib=N.load())
@@ -77,13 +97,11 @@ def test_c5_kernel_time_within_margin(randqp):
     x, y, z, se, si, info = b.results()
     assert all(info[i].status == 0 for i in range(B))
     b.close()
-    best = min(ms)
-    limit = (1.0 + guard["margin"]) * guard["c5_kernel_ms"]
-    assert best <= limit, "C5 solve kernel %.3f ms > %.3f ms (recorded %.3f ms): %s" % (best, limit, guard["c5_kernel_ms"], guard["c5_source"])
+    _check("C5", min(ms), guard["c5_kernel_ms"], f_lat, guard, guard["c5_source"])
 
 
 def test_kernel_resource_record_exists():
-    res = json.load(open(os.path.join(ROOT, "profiles", "r04_kernel_resources.json")))
+    res = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_resources.json")))
     c2 = res["pqp_solve_kernel<256,4,1>"]
     assert c2["VGPRs"] <= 128 and c2["Occupancy"] == 4  # four workgroups of four wavefronts per CU
     assert "VGPRs_Spill" in c2 and "ScratchSize" in c2
