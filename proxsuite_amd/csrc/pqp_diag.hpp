@@ -1,0 +1,1595 @@
+// The diagonal-structure solver as ONE WAVEFRONT PER QP with every per-QP vector in REGISTERS
+// (BASELINE.json configs[4]: "4096 box-constrained QPs with diagonal Hessian ... bandwidth-bound, no MFMA";
+// north_star: "one wavefront owns one QP instance").
+//
+// Diagonal structure (Solver::dm, pqp_solver.hpp): H diagonal or zero, no equality, and every inequality row on ONE
+// variable -- box constraints, or a C without off-diagonal entries and n_in == dim -- so constraint k sits on variable
+// k, L = I, the Gram matrix and the dual Schur block are diagonal, and the whole of qp_solve (reference
+// dense/solver.hpp:1088-1843) is element-wise work on vectors of length dim plus reductions and the exact line search.
+// The workgroup kernel pqp_solve_kernel<256, ., 2> spends that on 256 threads meeting at ~45 barriers per Newton step
+// with the vectors in 62.8 KB of LDS (two QPs per CU; 49 us per Newton step on 200-element vectors: VERDICT r4).  Here:
+//   * element k of every vector lives in lane k % 64, register slot k / 64 (E slots: dim <= 64 E); constraint k and
+//     variable k share a lane, so the KKT solve, the residuals, the active-set bookkeeping and the iterate update
+//     never leave the lane;
+//   * reductions are the DPP wavefront reductions of pqp_block.hpp -- no LDS round trip, no barrier anywhere in the
+//     kernel (a workgroup IS one wavefront);
+//   * the exact line search (reference linesearch.hpp:320-538) brackets the zero of phi' as the workgroup kernel does
+//     (ls_bracket), and evaluates phi' at the few breakpoints around it with every lane summing its own constraints'
+//     terms + one wavefront reduction per sum, instead of one lane walking all constraints in a serial chain;
+//   * LDS: 2.3 KB per QP (slot lists for the persistent state) against 62.8 KB.
+// Same algorithm, same decisions, same HBM state as the workgroup kernels (a QP may be solved by either, in any order:
+// warm starts, the QPLayer backward and pqp_batch_get_schur_factor read what this kernel leaves).  Sums are taken in
+// a different order (lane-serial over the E slots, then the wavefront tree), so results agree with the other kernels
+// and with the oracle to rounding, not bit for bit: tests/test_gpu_parity.py gates every C5 / C5box QP against the
+// oracle (1e-10, equal Info).
+#ifndef PQP_DIAG_HPP
+#define PQP_DIAG_HPP
+
+#include "pqp_solver.hpp"
+
+namespace pqp {
+
+// bytes of LDS one QP (= one wavefront = one workgroup) of the kernel needs
+__host__ __device__ inline size_t
+diag_lds_bytes(int E)
+{
+  return (size_t)(64 * E) * sizeof(int) + (size_t)(64 * E) * sizeof(double) + (ST_COUNT + 2) * sizeof(long long);
+}
+
+// value of lane `src` (uniform) in every lane
+__device__ __forceinline__ double
+wave_bcast(double v, int src)
+{
+#ifndef PQP_EMULATED_MFMA
+  return readlane_f64(v, src);
+#else
+  return __shfl(v, src);
+#endif
+}
+
+#define PQP_E(c) _Pragma("unroll") for (int c = 0; c < E; ++c)
+
+template<int E>
+struct DiagSolver
+{
+  const Batch& batch;
+  const long q;
+  const Dims d;
+  const QpRef P;
+  const pqp_settings& st;
+  UInfo info;
+  const int lane;
+  const int n;      // dim
+  const bool cform; // bounds as C (n_in == dim, C diagonal)
+  const bool boxf;  // bounds as box constraints (n_in == 0)
+  const bool hasc;  // nc > 0
+  PQP_LDS int* lds_i;          // 64 E ints: slot lists
+  PQP_LDS double* lds_d;       // 64 E doubles
+  PQP_LDS long long* lds_stat; // ST_COUNT + 2 (statistics, instrumented build)
+  UD ruiz_c, dual_feasibility_rhs_2;
+  int n_c;
+  bool schur_dirty, aty_fresh, nonfinite;
+  // persistent vectors (slot c of lane l = element 64 c + l; zeros beyond dim, dF = dS = 1 there)
+  double x[E], z[E], xp[E], zp[E], gs[E], ub[E], lb[E], zd[E], hd[E], dF[E], gd[E], dS[E], dres[E], rup[E], si[E];
+  // Newton step
+  double dx[E], dz[E], Hdx[E], Cdx[E], CTdz[E], CTzin[E], rx[E], rd[E], ex[E], ed[E], sd[E], zfull[E];
+  int fl[E]; // bit 0 active_set_up, bit 1 active_set_low, bit 2 wanted active, bit 3 in the factor (has a slot)
+
+  __device__ __forceinline__ DiagSolver(const Batch& b, long q_, lptr lds)
+    : batch(b)
+    , q(q_)
+    , d(b.d)
+    , P(b, q_)
+    , st(b.settings[q_])
+    , lane((int)(threadIdx.x & (WAVE - 1)))
+    , n(uni(b.d.n))
+    , cform(b.d.n_in > 0)
+    , boxf(b.d.box != 0)
+    , hasc(b.d.nc > 0)
+  {
+    lds_i = (PQP_LDS int*)lds;
+    lds_d = (PQP_LDS double*)(lds + 32 * E);
+    lds_stat = (PQP_LDS long long*)(lds + 32 * E + 64 * E);
+    n_c = 0;
+    schur_dirty = true;
+    aty_fresh = false;
+    nonfinite = false;
+  }
+  __device__ __forceinline__ int hess() const { return d.hessian == PQP_HESSIAN_ZERO ? (int)PQP_HESSIAN_ZERO : (int)PQP_HESSIAN_DIAGONAL; }
+  __device__ __forceinline__ int idx(int c) const { return c * WAVE + lane; }
+  __device__ __forceinline__ bool in(int c) const { return idx(c) < n; }
+  __device__ __forceinline__ bool active(int c) const { return (fl[c] & 8) != 0; }
+
+  // ---- statistics (see Solver::tic / toc): the instrumented build only; the total cycles of a solve (dispatch order)
+  // and the wall ticks (Info timings) are always recorded
+  __device__ __forceinline__ void tic()
+  {
+#ifdef PQP_STATS
+    if (lane == 0)
+      lds_stat[ST_COUNT] = clock64();
+#endif
+  }
+  __device__ __forceinline__ void toc(int which)
+  {
+#ifdef PQP_STATS
+    if (lane == 0) {
+      long long t = clock64();
+      lds_stat[which] += t - lds_stat[ST_COUNT];
+      lds_stat[ST_COUNT] = t;
+    }
+#else
+    (void)which;
+#endif
+  }
+  __device__ __forceinline__ void sub_tic(int which)
+  {
+#ifdef PQP_STATS
+    if (lane == 0)
+      lds_stat[which] -= clock64();
+#else
+    (void)which;
+#endif
+  }
+  __device__ __forceinline__ void sub_toc(int which)
+  {
+#ifdef PQP_STATS
+    if (lane == 0)
+      lds_stat[which] += clock64();
+#else
+    (void)which;
+#endif
+  }
+  __device__ __forceinline__ void count(int which, long long v = 1)
+  {
+#ifdef PQP_STATS
+    if (lane == 0)
+      lds_stat[which] += v;
+#else
+    (void)which;
+    (void)v;
+#endif
+  }
+  __device__ __forceinline__ void bytes(long long b) { count(ST_BYTES_ENGINE, b); }
+  __device__ __forceinline__ void trace_line(double kind, double i, double a, double b, double c, double d4, double e)
+  {
+    if (batch.trace == nullptr || lane != 0)
+      return;
+    const int slot = batch.trace_slot[q];
+    if (slot < 0)
+      return;
+    gptr t = (gptr)(batch.trace + (long)slot * batch.trace_cap * 8);
+    const int k = (int)t[0];
+    if (k + 1 >= batch.trace_cap) {
+      t[1] += 1.0;
+      return;
+    }
+    gptr r = t + (long)(k + 1) * 8;
+    r[0] = kind;
+    r[1] = i;
+    r[2] = a;
+    r[3] = b;
+    r[4] = c;
+    r[5] = d4;
+    r[6] = e;
+    t[0] = double(k + 1);
+  }
+
+  // ---- loads / stores of one vector of length dim
+  __device__ __forceinline__ void vload(double (&v)[E], cgptr src, double fill = 0.0)
+  {
+    PQP_E(c) v[c] = in(c) ? src[idx(c)] : fill;
+  }
+  __device__ __forceinline__ void vstore(gptr dst, const double (&v)[E])
+  {
+    PQP_E(c) if (in(c)) dst[idx(c)] = v[c];
+  }
+  __device__ __forceinline__ void vzero(double (&v)[E]) { PQP_E(c) v[c] = 0.0; }
+  __device__ __forceinline__ void vcopy(double (&a)[E], const double (&b)[E]) { PQP_E(c) a[c] = b[c]; }
+  // Ruiz scaling of the constraint rows: delta_in (C form) / delta_box (box form)
+  __device__ __forceinline__ cgptr dlt_c() const { return cform ? P.dlt_in() : P.dlt_box(); }
+
+  // rank of element (c, lane) among the elements with `flag`, in ascending element order; total in `tot`
+  __device__ __forceinline__ void ranks(const bool (&flag)[E], int (&rk)[E], int& tot)
+  {
+    int before = 0;
+    PQP_E(c)
+    {
+      const unsigned long long m = __ballot(flag[c] ? 1 : 0);
+      rk[c] = before + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (WAVE - lane))));
+      before += __popcll(m);
+    }
+    tot = uni(before);
+  }
+
+  // ---- the equilibrated vectors of a dirty re-solve (Solver::solve -> write_scaled(..., diag_only, matrices) with the
+  // stored scaling: reference solver.hpp:1192-1214; u, l unclamped, the box bounds clamped, helpers.hpp:638-649)
+  __device__ __forceinline__ void rescale(bool matrices)
+  {
+    cgptr S = P.delta();
+    const double c = ruiz_c;
+    double Sx[E], Sc[E];
+    vload(Sx, S);
+    if (hasc)
+      vload(Sc, S + n);
+    if (matrices) {
+      cgptr H = P.H();
+      gptr Hs = P.Hs(), hdg = P.F();
+      PQP_E(k) if (in(k))
+      {
+        const long o = (long)idx(k) * n + idx(k);
+        const double h = H[o];
+        const double v = (d.hessian == PQP_HESSIAN_DIAGONAL) ? h * Sx[k] * Sx[k] * c : h * c;
+        Hs[o] = v;
+        hdg[idx(k)] = v;
+      }
+      if (cform) {
+        cgptr C = P.C();
+        gptr Cs = P.Cs(), cd = P.CTs();
+        PQP_E(k) if (in(k))
+        {
+          const long o = (long)idx(k) * n + idx(k);
+          const double v = Sc[k] * C[o] * Sx[k];
+          Cs[o] = v;
+          cd[idx(k)] = v;
+        }
+      }
+      bytes(((long)n * 3 + (long)d.n_in * 3) * 8);
+    }
+    {
+      cgptr g = P.g();
+      gptr gsg = P.gs();
+      PQP_E(k) if (in(k)) gsg[idx(k)] = g[idx(k)] * Sx[k] * c;
+    }
+    if (cform) {
+      cgptr u = P.u(), l = P.l();
+      gptr us = P.us(), ls = P.ls();
+      PQP_E(k) if (in(k))
+      {
+        us[idx(k)] = u[idx(k)] * Sc[k];
+        ls[idx(k)] = l[idx(k)] * Sc[k];
+      }
+    }
+    if (boxf) {
+      cgptr u = P.u_box(), l = P.l_box();
+      gptr us = P.ubs(), ls = P.lbs(), is = P.is();
+      PQP_E(k) if (in(k))
+      {
+        double uu = u[idx(k)], ll = l[idx(k)];
+        uu = (uu <= 1.E20) ? uu : 1.E20;
+        ll = (ll >= -1.E20) ? ll : -1.E20;
+        us[idx(k)] = uu * Sc[k];
+        ls[idx(k)] = ll * Sc[k];
+        is[idx(k)] = Sx[k] * Sc[k];
+      }
+    }
+    // (delta is rewritten with the values it holds by the workgroup kernels: nothing to do)
+    __syncthreads();
+  }
+
+  // ---- primal block: L = I, D = diag(H_s) + rho; one entry of Z and of the Gram matrix per constraint
+  // (Solver::factor_primal_block + build_ZG, their dm() branches)
+  __device__ __forceinline__ void factor_primal_block()
+  {
+    const double rho = info.rho;
+    PQP_E(c) dF[c] = in(c) ? ((hess() == PQP_HESSIAN_DIAGONAL) ? hd[c] : 0.0) + rho : 1.0;
+    vstore(P.dF(), dF);
+    if (hasc) {
+      gptr Zr = P.Zr(), gdg = P.G();
+      PQP_E(c)
+      {
+        gd[c] = in(c) ? zd[c] * zd[c] / dF[c] : 0.0;
+        if (in(c)) {
+          Zr[idx(c)] = zd[c];
+          gdg[idx(c)] = gd[c];
+        }
+      }
+      bytes((long)d.nd * 8 * 3);
+    }
+  }
+
+  // ---- active set from fl bit 2 (Solver::apply_active_set, dm() path: never incremental; the slot order is the
+  // ascending constraint order, which only the persistent slot list and dS in HBM ever see)
+  __device__ __forceinline__ void apply_active_set()
+  {
+    tic();
+    double n_add = 0, n_rm = 0;
+    if (hasc) {
+      PQP_E(c)
+      {
+        const bool want = (fl[c] & 4) != 0, had = (fl[c] & 8) != 0;
+        n_add += (want && !had) ? 1.0 : 0.0;
+        n_rm += (!want && had) ? 1.0 : 0.0;
+      }
+    }
+    n_add = wave_sum(n_add);
+    n_rm = wave_sum(n_rm);
+    const int na = (int)n_add, nr = (int)n_rm;
+    if (na + nr == 0 && !schur_dirty) {
+      toc(ST_CYC_ZG);
+      return;
+    }
+    double tot = 0;
+    PQP_E(c)
+    {
+      const bool want = (fl[c] & 4) != 0;
+      fl[c] = (fl[c] & 7) | (want ? 8 : 0);
+      tot += want ? 1.0 : 0.0;
+    }
+    n_c = (int)wave_sum(tot);
+    schur_dirty = true;
+    toc(ST_CYC_ZG);
+    if (n_c > 0) {
+      // diagonal Schur block: D_S = mu_in + gd over the active constraints (Solver::factor_schur)
+      const double mu_in = info.mu_in;
+      PQP_E(c) dS[c] = active(c) ? mu_in + gd[c] : 1.0;
+      bytes((long)n_c * 8);
+      count(ST_N_SCHUR_FACT);
+    }
+    schur_dirty = false;
+    toc(ST_CYC_SCHUR);
+  }
+
+  // ---- K = [[D, Z_J^T], [Z_J, -mu I]] solved element-wise (Solver::kkt_solve_in_place, dm() branch)
+  __device__ __forceinline__ void kkt_solve_in_place(double (&bx)[E], double (&bd)[E])
+  {
+    PQP_E(c)
+    {
+      double t = bx[c];
+      if (active(c)) {
+        const double s = zd[c] * (bx[c] / dF[c]) - bd[c];
+        bd[c] = s / dS[c];
+        t -= zd[c] * bd[c];
+      }
+      bx[c] = t / dF[c];
+    }
+    bytes((long)n_c * 16);
+    count(ST_N_KKT_SOLVES);
+  }
+
+  // err = rhs - K sol; by-products Hdx, Cdx, CTdz (Solver::kkt_residual)
+  __device__ __forceinline__ double kkt_residual()
+  {
+    const double rho = info.rho, mu_in = info.mu_in;
+    double m = 0;
+    PQP_E(c)
+    {
+      Hdx[c] = (hess() == PQP_HESSIAN_DIAGONAL) ? hd[c] * dx[c] : 0.0;
+      if (hasc) {
+        Cdx[c] = zd[c] * dx[c];
+        CTdz[c] = zd[c] * zfull[c];
+      } else {
+        CTdz[c] = 0.0;
+      }
+      const double e = rx[c] - rho * dx[c] - Hdx[c] - CTdz[c];
+      ex[c] = e;
+      m = fmax(m, fabs(e));
+      if (active(c)) {
+        const double e2 = rd[c] - (Cdx[c] - sd[c] * mu_in);
+        ed[c] = e2;
+        m = fmax(m, fabs(e2));
+      }
+    }
+    bytes(((long)n + (long)d.n_in) * 8);
+    return wave_max(m);
+  }
+
+  // reference solver.hpp:406-541 (Solver::iterative_solve): solve + refinement on the unfactorised operator
+  __device__ __forceinline__ void iterative_solve(double eps)
+  {
+    PQP_E(c)
+    {
+      dx[c] = 0.0;
+      sd[c] = 0.0;
+      ex[c] = rx[c];
+      ed[c] = rd[c];
+    }
+    long it = 0, it_stability = 0;
+    UD preverr = 0, cur = 0;
+    while (true) {
+      tic();
+      kkt_solve_in_place(ex, ed);
+      PQP_E(c)
+      {
+        dx[c] += ex[c];
+        if (active(c)) {
+          sd[c] += ed[c];
+          zfull[c] = sd[c];
+        } else {
+          zfull[c] = 0.0;
+        }
+      }
+      toc(ST_CYC_KKT_SOLVE);
+      cur = kkt_residual();
+      toc(ST_CYC_RESIDUAL);
+      ++it;
+      if (it > 1) {
+        if (cur > preverr)
+          it_stability += 1;
+        else
+          it_stability = 0;
+        if (it_stability == 2)
+          break;
+      }
+      preverr = cur;
+      if (!(cur >= eps))
+        break;
+      if (it >= st.nb_iterative_refinement)
+        break;
+    }
+    info.iterative_residual = cur;
+  }
+
+  // mode 0: semismooth Newton step (reference solver.hpp:754-869); 1: equality-constrained initial guess
+  // (helpers.hpp:199-228); 2: install the active set in fl only (solver.hpp:1231-1240)   (Solver::linear_step)
+  __device__ __forceinline__ void linear_step(int mode, double eps)
+  {
+    const double zfac = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
+    if (mode == 0 && hasc) {
+      PQP_E(c) if (in(c))
+      {
+        const int up = rup[c] >= 0 ? 1 : 0;
+        const int lo = si[c] <= 0 ? 2 : 0;
+        fl[c] = (fl[c] & 8) | up | lo | ((up | lo) ? 4 : 0);
+      }
+    }
+    apply_active_set();
+    if (mode == 2)
+      return;
+    tic();
+    if (mode == 0) {
+      PQP_E(c)
+      {
+        zfull[c] = active(c) ? 0.0 : z[c]; // inactive multipliers
+        CTzin[c] = hasc ? zd[c] * zfull[c] : 0.0;
+        rx[c] = -dres[c] + CTzin[c];
+        double v = 0;
+        if (active(c)) {
+          if (fl[c] & 1)
+            v = -rup[c] + z[c] * info.mu_in * zfac;
+          else if (fl[c] & 2)
+            v = -si[c] + z[c] * info.mu_in * zfac;
+        }
+        rd[c] = v;
+      }
+    } else {
+      PQP_E(c)
+      {
+        rx[c] = -gs[c];
+        rd[c] = 0.0;
+      }
+    }
+    toc(ST_CYC_NEWTON_MISC);
+    iterative_solve(eps);
+    if (mode == 1) {
+      vcopy(x, dx);
+      return;
+    }
+    PQP_E(c)
+    {
+      dz[c] = active(c) ? sd[c] : -z[c];
+      CTdz[c] -= CTzin[c];
+    }
+  }
+
+  // ---- exact line search (reference linesearch.hpp:320-538; Solver::primal_dual_ls / ls_bracket).
+  // Inequality part of (a, b) of phi' at NP step lengths: every lane sums the terms of its own constraints, one wavefront
+  // reduction per sum.
+  template<int NP>
+  __device__ __forceinline__ void ls_terms(const double (&al)[NP], double (&a_in)[NP], double (&b_in)[NP])
+  {
+    const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
+    double sa[NP], sb[NP], sa2[NP], sb2[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      sa[p] = sb[p] = sa2[p] = sb2[p] = 0.0;
+    PQP_E(c)
+    {
+      const double cdx = Cdx[c], up0 = rup[c], lo0 = si[c];
+      const double dzi = dz[c] * info.mu_in, zi = z[c] * info.mu_in;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const bool up = (up0 + cdx * al[p]) > 0.;
+        const bool lw = (lo0 + cdx * al[p]) < 0.;
+        const double e = (up || lw) ? cdx : 0.0;
+        const double apz = (up ? up0 : 0.0) + (lw ? lo0 : 0.0);
+        sa[p] = fma(e, e, sa[p]);
+        sb[p] = fma(apz, e, sb[p]);
+        if (!gpdal) {
+          const double e2 = e - dzi, apz2 = apz - zi;
+          sa2[p] = fma(e2, e2, sa2[p]);
+          sb2[p] = fma(e2, apz2, sb2[p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      sa[p] = wave_sum(sa[p]);
+      sb[p] = wave_sum(sb[p]);
+      if (gpdal) {
+        a_in[p] = info.mu_in_inv * sa[p] / st.alpha_gpdal;
+        b_in[p] = info.mu_in_inv * sb[p] / st.alpha_gpdal;
+      } else {
+        sa2[p] = wave_sum(sa2[p]);
+        sb2[p] = wave_sum(sb2[p]);
+        a_in[p] = info.mu_in_inv * sa[p] + info.nu * info.mu_in_inv * sa2[p];
+        b_in[p] = info.mu_in_inv * sb[p] + info.nu * info.mu_in_inv * sb2[p];
+      }
+    }
+  }
+  __device__ __forceinline__ double ls_grad(double al, double a0, double b0)
+  {
+    const double a1[1] = { al };
+    double ai[1], bi[1];
+    ls_terms<1>(a1, ai, bi);
+    return (a0 + ai[0]) * al + (b0 + bi[0]);
+  }
+
+  static constexpr int NBP = 2 * E; // breakpoints a lane owns: two per constraint
+
+  // phi' at three step lengths (values that only steer the bracket) + the number of breakpoints in (lo, al[p]] and in
+  // (lo, hi]   (Solver::ls_grad3)
+  __device__ __forceinline__ void ls_grad3(const double (&al)[3], double a0, double b0, double bmag, const double (&mine)[NBP],
+                                           double lo, double hi, double (&g)[3], double (&mag)[3], double (&cle)[3], double& ctot)
+  {
+    double ai[3], bi[3];
+    ls_terms<3>(al, ai, bi);
+    double cl[3] = { 0, 0, 0 }, ct = 0;
+#pragma unroll
+    for (int r = 0; r < NBP; ++r)
+      if (mine[r] > lo && mine[r] <= hi) {
+        ct += 1.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          if (mine[r] <= al[p])
+            cl[p] += 1.0;
+      }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      g[p] = (a0 + ai[p]) * al[p] + (b0 + bi[p]);
+      mag[p] = fabs((a0 + ai[p]) * al[p]) + fabs(b0) + bmag;
+      cle[p] = wave_sum(cl[p]);
+    }
+    ctot = wave_sum(ct);
+  }
+
+  // The breakpoints flagged in `take` evaluated exactly, then the selections of linesearch.hpp:427-536.  `pred`: the
+  // largest breakpoint at or below the bracket (0: none).  false: the caller must evaluate every breakpoint.
+  __device__ __forceinline__ bool ls_select(const double (&mine)[NBP], const bool (&take)[NBP], double a0, double b0, double pred,
+                                            bool all_negative, double amax, bool everything, double& result)
+  {
+    const double INF = __builtin_inf();
+    double gr[NBP];
+#pragma unroll
+    for (int r = 0; r < NBP; ++r)
+      gr[r] = 0.0;
+    int nev = 0;
+#pragma unroll
+    for (int r = 0; r < NBP; ++r) {
+      unsigned long long m = __ballot(take[r] ? 1 : 0);
+      while (m != 0ull) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const double al = wave_bcast(mine[r], src);
+        const double g = ls_grad(al, a0, b0);
+        if (lane == src)
+          gr[r] = g;
+        ++nev;
+      }
+    }
+    count(ST_N_LS_BREAKPOINTS, nev);
+    double afp = INF;
+#pragma unroll
+    for (int r = 0; r < NBP; ++r)
+      if (take[r] && !(gr[r] < 0) && mine[r] < afp)
+        afp = mine[r];
+    afp = wave_min(afp);
+    if (all_negative) {
+      if (afp < INF)
+        return false; // the exact value at the largest breakpoint is not negative after all
+      double a1[1] = { 2 * amax + 1 }, ai[1], bi[1];
+      ls_terms<1>(a1, ai, bi);
+      result = -(b0 + bi[0]) / (a0 + ai[0]);
+      return true;
+    }
+    double aln = 0.0;
+    if (!(afp < INF)) {
+      if (!everything)
+        return false;
+      // no breakpoint with phi' >= 0 (linesearch.hpp:496-526): aln = the largest one
+#pragma unroll
+      for (int r = 0; r < NBP; ++r)
+        if (take[r])
+          aln = fmax(aln, mine[r]);
+      aln = wave_max(aln);
+      double a1[1] = { 2 * aln + 1 }, ai[1], bi[1];
+      ls_terms<1>(a1, ai, bi);
+      result = -(b0 + bi[0]) / (a0 + ai[0]);
+      return true;
+    }
+    if (pred > 0.0 && !(afp > pred))
+      return false; // phi'(pred) >= 0 exactly: the zero lies further left than the bracket said
+    double gfp = -INF;
+#pragma unroll
+    for (int r = 0; r < NBP; ++r)
+      if (take[r]) {
+        if (mine[r] == afp && !(gr[r] < 0))
+          gfp = fmax(gfp, gr[r]);
+        if (mine[r] < afp)
+          aln = fmax(aln, mine[r]);
+      }
+    gfp = wave_max(gfp);
+    aln = wave_max(aln);
+    double gln = -INF;
+#pragma unroll
+    for (int r = 0; r < NBP; ++r)
+      if (take[r] && mine[r] == aln)
+        gln = fmax(gln, gr[r]);
+    gln = wave_max(gln);
+    if (aln == 0.0) { // no breakpoint before afp: linesearch.hpp:477-495
+      if (pred > 0.0)
+        return false;
+      double a1[1] = { 0.0 }, ai[1], bi[1];
+      ls_terms<1>(a1, ai, bi);
+      gln = b0 + bi[0];
+    }
+    result = fabs(aln - gln * (afp - aln) / (gfp - gln)); // linesearch.hpp:534-536
+    return true;
+  }
+
+  __device__ __forceinline__ double primal_dual_ls(double& dw_max)
+  {
+    const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
+    const double INF = __builtin_inf();
+    double s_dxHdx = 0, s_dx2 = 0, s_xHdx = 0, s_errdx = 0, s_dz2 = 0, s_dzz = 0, s_bmag = 0, dwm = 0;
+    PQP_E(c)
+    {
+      const double dxk = dx[c];
+      dwm = fmax(dwm, fabs(dxk));
+      s_dxHdx += dxk * Hdx[c];
+      s_dx2 += dxk * dxk;
+      s_xHdx += x[c] * Hdx[c];
+      s_errdx += (info.rho * (x[c] - xp[c]) + gs[c]) * dxk;
+    }
+    PQP_E(c)
+    {
+      dwm = fmax(dwm, fabs(dz[c]));
+      s_dz2 += dz[c] * dz[c];
+      s_dzz += dz[c] * z[c];
+      const double ac = fabs(Cdx[c]), ar = fabs(rup[c]) + fabs(si[c]);
+      s_bmag = fma(ar, ac, s_bmag);
+      if (!gpdal)
+        s_bmag = fma(double(info.nu) * (ar + fabs(z[c]) * info.mu_in), ac + fabs(dz[c]) * info.mu_in, s_bmag);
+    }
+    dw_max = wave_max(dwm);
+    s_dxHdx = wave_sum(s_dxHdx);
+    s_dx2 = wave_sum(s_dx2);
+    s_xHdx = wave_sum(s_xHdx);
+    s_errdx = wave_sum(s_errdx);
+    s_dz2 = wave_sum(s_dz2);
+    s_dzz = wave_sum(s_dzz);
+    s_bmag = wave_sum(s_bmag);
+    const double nu = gpdal ? 1.0 : double(info.nu);
+    double a0 = s_dxHdx + info.mu_eq_inv * 0.0 + info.rho * s_dx2 + 0.0 * info.mu_eq_inv * nu;
+    double b0 = s_xHdx + s_errdx + info.mu_eq_inv * 0.0 + nu * info.mu_eq_inv * 0.0;
+    if (gpdal) {
+      a0 += info.mu_in * (1. - st.alpha_gpdal) * s_dz2;
+      b0 += info.mu_in * (1. - st.alpha_gpdal) * s_dzz;
+    }
+    const double bmag = gpdal ? info.mu_in_inv * s_bmag / st.alpha_gpdal : info.mu_in_inv * s_bmag;
+    sub_tic(ST_CYC_LS_EVAL);
+    // this lane's breakpoints (linesearch.hpp:378-391): two per constraint
+    double mine[NBP];
+    double cnt = 0, amax = 0, amin_neg = -INF;
+    PQP_E(c)
+    {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        double al = -1.0;
+        if (in(c) && Cdx[c] != 0.) {
+          const double num = h ? si[c] : rup[c];
+          al = -num / (Cdx[c] + MACHINE_EPS);
+        }
+        const bool ok = al > MACHINE_EPS;
+        mine[2 * c + h] = ok ? al : -1.0;
+        if (ok) {
+          cnt += 1.0;
+          amax = fmax(amax, al);
+          amin_neg = fmax(amin_neg, -al);
+        }
+      }
+    }
+    cnt = wave_sum(cnt);
+    amax = wave_max(amax);
+    amin_neg = wave_max(amin_neg);
+    double result = 0;
+    if (cnt == 0.0) { // linesearch.hpp:405-419
+      double a1[1] = { 0.0 }, ai[1], bi[1];
+      ls_terms<1>(a1, ai, bi);
+      sub_toc(ST_CYC_LS_EVAL);
+      return -(b0 + bi[0]) / (a0 + ai[0]);
+    }
+    constexpr int WCAP = 32; // breakpoints evaluated exactly at most before the bracket is given up
+    bool take[NBP];
+    bool done = false;
+    if (cnt > 8.0 && amax < INF) {
+      // bracket (lo, hi] of the zero of the monotone phi' (Solver::ls_bracket): phi'(lo) < 0 surely, phi'(hi) > 0 surely
+      const double SURE = 3.6e-15 * (double)(d.nc + d.n + d.n_eq);
+      const double floor_ = -0.5 * amin_neg;
+      double lo = 0.0, hi = amax, inside = cnt;
+      bool all_negative = false, give_up = false;
+      {
+        const double al[3] = { 0.0, sqrt(floor_) * sqrt(amax), amax };
+        double g[3], mag[3], cle[3], ctot;
+        ls_grad3(al, a0, b0, bmag, mine, 0.0, amax, g, mag, cle, ctot);
+        if (!(g[0] < -SURE * mag[0]))
+          give_up = true;
+        else if (g[2] < -SURE * mag[2])
+          all_negative = true;
+        else if (!(g[2] > SURE * mag[2]))
+          give_up = true;
+        else if (g[1] < -SURE * mag[1]) {
+          lo = al[1];
+          inside = ctot - cle[1];
+        } else if (g[1] > SURE * mag[1]) {
+          hi = al[1];
+          inside = cle[1];
+        }
+      }
+      if (!give_up && !all_negative) {
+        for (int round = 0; round < 6 && inside > 6.0; ++round) {
+          const double base = fmax(lo, floor_);
+          const double r4 = sqrt(sqrt(hi / base));
+          const double al[3] = { base * r4, base * r4 * r4, base * r4 * r4 * r4 };
+          double g[3], mag[3], cle[3], ctot;
+          ls_grad3(al, a0, b0, bmag, mine, lo, hi, g, mag, cle, ctot);
+          double nlo = lo, nhi = hi, below = 0.0, upto = ctot;
+          int first_pos = 3;
+#pragma unroll
+          for (int p = 2; p >= 0; --p)
+            if (g[p] > SURE * mag[p])
+              first_pos = p;
+          if (first_pos < 3) {
+            nhi = al[first_pos];
+            upto = cle[first_pos];
+          }
+          bool moved = first_pos < 3;
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            if (p < first_pos && g[p] < -SURE * mag[p]) {
+              nlo = al[p];
+              below = cle[p];
+              moved = true;
+            }
+          if (!(nlo < nhi)) {
+            give_up = true;
+            break;
+          }
+          lo = nlo;
+          hi = nhi;
+          inside = upto - below;
+          if (!moved)
+            break;
+        }
+        if (inside > double(WCAP - 3))
+          give_up = true;
+      }
+      if (!give_up) {
+        double pred = 0.0, succ = INF;
+        if (!all_negative) {
+          double below = 0.0, above = -INF;
+#pragma unroll
+          for (int r = 0; r < NBP; ++r)
+            if (mine[r] > 0) {
+              if (mine[r] <= lo)
+                below = fmax(below, mine[r]);
+              if (mine[r] > hi)
+                above = fmax(above, -mine[r]);
+            }
+          pred = wave_max(below);
+          succ = -wave_max(above);
+        }
+#pragma unroll
+        for (int r = 0; r < NBP; ++r) {
+          const double a = mine[r];
+          take[r] = all_negative ? (a > 0 && a == amax) : (a > 0 && ((a > lo && a <= hi) || a == pred || a == succ));
+        }
+        done = ls_select(mine, take, a0, b0, pred, all_negative, amax, false, result);
+      }
+    }
+    if (!done) {
+      // every breakpoint (few of them, or a bracket that could not be trusted): the reference's own evaluation
+#pragma unroll
+      for (int r = 0; r < NBP; ++r)
+        take[r] = mine[r] > 0;
+      ls_select(mine, take, a0, b0, 0.0, false, amax, true, result);
+    }
+    sub_toc(ST_CYC_LS_EVAL);
+    return result;
+  }
+
+  // both infeasibility certificates + the inner stopping criterion (Solver::saddle_point_and_certificates;
+  // reference utils.hpp:269-324, :343-419, solver.hpp:687-743)
+  __device__ __forceinline__ void saddle_point_and_certificates(bool do_cert, double& err_in, bool& primal_infeasible,
+                                                                bool& dual_infeasible)
+  {
+    const double c = ruiz_c;
+    const double NEG = -__builtin_inf();
+    double lb1 = 0, gdx = 0, nrm_dz = 0, lb2 = 0, ndx = 0, nhdx = 0, mviol = NEG, e1 = 0, e3 = 0;
+    {
+      const double zf = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
+      PQP_E(k)
+      {
+        if (hasc && in(k)) {
+          const double up = rup[k], lo = si[k];
+          const double v = (up > 0 ? up : 0.0) + (lo < 0 ? lo : 0.0) - zf * z[k] * info.mu_in;
+          e1 = fmax(e1, fabs(v));
+        }
+        e3 = fmax(e3, fabs(dres[k]));
+      }
+    }
+    if (do_cert) {
+      cgptr dxs = P.dlt_x();
+      cgptr dcs = dlt_c();
+      double sx[E], sc_[E];
+      vload(sx, dxs, 1.0);
+      if (hasc)
+        vload(sc_, dcs, 1.0);
+      PQP_E(k) if (in(k))
+      {
+        const double sc = sx[k] * c;
+        CTdz[k] /= sc;
+        lb2 = fmax(lb2, fabs(0.0 + CTdz[k]));
+        Hdx[k] /= sc;
+        nhdx = fmax(nhdx, fabs(Hdx[k]));
+        gdx += dx[k] * gs[k];
+        dx[k] *= sx[k];
+        ndx = fmax(ndx, fabs(dx[k]));
+      }
+      if (hasc) {
+        PQP_E(k) if (in(k))
+        {
+          const double v = dz[k];
+          lb1 += (v > 0 ? v : 0.0) * ub[k];
+          lb1 -= (v < 0 ? v : 0.0) * lb[k];
+          dz[k] = cform ? v * sc_[k] / c : sc_[k] * v / c;
+          nrm_dz = fmax(nrm_dz, fabs(dz[k]));
+          Cdx[k] /= sc_[k];
+          // utils.hpp:381-398: two-sided bound -> |w| <= bound; no upper bound -> -w <= bound; no lower -> w <= bound
+          const double w = cform ? Cdx[k] : dx[k]; // (box form: the unscaled dx itself)
+          const double val = (ub[k] <= 1.E20 && lb[k] >= -1.E20) ? fabs(w) : ((ub[k] > 1.E20) ? -w : w);
+          mviol = fmax(mviol, val);
+        }
+      }
+    }
+    lb1 = wave_sum(lb1);
+    gdx = wave_sum(gdx);
+    nrm_dz = wave_max(nrm_dz);
+    lb2 = wave_max(lb2);
+    ndx = wave_max(ndx);
+    nhdx = wave_max(nhdx);
+    mviol = wave_max(mviol);
+    e1 = wave_max(e1);
+    e3 = wave_max(e3);
+    err_in = fmax(e1, fmax(0.0, e3));
+    primal_infeasible = false;
+    dual_infeasible = false;
+    if (!do_cert)
+      return;
+    {
+      const double upper_bound = st.eps_primal_inf * fmax(0.0, nrm_dz);
+      primal_infeasible = (nrm_dz != 0) && lb2 <= upper_bound && lb1 <= -upper_bound;
+    }
+    {
+      double bound = ndx * st.eps_dual_inf;
+      const bool first_cond = (0.0 <= bound) && !(mviol > bound);
+      bound *= c;
+      const bool second_cond_alt1 = nhdx <= bound && gdx <= -bound;
+      dual_infeasible = first_cond && second_cond_alt1 && ndx != 0;
+    }
+  }
+
+  // reference solver.hpp:882-1077 (Solver::newton_semi_smooth)
+  __device__ __forceinline__ void newton_semi_smooth(double eps_int)
+  {
+    for (long iter = 0; iter <= st.max_iter_in; ++iter) {
+      if (iter == st.max_iter_in) {
+        info.iter += st.max_iter_in + 1;
+        break;
+      }
+      count(ST_N_NEWTON);
+      linear_step(0, eps_int);
+      tic();
+      if (st.merit_function_type == PQP_MERIT_GPDAL && hasc) {
+        PQP_E(c) Cdx[c] += (st.alpha_gpdal - 1.) * info.mu_in * dz[c];
+      }
+      UD alpha = 1.0;
+      double dw_max = 0;
+      if (hasc) {
+        alpha = primal_dual_ls(dw_max);
+      } else {
+        PQP_E(c) dw_max = fmax(dw_max, fabs(dx[c]));
+        dw_max = wave_max(dw_max);
+      }
+      toc(ST_CYC_LINESEARCH);
+      sub_tic(ST_CYC_UPDATE);
+      if (fabs(alpha) * dw_max < 1.E-11 && iter > 0) {
+        info.iter += iter + 1;
+        sub_toc(ST_CYC_UPDATE);
+        break;
+      }
+      PQP_E(c)
+      {
+        x[c] += alpha * dx[c];
+        dres[c] += alpha * (info.rho * dx[c] + Hdx[c] + 0.0 + CTdz[c]);
+        if (hasc) {
+          rup[c] += alpha * Cdx[c];
+          si[c] += alpha * Cdx[c];
+          z[c] += alpha * dz[c];
+        }
+      }
+      sub_toc(ST_CYC_UPDATE);
+      bool stop = false;
+      UD err_in = 0.0;
+      {
+        sub_tic(ST_CYC_CERT);
+        const bool do_cert = iter % st.frequence_infeasibility_check == 0 || st.primal_infeasibility_solving;
+        bool is_primal_infeasible, is_dual_infeasible;
+        double e;
+        saddle_point_and_certificates(do_cert, e, is_primal_infeasible, is_dual_infeasible);
+        err_in = e;
+        if (PQP_UNLIKELY(st.verbose != 0))
+          trace_line(2.0, double(iter + 1), e, alpha, 0.0, 0.0, 0.0);
+        sub_toc(ST_CYC_CERT);
+        if (PQP_UNLIKELY(is_primal_infeasible)) {
+          info.status = PQP_PRIMAL_INFEASIBLE;
+          if (!st.primal_infeasibility_solving) {
+            info.iter += iter + 1;
+            stop = true;
+          }
+        } else if (PQP_UNLIKELY(is_dual_infeasible)) {
+          info.status = PQP_DUAL_INFEASIBLE;
+          info.iter += iter + 1;
+          stop = true;
+        }
+      }
+      toc(ST_CYC_NEWTON_MISC);
+      if (stop)
+        break;
+      if (err_in <= eps_int) {
+        info.iter += iter + 1;
+        break;
+      }
+      if (PQP_UNLIKELY(!(err_in == err_in))) {
+        info.iter += iter + 1;
+        nonfinite = true;
+        break;
+      }
+    }
+  }
+
+  // reference utils.hpp:164-252 (Solver::global_primal_residual, dm() branch)
+  __device__ __forceinline__ void global_primal_residual(UD& lhs, UD& eq_rhs_0, UD& in_rhs_0, UD& eq_lhs, UD& in_lhs)
+  {
+    double m_in0 = 0, m_inl = 0;
+    if (cform) {
+      cgptr di = P.dlt_in();
+      cgptr uu = P.u(), ll = P.l();
+      double dv[E], uv[E], lv[E];
+      vload(dv, di, 1.0);
+      vload(uv, uu);
+      vload(lv, ll);
+      PQP_E(k) if (in(k))
+      {
+        CTdz[k] = zd[k] * z[k];
+        const double v = (zd[k] * x[k]) / dv[k]; // unscaled C x
+        rup[k] = v;
+        m_in0 = fmax(m_in0, fabs(v));
+        const double pu = v - uv[k], pl = v - lv[k];
+        const double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
+        si[k] = sv;
+        m_inl = fmax(m_inl, fabs(sv));
+      }
+    } else {
+      vzero(CTdz);
+    }
+    if (boxf) {
+      cgptr dxs = P.dlt_x();
+      cgptr ubx = P.u_box(), lbx = P.l_box();
+      double dv[E], uv[E], lv[E];
+      vload(dv, dxs, 1.0);
+      vload(uv, ubx);
+      vload(lv, lbx);
+      PQP_E(k) if (in(k))
+      {
+        const double v = x[k] * dv[k]; // unscaled x
+        rup[k] = v;
+        const double pu = v - uv[k], pl = v - lv[k];
+        const double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
+        si[k] = sv;
+        m_inl = fmax(m_inl, fabs(sv));
+        m_in0 = fmax(m_in0, fabs(x[k] - sv)); // utils.hpp:225-229 (as written)
+        m_in0 = fmax(m_in0, fabs(x[k]));      // utils.hpp:230-231
+      }
+    }
+    aty_fresh = true;
+    bytes((long)d.n_in * 8);
+    eq_rhs_0 = 0.0;
+    in_rhs_0 = wave_max(m_in0);
+    eq_lhs = 0.0;
+    in_lhs = wave_max(m_inl);
+    lhs = fmax(eq_lhs, in_lhs);
+    if (PQP_UNLIKELY(st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)) {
+      // utils.hpp:241-248 : || A^T se + C^T si ||_inf on the unscaled model (C is diagonal here)
+      double m = 0;
+      if (cform) {
+        cgptr C = P.C();
+        PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + C[(long)idx(k) * n + idx(k)] * si[k]));
+      }
+      lhs = wave_max(m);
+    }
+  }
+
+  // reference utils.hpp:437-587 (Solver::global_dual_residual)
+  __device__ __forceinline__ void global_dual_residual(UD& lhs, UD& rhs_0, UD& rhs_1, UD& rhs_3, UD& rhs_duality_gap,
+                                                       UD& duality_gap)
+  {
+    const double c = ruiz_c;
+    double m0 = 0, m3 = 0, ml = 0, xHx = 0, gx = 0, zu = 0, zl = 0;
+    const double ib = 1.3407807929942596e+154; // sqrt(DBL_MAX), helpers/common.hpp:17-25
+    double sx[E], gv[E], sc_[E], uv[E], lv[E];
+    vload(sx, P.dlt_x(), 1.0);
+    vload(gv, P.g());
+    if (hasc) {
+      vload(sc_, dlt_c(), 1.0);
+      vload(uv, cform ? P.u() : P.u_box());
+      vload(lv, cform ? P.l() : P.l_box());
+    }
+    const bool have_products = aty_fresh;
+    bytes(((hess() == PQP_HESSIAN_ZERO ? 0L : (long)n) + (have_products ? 0L : (long)d.n_in)) * 8);
+    PQP_E(k) if (in(k))
+    {
+      const double sc = sx[k] * c;
+      const double hx = (hess() == PQP_HESSIAN_DIAGONAL) ? hd[k] * x[k] : 0.0;
+      double ctz = cform ? (have_products ? CTdz[k] : zd[k] * z[k]) : 0.0;
+      const double v = hx / sc; // unscaled H x (utils.hpp:469-471)
+      m0 = fmax(m0, fabs(v));
+      const double xu = x[k] * sx[k];
+      xHx += v * xu;
+      gx += gv[k] * xu;
+      double m3k = fabs(ctz / sc);
+      if (boxf) {
+        const double zb = z[k] * zd[k];
+        ctz += zb;
+        m3k = fmax(m3k, fabs(zb / sc));
+      }
+      m3 = fmax(m3, m3k);
+      const double dr = gs[k] + hx + 0.0 + ctz;
+      dres[k] = dr;
+      ml = fmax(ml, fabs(dr / sc));
+      if (hasc) {
+        // duality gap terms (utils.hpp:482-586)
+        const double zi = cform ? z[k] * sc_[k] / c : sc_[k] * z[k] / c;
+        const double uk = uv[k] < ib ? uv[k] : ib;
+        const double lk = lv[k] > -ib ? lv[k] : -ib;
+        if (fl[k] & 1)
+          zu += zi * uk;
+        if (fl[k] & 2)
+          zl += zi * lk;
+      }
+    }
+    gx = wave_sum(gx);
+    xHx = wave_sum(xHx);
+    zu = wave_sum(zu);
+    zl = wave_sum(zl);
+    m0 = wave_max(m0);
+    m3 = wave_max(m3);
+    ml = wave_max(ml);
+    rhs_0 = (hess() == PQP_HESSIAN_ZERO) ? 0.0 : m0;
+    rhs_1 = 0.0;
+    rhs_3 = m3;
+    lhs = ml;
+    duality_gap = gx;
+    rhs_duality_gap = fabs(gx);
+    if (hess() != PQP_HESSIAN_ZERO) {
+      duality_gap += xHx;
+      rhs_duality_gap = fmax(rhs_duality_gap, fabs(xHx));
+    }
+    // (no equality: by = 0)
+    rhs_duality_gap = fmax(rhs_duality_gap, 0.0);
+    duality_gap += 0.0;
+    if (cform) {
+      rhs_duality_gap = fmax(rhs_duality_gap, fabs(zu));
+      duality_gap += zu;
+      rhs_duality_gap = fmax(rhs_duality_gap, fabs(zl));
+      duality_gap += zl;
+    } else {
+      // (the general-inequality sums are empty; the box sums follow them in the reference's order)
+      rhs_duality_gap = fmax(rhs_duality_gap, 0.0);
+      duality_gap += 0.0;
+      rhs_duality_gap = fmax(rhs_duality_gap, 0.0);
+      duality_gap += 0.0;
+      if (boxf) {
+        rhs_duality_gap = fmax(rhs_duality_gap, fabs(zu));
+        duality_gap += zu;
+        rhs_duality_gap = fmax(rhs_duality_gap, fabs(zl));
+        duality_gap += zl;
+      }
+    }
+  }
+
+  // ---- reference solver.hpp:1088-1843 (Solver::solve)
+  __device__ __forceinline__ void solve()
+  {
+    State W = *P.state();
+    info.load(*P.info());
+    ruiz_c = W.ruiz_c;
+    dual_feasibility_rhs_2 = W.dual_feasibility_rhs_2;
+#ifdef PQP_STATS
+    for (int k = lane; k < ST_COUNT + 2; k += WAVE)
+      lds_stat[k] = 0;
+    __syncthreads();
+#endif
+    const long long cyc0 = clock64();
+    const long long wall0 = wall_clock64();
+    const int nc = d.nc;
+    // every register slot beyond dim holds a benign value from here on (0; 1 for the divisors dF, dS): the element-wise
+    // code runs over all E slots of all lanes, and the reductions take whatever those slots hold
+    PQP_E(c)
+    {
+      xp[c] = zp[c] = dres[c] = rup[c] = si[c] = 0.0;
+      dx[c] = dz[c] = Hdx[c] = Cdx[c] = CTdz[c] = CTzin[c] = rx[c] = rd[c] = ex[c] = ed[c] = sd[c] = zfull[c] = 0.0;
+    }
+    // results -> registers (the warm-start modes read them)
+    vload(x, P.x());
+    if (hasc)
+      vload(z, P.z());
+    else
+      vzero(z);
+    {
+      // the persistent active_set_up / active_set_low flags (bits 16-17 of act[i], see Solver::solve)
+      const PQP_GLOBAL int* ga = P.act();
+      PQP_E(c) fl[c] = (hasc && in(c)) ? act_flags(ga[idx(c)]) : 0;
+    }
+    const int ig = st.initial_guess;
+    const bool wswpr = (ig == PQP_WARM_START_WITH_PREVIOUS_RESULT);
+    const bool dirty = W.dirty != 0;
+    const bool do_rescale = dirty && !wswpr;
+    bool do_factor, do_scale_ws, do_aset_from_z, do_eq_guess = false, do_restore = false;
+    if (dirty) {
+      if (ig == PQP_EQUALITY_CONSTRAINED_INITIAL_GUESS || ig == PQP_NO_INITIAL_GUESS) {
+        vzero(x); // results.cleanup
+        vzero(z);
+        cold_start(info, st);
+      } else if (wswpr) {
+        cleanup_statistics(info);
+      } else {
+        cold_start(info, st);
+      }
+    }
+    if (ig == PQP_EQUALITY_CONSTRAINED_INITIAL_GUESS) {
+      do_factor = true;
+      do_scale_ws = false;
+      do_aset_from_z = false;
+      do_eq_guess = true;
+    } else if (ig == PQP_NO_INITIAL_GUESS) {
+      do_factor = true;
+      do_scale_ws = false;
+      do_aset_from_z = false;
+    } else if (ig == PQP_COLD_START_WITH_PREVIOUS_RESULT || ig == PQP_WARM_START) {
+      do_factor = true;
+      do_scale_ws = true;
+      do_aset_from_z = true;
+    } else { // WARM_START_WITH_PREVIOUS_RESULT
+      do_scale_ws = true;
+      if (!dirty && W.refactorize) {
+        do_factor = true;
+        do_aset_from_z = true;
+      } else if (!W.factor_valid) {
+        do_factor = true;
+        do_aset_from_z = true;
+      } else {
+        do_factor = false;
+        do_aset_from_z = false;
+        do_restore = true;
+      }
+    }
+    if (do_rescale) {
+      tic();
+      rescale(W.scaled_valid == 0);
+      toc(ST_CYC_SCALE);
+    }
+    // the equilibrated model: g_s, the bounds, the diagonals of H_s and of the constraint rows
+    vload(gs, P.gs());
+    vload(hd, P.F());
+    if (cform) {
+      vload(ub, P.us());
+      vload(lb, P.ls());
+      vload(zd, P.CTs());
+    } else if (boxf) {
+      vload(ub, P.ubs());
+      vload(lb, P.lbs());
+      vload(zd, P.is());
+    } else {
+      vzero(ub);
+      vzero(lb);
+      vzero(zd);
+    }
+    if (do_scale_ws) {
+      // solver.hpp:1137-1146: the warm start into the equilibrated space
+      double sx[E], sc_[E];
+      vload(sx, P.dlt_x(), 1.0);
+      PQP_E(k) x[k] /= sx[k];
+      if (hasc) {
+        vload(sc_, dlt_c(), 1.0);
+        PQP_E(k) z[k] = z[k] / sc_[k] * ruiz_c;
+      }
+    }
+    PQP_E(c)
+    {
+      dF[c] = 1.0;
+      dS[c] = 1.0;
+      gd[c] = 0.0;
+    }
+    if (do_factor) {
+      tic();
+      factor_primal_block();
+      toc(ST_CYC_FACTOR_H);
+      n_c = 0;
+      schur_dirty = true;
+    }
+    if (do_restore) {
+      // WARM_START_WITH_PREVIOUS_RESULT on an unchanged model: the state the previous solve left in HBM
+      // (solver.hpp:1173-1187, 1343-1375): D, the Gram entries, the slot list and D_S by slot
+      vload(dF, P.dF(), 1.0);
+      if (hasc)
+        vload(gd, P.G());
+      n_c = W.n_c;
+      const int n_slots = W.n_slots;
+      {
+        const PQP_GLOBAL int* ga = P.act();
+        cgptr dSg = P.dS();
+        for (int j = lane; j < 64 * E; j += WAVE)
+          lds_i[j] = -1;
+        __syncthreads();
+        for (int j = lane; j < n_slots; j += WAVE) {
+          const int i = act_cid(ga[j]);
+          if (i >= 0) {
+            lds_i[i] = j;
+            lds_d[i] = dSg[j];
+          }
+        }
+        __syncthreads();
+        PQP_E(c)
+        {
+          const int s = lds_i[idx(c)];
+          if (in(c) && s >= 0) {
+            fl[c] |= 8;
+            dS[c] = lds_d[idx(c)];
+          }
+        }
+        __syncthreads();
+      }
+      schur_dirty = !(W.ls_valid && W.mu_eq_fact == info.mu_eq && W.mu_in_fact == info.mu_in);
+    }
+    if (do_aset_from_z || do_eq_guess) {
+      if (do_aset_from_z) {
+        PQP_E(c) fl[c] = (fl[c] & 11) | ((z[c] != 0) ? 4 : 0); // only active_inequalities is rewritten (solver.hpp:1231-1238)
+      } else {
+        PQP_E(c) fl[c] = (fl[c] & 15); // (mode 1 keeps the wanted bits as they are: none set on this path)
+      }
+      linear_step(do_eq_guess ? 1 : 2, 1.0);
+    }
+
+    // BCL state (solver.hpp:1378-1395)
+    const UD bcl_eta_ext_init = pow(0.1, st.alpha_bcl);
+    UD bcl_eta_ext = bcl_eta_ext_init;
+    UD bcl_eta_in = 1;
+    const UD eps_in_min = fmin(st.eps_abs, 1.E-9);
+    UD primal_feasibility_eq_rhs_0 = 0, primal_feasibility_in_rhs_0 = 0;
+    UD dual_feasibility_rhs_0 = 0, dual_feasibility_rhs_1 = 0, dual_feasibility_rhs_3 = 0;
+    UD primal_feasibility_lhs = 0, primal_feasibility_eq_lhs = 0, primal_feasibility_in_lhs = 0;
+    UD dual_feasibility_lhs = 0;
+    UD duality_gap = 0, rhs_duality_gap = 0;
+    UD scaled_eps = st.eps_abs;
+    UD primal_feasibility_lhs_new = 0, dual_feasibility_lhs_new = 0;
+    UD new_bcl_mu_in = 0, new_bcl_mu_eq = 0, new_bcl_mu_in_inv = 0, new_bcl_mu_eq_inv = 0;
+    bool is_primal_feasible = false, is_dual_feasible = false;
+    long iter = 0;
+    int stage = 0; // 0: top of loop, 1: after the Newton loop, 2: before the mu update (see Solver::solve)
+    bool done = (st.max_iter <= 0);
+    bool gpr_fresh = false, gdr_fresh = false;
+    aty_fresh = false;
+    UD pl_cache = 0, dl_cache = 0;
+    while (!done) {
+      tic();
+      if (st.primal_infeasibility_solving)
+        gpr_fresh = false;
+      UD pl = pl_cache, dl = dl_cache;
+      const bool want_primal = (stage != 2);
+      const bool want_dual_pre = (stage != 1);
+      if (want_primal && !gpr_fresh) {
+        global_primal_residual(pl, primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0, primal_feasibility_eq_lhs,
+                               primal_feasibility_in_lhs);
+        pl_cache = pl;
+        gpr_fresh = true;
+      }
+      bool want_dual = want_dual_pre;
+      if (stage == 1) {
+        primal_feasibility_lhs_new = pl;
+        is_primal_feasible = primal_feasibility_lhs_new <=
+                             (scaled_eps + st.eps_rel * fmax(primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0));
+        info.pri_res = primal_feasibility_lhs_new;
+        want_dual = is_primal_feasible;
+      }
+      if (want_dual && !gdr_fresh) {
+        global_dual_residual(dl, dual_feasibility_rhs_0, dual_feasibility_rhs_1, dual_feasibility_rhs_3, rhs_duality_gap,
+                             duality_gap);
+        dl_cache = dl;
+        gdr_fresh = true;
+      }
+      toc(ST_CYC_GLOBAL_RES);
+      const UD rhs_dua_rel = st.eps_rel * fmax(fmax(dual_feasibility_rhs_3, dual_feasibility_rhs_0),
+                                               fmax(dual_feasibility_rhs_1, dual_feasibility_rhs_2));
+      if (stage == 0) {
+        primal_feasibility_lhs = pl;
+        dual_feasibility_lhs = dl;
+        info.pri_res = primal_feasibility_lhs;
+        info.dua_res = dual_feasibility_lhs;
+        info.duality_gap = duality_gap;
+        new_bcl_mu_in = info.mu_in;
+        new_bcl_mu_eq = info.mu_eq;
+        new_bcl_mu_in_inv = info.mu_in_inv;
+        new_bcl_mu_eq_inv = info.mu_eq_inv;
+        UD rhs_pri = scaled_eps;
+        if (st.eps_rel != 0)
+          rhs_pri += st.eps_rel * fmax(primal_feasibility_eq_rhs_0, primal_feasibility_in_rhs_0);
+        is_primal_feasible = primal_feasibility_lhs <= rhs_pri;
+        UD rhs_dua = st.eps_abs;
+        if (st.eps_rel != 0)
+          rhs_dua += rhs_dua_rel;
+        is_dual_feasible = dual_feasibility_lhs <= rhs_dua;
+        if (PQP_UNLIKELY(st.verbose != 0)) {
+          // solver.hpp:1469-1510: the reference's report block unscales x, y, z and scales them back
+          trace_line(1.0, double(info.iter_ext + 1), info.pri_res, info.dua_res, info.duality_gap, info.mu_in, info.rho);
+          double sx[E], sc_[E];
+          vload(sx, P.dlt_x(), 1.0);
+          PQP_E(k) x[k] = (x[k] * sx[k]) / sx[k];
+          if (hasc) {
+            vload(sc_, dlt_c(), 1.0);
+            if (cform) {
+              PQP_E(k) z[k] = (z[k] * sc_[k] / ruiz_c) / sc_[k] * ruiz_c;
+            } else {
+              PQP_E(k) z[k] = (sc_[k] * z[k] / ruiz_c) / sc_[k] * ruiz_c;
+            }
+          }
+        }
+        if (is_primal_feasible && is_dual_feasible) {
+          if (st.check_duality_gap) {
+            if (fabs(info.duality_gap) <= st.eps_duality_gap_abs + st.eps_duality_gap_rel * rhs_duality_gap) {
+              info.status = (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)
+                              ? PQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE
+                              : PQP_SOLVED;
+              break;
+            }
+          } else {
+            info.status = PQP_SOLVED;
+            break;
+          }
+        }
+        info.iter_ext += 1;
+        vcopy(xp, x);
+        vcopy(zp, z);
+        // shifted inequality residuals (solver.hpp:1523-1559)
+        if (hasc) {
+          double sc_[E];
+          vload(sc_, dlt_c(), 1.0);
+          PQP_E(i) if (in(i))
+          {
+            double v = rup[i] * sc_[i] + z[i] * info.mu_in;
+            if (st.merit_function_type == PQP_MERIT_GPDAL)
+              v += (st.alpha_gpdal - 1.) * info.mu_in * z[i];
+            rup[i] = v - ub[i];
+            si[i] = v - lb[i];
+          }
+        }
+        newton_semi_smooth(bcl_eta_in);
+        gpr_fresh = false;
+        gdr_fresh = false;
+        aty_fresh = false;
+        if (PQP_UNLIKELY(nonfinite)) {
+          info.status = PQP_MAX_ITER_REACHED;
+          break;
+        }
+        if ((info.status == PQP_PRIMAL_INFEASIBLE && !st.primal_infeasibility_solving) || info.status == PQP_DUAL_INFEASIBLE) {
+          vcopy(x, dx); // certificates (solver.hpp:1572-1580)
+          vcopy(z, dz);
+          break;
+        }
+        if (PQP_UNLIKELY(scaled_eps == st.eps_abs && st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)) {
+          // solver.hpp:1581-1595 : || A^T 1 + C^T 1 (+ i_scaled) ||_inf * eps_abs   (C diagonal)
+          double m = 0;
+          if (cform) {
+            cgptr C = P.C();
+            PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + C[(long)idx(k) * n + idx(k)] * 1.0 + 0.0));
+          } else if (boxf) {
+            PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + 0.0 + zd[k]));
+          }
+          scaled_eps = wave_max(m) * st.eps_abs;
+        }
+        stage = 1;
+        continue;
+      }
+      if (stage == 1) {
+        if (is_primal_feasible) {
+          dual_feasibility_lhs_new = dl;
+          info.dua_res = dual_feasibility_lhs_new;
+          info.duality_gap = duality_gap;
+          is_dual_feasible = dual_feasibility_lhs_new <= (st.eps_abs + rhs_dua_rel);
+          if (is_dual_feasible) {
+            bool gap_ok = true;
+            if (st.check_duality_gap)
+              gap_ok = fabs(info.duality_gap) <= st.eps_duality_gap_abs + st.eps_duality_gap_rel * rhs_duality_gap;
+            if (gap_ok)
+              info.status = (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)
+                              ? PQP_SOLVED_CLOSEST_PRIMAL_FEASIBLE
+                              : PQP_SOLVED;
+          }
+        }
+        if (st.bcl_update) { // solver.hpp:564-614
+          if (primal_feasibility_lhs_new <= bcl_eta_ext || info.iter > st.safe_guard) {
+            bcl_eta_ext *= pow(info.mu_in, st.beta_bcl);
+            bcl_eta_in = fmax(bcl_eta_in * info.mu_in, eps_in_min);
+          } else {
+            vcopy(z, zp);
+            gdr_fresh = false; // z was reset
+            aty_fresh = false;
+            new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
+            new_bcl_mu_eq = fmax(info.mu_eq * st.mu_update_factor, st.mu_min_eq);
+            new_bcl_mu_in_inv = fmin(info.mu_in_inv * st.mu_update_inv_factor, st.mu_max_in_inv);
+            new_bcl_mu_eq_inv = fmin(info.mu_eq_inv * st.mu_update_inv_factor, st.mu_max_eq_inv);
+            bcl_eta_ext = bcl_eta_ext_init * pow(new_bcl_mu_in, st.alpha_bcl);
+            bcl_eta_in = fmax(new_bcl_mu_in, eps_in_min);
+          }
+        } else { // Martinez, solver.hpp:637-677
+          bcl_eta_in = fmax(bcl_eta_in * 0.1, eps_in_min);
+          if (!(primal_feasibility_lhs_new <= 0.95 * primal_feasibility_lhs)) {
+            new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
+            new_bcl_mu_eq = fmax(info.mu_eq * st.mu_update_factor, st.mu_min_eq);
+            new_bcl_mu_in_inv = fmin(info.mu_in_inv * st.mu_update_inv_factor, st.mu_max_in_inv);
+            new_bcl_mu_eq_inv = fmin(info.mu_eq_inv * st.mu_update_inv_factor, st.mu_max_eq_inv);
+          }
+        }
+        stage = 2;
+        continue;
+      }
+      // stage 2 (solver.hpp:1693-1746)
+      dual_feasibility_lhs_new = dl;
+      info.dua_res = dual_feasibility_lhs_new;
+      info.duality_gap = duality_gap;
+      if (primal_feasibility_lhs_new >= primal_feasibility_lhs && dual_feasibility_lhs_new >= dual_feasibility_lhs &&
+          info.mu_in <= 1e-5) {
+        new_bcl_mu_in = st.cold_reset_mu_in; // cold restart
+        new_bcl_mu_eq = st.cold_reset_mu_eq;
+        new_bcl_mu_in_inv = st.cold_reset_mu_in_inv;
+        new_bcl_mu_eq_inv = st.cold_reset_mu_eq_inv;
+      }
+      if (info.mu_in != new_bcl_mu_in || info.mu_eq != new_bcl_mu_eq) {
+        ++info.mu_updates;
+        if (n_c > 0)
+          schur_dirty = true; // mu_update (solver.hpp:128-232): a diagonal shift of the Schur block
+      }
+      info.mu_eq = new_bcl_mu_eq;
+      info.mu_in = new_bcl_mu_in;
+      info.mu_eq_inv = new_bcl_mu_eq_inv;
+      info.mu_in_inv = new_bcl_mu_in_inv;
+      stage = 0;
+      ++iter;
+      if (iter >= st.max_iter)
+        done = true;
+    }
+
+    // unscale the solution (solver.hpp:1749-1767)
+    {
+      double sx[E], sc_[E];
+      vload(sx, P.dlt_x(), 1.0);
+      PQP_E(k) x[k] *= sx[k];
+      if (hasc) {
+        vload(sc_, dlt_c(), 1.0);
+        if (cform) {
+          PQP_E(k) z[k] = z[k] * sc_[k] / ruiz_c;
+        } else {
+          PQP_E(k) z[k] = sc_[k] * z[k] / ruiz_c;
+        }
+        if (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE) {
+          PQP_E(k) si[k] /= sc_[k];
+        }
+      }
+    }
+    // objective on the unscaled model (solver.hpp:1771-1780)
+    {
+      double obj = 0;
+      cgptr g = P.g();
+      cgptr H = P.H();
+      PQP_E(k) if (in(k)) obj += 0.5 * x[k] * x[k] * H[(long)idx(k) * n + idx(k)] + g[idx(k)] * x[k];
+      bytes((long)n * 8);
+      info.objValue = wave_sum(obj);
+    }
+    // write back
+    vstore(P.x(), x);
+    if (hasc) {
+      vstore(P.z(), z);
+      vstore(P.si(), si);
+    }
+    if (batch.hx) { // host-mapped mirrors (see Batch)
+      vstore((gptr)(batch.hx + P.lq() * n), x);
+      if (hasc) {
+        vstore((gptr)(batch.hz + P.lq() * nc), z);
+        vstore((gptr)(batch.hsi + P.lq() * nc), si);
+      }
+    }
+    if (hasc) {
+      // the slot list and D_S by slot (ascending constraint order), the persistent up / low flags in bits 16-17
+      bool act_[E];
+      int rk[E], tot;
+      PQP_E(c) act_[c] = active(c);
+      ranks(act_, rk, tot);
+      for (int j = lane; j < 64 * E; j += WAVE)
+        lds_i[j] = -1;
+      __syncthreads();
+      gptr dSg = P.dS();
+      PQP_E(c) if (active(c))
+      {
+        lds_i[rk[c]] = idx(c);
+        dSg[rk[c]] = dS[c];
+      }
+      __syncthreads();
+      PQP_GLOBAL int* ga = P.act();
+      PQP_E(c) if (in(c)) ga[idx(c)] = act_pack(lds_i[idx(c)], fl[c] & 3);
+    }
+    if (lane == 0) {
+      if (st.compute_timings) {
+        info.solve_time = (double)(wall_clock64() - wall0) * batch.wall_us_per_tick;
+        info.run_time = info.solve_time + info.setup_time;
+      }
+      info.store(*P.info());
+      if (batch.hinfo)
+        info.store(batch.hinfo[q]);
+      W.dirty = 1;
+      W.is_initialized = 1;
+      W.n_c = n_c;
+      W.n_slots = n_c;
+      W.factor_valid = 1;
+      W.ls_valid = schur_dirty ? 0 : 1;
+      W.ls_edited = 0;
+      W.mu_eq_fact = info.mu_eq;
+      W.mu_in_fact = info.mu_in;
+      W.rho_fact = info.rho;
+      *P.state() = W;
+      PQP_GLOBAL long long* gs_ = P.stats();
+#ifdef PQP_STATS
+      for (int k = 0; k < ST_COUNT; ++k)
+        gs_[k] = lds_stat[k];
+#else
+      for (int k = 0; k < ST_COUNT; ++k)
+        gs_[k] = 0;
+#endif
+      gs_[ST_N_ACTIVE_FINAL] = n_c;
+      gs_[ST_CYC_TOTAL] = clock64() - cyc0;
+      gs_[ST_WALL_TICKS] = wall_clock64() - wall0;
+    }
+  }
+};
+
+#undef PQP_E
+
+template<int E>
+__device__ __forceinline__ void
+diag_solve_body(const Batch& batch, long q, lptr lds)
+{
+  DiagSolver<E> S(batch, q, lds);
+  S.solve();
+}
+
+} // namespace pqp
+
+#endif

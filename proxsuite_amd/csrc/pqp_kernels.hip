@@ -37,6 +37,7 @@
 #define PQP_ZG_DEPTH 4
 #endif
 #include "pqp_host.hpp"
+#include "pqp_diag.hpp"
 
 #define PQP_TU_HAS(k) (PQP_TU == 0 || PQP_TU == (k))
 
@@ -96,7 +97,7 @@ int pqp_launch_solve_256_s0_one(pqp_batch* h);
 int pqp_launch_solve_256_s1_two(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_256_s2(pqp_batch* h);
-int pqp_launch_solve_64_s2(pqp_batch* h);
+int pqp_launch_solve_diag_wave(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
@@ -158,13 +159,34 @@ pqp_launch_solve_256_s2(pqp_batch* h)
   return launch_solve<256, PQP_WPS_256_DIAG, 2>(h);
 }
 #endif
-// One WAVEFRONT per QP for the diagonal-structure solver: every barrier of the solver is a no-op in a workgroup of
-// one wavefront (the compiler drops s_barrier when the flat workgroup size is the wave size).
+// One WAVEFRONT per QP, every per-QP vector in registers: the diagonal-structure solver of pqp_diag.hpp
+// (BASELINE.json configs[4]).  A workgroup is one wavefront; E = 4 register slots per vector serve dim <= 256, the
+// range of the 256-thread kernel class.
 #if PQP_TU_HAS(16)
-int
-pqp_launch_solve_64_s2(pqp_batch* h)
+#ifndef PQP_WPS_DIAG_WAVE
+#define PQP_WPS_DIAG_WAVE 2
+#endif
+template<int E, int WPS>
+__global__ __launch_bounds__(64, WPS) void
+pqp_diag_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
 {
-  return launch_solve<64, 1, 2>(h);
+  HIP_DYNAMIC_SHARED(double, smem)
+  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
+  pqp::diag_solve_body<E>(batch, first + slot, (pqp::lptr)smem);
+}
+
+int
+pqp_launch_solve_diag_wave(pqp_batch* h)
+{
+  constexpr int E = 4;
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
+  const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
+  hipLaunchKernelGGL((pqp_diag_kernel<E, PQP_WPS_DIAG_WAVE>), dim3((unsigned)h->range_count), dim3(64),
+                     pqp::diag_lds_bytes(E), h->stream, h->dev, h->range_first, order);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  return PQP_OK;
 }
 #endif
 #if PQP_TU_HAS(3)
@@ -391,8 +413,9 @@ pqp_launch_solve(pqp_batch* h)
         for (size_t q = 0; all_diag && q < h->c_diag.size(); ++q)
           all_diag = h->c_diag[q] != 0;
         if (all_diag) {
-          static const int diag_nt = [] { const char* e = std::getenv("PQP_DIAG_NT"); return e ? std::atoi(e) : 256; }();
-          return diag_nt == 64 ? pqp_launch_solve_64_s2(h) : pqp_launch_solve_256_s2(h);
+          // (PQP_DIAG_KERNEL=workgroup: the 256-thread form of the same solver, kept as the A/B partner of the tests)
+          static const bool wg = [] { const char* e = std::getenv("PQP_DIAG_KERNEL"); return e && e[0] == 'w'; }();
+          return (!wg && dd.n <= 256) ? pqp_launch_solve_diag_wave(h) : pqp_launch_solve_256_s2(h);
         }
         return (h->range_count <= (long)h->n_cu) ? pqp_launch_solve_256_s0_one(h) : pqp_launch_solve_256_s0(h);
       }
