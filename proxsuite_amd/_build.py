@@ -145,6 +145,7 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
     rec_path = odir / "kernel_resources.json"
     rec = json.loads(rec_path.read_text()) if rec_path.exists() else {}
     for j, r in zip(todo, results):
+        rec = {k: v for k, v in rec.items() if v.get("object") != j[1].name}  # (what that object held before this compile)
         for name, fields in parse_kernel_resources(r.stderr).items():
             rec[kernel_label(name)] = dict(fields, object=j[1].name)
     rec_path.write_text(json.dumps(rec, indent=1, sort_keys=True))

@@ -33,7 +33,10 @@ namespace pqp {
 __host__ __device__ inline size_t
 diag_lds_bytes(int E)
 {
-  return (size_t)(64 * E) * sizeof(int) + (size_t)(64 * E) * sizeof(double) + (ST_COUNT + 2) * sizeof(long long);
+  // slot list (ints), the nine vectors that are read at most a few times per Newton step (previous iterate x, z of the
+  // proximal terms, the two bounds, g_s, diag(H_s), the Ruiz scalings of the variables and of the constraint rows, the
+  // unscaled g), statistics.  19.3 KB for E = 4: eight QPs per CU.
+  return (size_t)(64 * E) * sizeof(int) + (size_t)(64 * E) * sizeof(double) * 9 + (ST_COUNT + 2) * sizeof(long long);
 }
 
 // value of lane `src` (uniform) in every lane
@@ -48,6 +51,12 @@ wave_bcast(double v, int src)
 }
 
 #define PQP_E(c) _Pragma("unroll") for (int c = 0; c < E; ++c)
+// keeps a value in a vector register across this point (see rhs_d)
+#ifndef PQP_EMULATED_MFMA
+#define PQP_KEEP(v) asm volatile("" : "+v"(v))
+#else
+#define PQP_KEEP(v)
+#endif
 
 template<int E>
 struct DiagSolver
@@ -64,23 +73,39 @@ struct DiagSolver
   const bool boxf;  // bounds as box constraints (n_in == 0)
   const bool hasc;  // nc > 0
   PQP_LDS int* lds_i;          // 64 E ints: slot lists
-  PQP_LDS double* lds_d;       // 64 E doubles
+  PQP_LDS double* lds_d;       // 64 E doubles of scratch
+  PQP_LDS double* lds_v;       // LV_COUNT vectors of 64 E doubles (element k of a vector is only ever touched by its own lane)
+  enum
+  {
+    LV_XP = 0,
+    LV_ZP,
+    LV_UB,
+    LV_LB,
+    LV_GS,
+    LV_HD,
+    LV_SX, // delta_x (1 beyond dim)
+    LV_SC, // delta_in / delta_box (1 beyond dim)
+    LV_GU, // g of the unscaled model
+    LV_COUNT
+  };
   PQP_LDS long long* lds_stat; // ST_COUNT + 2 (statistics, instrumented build)
   UD ruiz_c, dual_feasibility_rhs_2;
   int n_c;
   bool schur_dirty, aty_fresh, nonfinite;
   // persistent vectors (slot c of lane l = element 64 c + l; zeros beyond dim, dF = dS = 1 there)
-  double x[E], z[E], xp[E], zp[E], gs[E], ub[E], lb[E], zd[E], hd[E], dF[E], gd[E], dS[E], dres[E], rup[E], si[E];
+  // (xp, zp, the bounds, g_s and diag(H_s) live in LDS: lv(); 27 vectors in registers are 100 more registers than a
+  // wavefront sharing its SIMD with another one may hold)
+  double x[E], z[E], zd[E], dF[E], dS[E], dres[E], rup[E], si[E];
   // Newton step
-  double dx[E], dz[E], Hdx[E], Cdx[E], CTdz[E], CTzin[E], rx[E], rd[E], ex[E], ed[E], sd[E], zfull[E];
+  double dx[E], dz[E], Hdx[E], Cdx[E], CTdz[E], ex[E], ed[E], sd[E];
   int fl[E]; // bit 0 active_set_up, bit 1 active_set_low, bit 2 wanted active, bit 3 in the factor (has a slot)
 
   __device__ __forceinline__ DiagSolver(const Batch& b, long q_, lptr lds)
     : batch(b)
-    , q(q_)
+    , q(uni(q_))
     , d(b.d)
-    , P(b, q_)
-    , st(b.settings[q_])
+    , P(b, uni(q_))
+    , st(b.settings[uni(q_)])
     , lane((int)(threadIdx.x & (WAVE - 1)))
     , n(uni(b.d.n))
     , cform(b.d.n_in > 0)
@@ -88,8 +113,9 @@ struct DiagSolver
     , hasc(b.d.nc > 0)
   {
     lds_i = (PQP_LDS int*)lds;
-    lds_d = (PQP_LDS double*)(lds + 32 * E);
-    lds_stat = (PQP_LDS long long*)(lds + 32 * E + 64 * E);
+    lds_v = (PQP_LDS double*)(lds + 32 * E);
+    lds_d = lds_v; // (scratch of the restore path of the prologue: the LV_XP slot, written for the first time after it)
+    lds_stat = (PQP_LDS long long*)(lds + 32 * E + 64 * E * LV_COUNT);
     n_c = 0;
     schur_dirty = true;
     aty_fresh = false;
@@ -99,6 +125,38 @@ struct DiagSolver
   __device__ __forceinline__ int idx(int c) const { return c * WAVE + lane; }
   __device__ __forceinline__ bool in(int c) const { return idx(c) < n; }
   __device__ __forceinline__ bool active(int c) const { return (fl[c] & 8) != 0; }
+  // element (c, lane) of LDS vector V
+  __device__ __forceinline__ double lv(int V, int c) const { return lds_v[V * (64 * E) + idx(c)]; }
+  __device__ __forceinline__ void lv_set(int V, int c, double v) { lds_v[V * (64 * E) + idx(c)] = v; }
+  __device__ __forceinline__ void lv_load(int V, cgptr src, double fill = 0.0)
+  {
+    PQP_E(c) lv_set(V, c, in(c) ? src[idx(c)] : fill);
+  }
+  // right-hand side of the linear step in progress (mode 0: Newton step, reference solver.hpp:787-847; 1: equality-constrained
+  // initial guess), recomputed from the iterate where it is used instead of held in registers
+  __device__ __forceinline__ double ctz_inactive(int c) const { return hasc ? zd[c] * (active(c) ? 0.0 : z[c]) : 0.0; }
+  __device__ __forceinline__ double rhs_x(int c, int mode) const
+  {
+    return mode == 0 ? -dres[c] + ctz_inactive(c) : -lv(LV_GS, c);
+  }
+  __device__ __forceinline__ double rhs_d(int c, int mode) const
+  {
+    double v = 0;
+    if (mode == 0 && active(c)) {
+      const double zfac = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
+      // (both candidates are read into registers first: a select between the ADDRESSES of rup[c] and si[c] would put
+      // the whole solver object into scratch memory)
+      double ru = rup[c], sv = si[c];
+      PQP_KEEP(ru);
+      PQP_KEEP(sv);
+      const double shift = z[c] * info.mu_in * zfac;
+      if (fl[c] & 1)
+        v = -ru + shift;
+      else if (fl[c] & 2)
+        v = -sv + shift;
+    }
+    return v;
+  }
 
   // ---- statistics (see Solver::tic / toc): the instrumented build only; the total cycles of a solve (dispatch order)
   // and the wall ticks (Info timings) are always recorded
@@ -271,17 +329,14 @@ struct DiagSolver
   __device__ __forceinline__ void factor_primal_block()
   {
     const double rho = info.rho;
-    PQP_E(c) dF[c] = in(c) ? ((hess() == PQP_HESSIAN_DIAGONAL) ? hd[c] : 0.0) + rho : 1.0;
+    PQP_E(c) dF[c] = in(c) ? ((hess() == PQP_HESSIAN_DIAGONAL) ? lv(LV_HD, c) : 0.0) + rho : 1.0;
     vstore(P.dF(), dF);
     if (hasc) {
       gptr Zr = P.Zr(), gdg = P.G();
-      PQP_E(c)
+      PQP_E(c) if (in(c))
       {
-        gd[c] = in(c) ? zd[c] * zd[c] / dF[c] : 0.0;
-        if (in(c)) {
-          Zr[idx(c)] = zd[c];
-          gdg[idx(c)] = gd[c];
-        }
+        Zr[idx(c)] = zd[c];
+        gdg[idx(c)] = zd[c] * zd[c] / dF[c];
       }
       bytes((long)d.nd * 8 * 3);
     }
@@ -321,7 +376,7 @@ struct DiagSolver
     if (n_c > 0) {
       // diagonal Schur block: D_S = mu_in + gd over the active constraints (Solver::factor_schur)
       const double mu_in = info.mu_in;
-      PQP_E(c) dS[c] = active(c) ? mu_in + gd[c] : 1.0;
+      PQP_E(c) dS[c] = active(c) ? mu_in + zd[c] * zd[c] / dF[c] : 1.0;
       bytes((long)n_c * 8);
       count(ST_N_SCHUR_FACT);
     }
@@ -347,24 +402,24 @@ struct DiagSolver
   }
 
   // err = rhs - K sol; by-products Hdx, Cdx, CTdz (Solver::kkt_residual)
-  __device__ __forceinline__ double kkt_residual()
+  __device__ __forceinline__ double kkt_residual(int mode)
   {
     const double rho = info.rho, mu_in = info.mu_in;
     double m = 0;
     PQP_E(c)
     {
-      Hdx[c] = (hess() == PQP_HESSIAN_DIAGONAL) ? hd[c] * dx[c] : 0.0;
+      Hdx[c] = (hess() == PQP_HESSIAN_DIAGONAL) ? lv(LV_HD, c) * dx[c] : 0.0;
       if (hasc) {
         Cdx[c] = zd[c] * dx[c];
-        CTdz[c] = zd[c] * zfull[c];
+        CTdz[c] = zd[c] * (active(c) ? sd[c] : 0.0); // (the dual solution by constraint, zero where inactive)
       } else {
         CTdz[c] = 0.0;
       }
-      const double e = rx[c] - rho * dx[c] - Hdx[c] - CTdz[c];
+      const double e = rhs_x(c, mode) - rho * dx[c] - Hdx[c] - CTdz[c];
       ex[c] = e;
       m = fmax(m, fabs(e));
       if (active(c)) {
-        const double e2 = rd[c] - (Cdx[c] - sd[c] * mu_in);
+        const double e2 = rhs_d(c, mode) - (Cdx[c] - sd[c] * mu_in);
         ed[c] = e2;
         m = fmax(m, fabs(e2));
       }
@@ -374,14 +429,14 @@ struct DiagSolver
   }
 
   // reference solver.hpp:406-541 (Solver::iterative_solve): solve + refinement on the unfactorised operator
-  __device__ __forceinline__ void iterative_solve(double eps)
+  __device__ __forceinline__ void iterative_solve(double eps, int mode)
   {
     PQP_E(c)
     {
       dx[c] = 0.0;
       sd[c] = 0.0;
-      ex[c] = rx[c];
-      ed[c] = rd[c];
+      ex[c] = rhs_x(c, mode);
+      ed[c] = rhs_d(c, mode);
     }
     long it = 0, it_stability = 0;
     UD preverr = 0, cur = 0;
@@ -391,15 +446,11 @@ struct DiagSolver
       PQP_E(c)
       {
         dx[c] += ex[c];
-        if (active(c)) {
+        if (active(c))
           sd[c] += ed[c];
-          zfull[c] = sd[c];
-        } else {
-          zfull[c] = 0.0;
-        }
       }
       toc(ST_CYC_KKT_SOLVE);
-      cur = kkt_residual();
+      cur = kkt_residual(mode);
       toc(ST_CYC_RESIDUAL);
       ++it;
       if (it > 1) {
@@ -423,7 +474,6 @@ struct DiagSolver
   // (helpers.hpp:199-228); 2: install the active set in fl only (solver.hpp:1231-1240)   (Solver::linear_step)
   __device__ __forceinline__ void linear_step(int mode, double eps)
   {
-    const double zfac = (st.merit_function_type == PQP_MERIT_GPDAL) ? st.alpha_gpdal : 1.0;
     if (mode == 0 && hasc) {
       PQP_E(c) if (in(c))
       {
@@ -435,31 +485,7 @@ struct DiagSolver
     apply_active_set();
     if (mode == 2)
       return;
-    tic();
-    if (mode == 0) {
-      PQP_E(c)
-      {
-        zfull[c] = active(c) ? 0.0 : z[c]; // inactive multipliers
-        CTzin[c] = hasc ? zd[c] * zfull[c] : 0.0;
-        rx[c] = -dres[c] + CTzin[c];
-        double v = 0;
-        if (active(c)) {
-          if (fl[c] & 1)
-            v = -rup[c] + z[c] * info.mu_in * zfac;
-          else if (fl[c] & 2)
-            v = -si[c] + z[c] * info.mu_in * zfac;
-        }
-        rd[c] = v;
-      }
-    } else {
-      PQP_E(c)
-      {
-        rx[c] = -gs[c];
-        rd[c] = 0.0;
-      }
-    }
-    toc(ST_CYC_NEWTON_MISC);
-    iterative_solve(eps);
+    iterative_solve(eps, mode);
     if (mode == 1) {
       vcopy(x, dx);
       return;
@@ -467,7 +493,7 @@ struct DiagSolver
     PQP_E(c)
     {
       dz[c] = active(c) ? sd[c] : -z[c];
-      CTdz[c] -= CTzin[c];
+      CTdz[c] -= ctz_inactive(c);
     }
   }
 
@@ -525,32 +551,6 @@ struct DiagSolver
   }
 
   static constexpr int NBP = 2 * E; // breakpoints a lane owns: two per constraint
-
-  // phi' at three step lengths (values that only steer the bracket) + the number of breakpoints in (lo, al[p]] and in
-  // (lo, hi]   (Solver::ls_grad3)
-  __device__ __forceinline__ void ls_grad3(const double (&al)[3], double a0, double b0, double bmag, const double (&mine)[NBP],
-                                           double lo, double hi, double (&g)[3], double (&mag)[3], double (&cle)[3], double& ctot)
-  {
-    double ai[3], bi[3];
-    ls_terms<3>(al, ai, bi);
-    double cl[3] = { 0, 0, 0 }, ct = 0;
-#pragma unroll
-    for (int r = 0; r < NBP; ++r)
-      if (mine[r] > lo && mine[r] <= hi) {
-        ct += 1.0;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          if (mine[r] <= al[p])
-            cl[p] += 1.0;
-      }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      g[p] = (a0 + ai[p]) * al[p] + (b0 + bi[p]);
-      mag[p] = fabs((a0 + ai[p]) * al[p]) + fabs(b0) + bmag;
-      cle[p] = wave_sum(cl[p]);
-    }
-    ctot = wave_sum(ct);
-  }
 
   // The breakpoints flagged in `take` evaluated exactly, then the selections of linesearch.hpp:427-536.  `pred`: the
   // largest breakpoint at or below the bracket (0: none).  false: the caller must evaluate every breakpoint.
@@ -648,7 +648,7 @@ struct DiagSolver
       s_dxHdx += dxk * Hdx[c];
       s_dx2 += dxk * dxk;
       s_xHdx += x[c] * Hdx[c];
-      s_errdx += (info.rho * (x[c] - xp[c]) + gs[c]) * dxk;
+      s_errdx += (info.rho * (x[c] - lv(LV_XP, c)) + lv(LV_GS, c)) * dxk;
     }
     PQP_E(c)
     {
@@ -712,63 +712,67 @@ struct DiagSolver
     bool take[NBP];
     bool done = false;
     if (cnt > 8.0 && amax < INF) {
-      // bracket (lo, hi] of the zero of the monotone phi' (Solver::ls_bracket): phi'(lo) < 0 surely, phi'(hi) > 0 surely
+      // Bracket (lo, hi] of the zero of the monotone phi' (the job of Solver::ls_bracket).  The probes are BREAKPOINTS: a
+      // round takes one that lies strictly inside the bracket (every lane offers the first of its own, the lane in the
+      // middle of those that offer one is taken: a pivot of arbitrary rank, as in quickselect), evaluates phi' there --
+      // each lane its own constraints' terms, two wavefront reductions -- and keeps the side the zero is on: the number of
+      // breakpoints left shrinks by a third per round on average whatever their distribution over the decades (the
+      // geometric quarter-steps of the workgroup kernel cost three evaluations, a division and two square roots a round).
+      // Nothing here is trusted: the exact evaluation of the few breakpoints that remain validates the bracket (ls_select).
       const double SURE = 3.6e-15 * (double)(d.nc + d.n + d.n_eq);
-      const double floor_ = -0.5 * amin_neg;
       double lo = 0.0, hi = amax, inside = cnt;
       bool all_negative = false, give_up = false;
       {
-        const double al[3] = { 0.0, sqrt(floor_) * sqrt(amax), amax };
-        double g[3], mag[3], cle[3], ctot;
-        ls_grad3(al, a0, b0, bmag, mine, 0.0, amax, g, mag, cle, ctot);
-        if (!(g[0] < -SURE * mag[0]))
+        const double al[2] = { 0.0, amax };
+        double ai[2], bi[2];
+        ls_terms<2>(al, ai, bi);
+        const double g0 = b0 + bi[0], mag0 = fabs(b0) + bmag;
+        const double gh = (a0 + ai[1]) * amax + (b0 + bi[1]), magh = fabs((a0 + ai[1]) * amax) + fabs(b0) + bmag;
+        if (!(g0 < -SURE * mag0))
           give_up = true;
-        else if (g[2] < -SURE * mag[2])
-          all_negative = true;
-        else if (!(g[2] > SURE * mag[2]))
+        else if (gh < -SURE * magh)
+          all_negative = true; // no breakpoint with phi' >= 0: linesearch.hpp:496-526
+        else if (!(gh > SURE * magh))
           give_up = true;
-        else if (g[1] < -SURE * mag[1]) {
-          lo = al[1];
-          inside = ctot - cle[1];
-        } else if (g[1] > SURE * mag[1]) {
-          hi = al[1];
-          inside = cle[1];
-        }
       }
       if (!give_up && !all_negative) {
-        for (int round = 0; round < 6 && inside > 6.0; ++round) {
-          const double base = fmax(lo, floor_);
-          const double r4 = sqrt(sqrt(hi / base));
-          const double al[3] = { base * r4, base * r4 * r4, base * r4 * r4 * r4 };
-          double g[3], mag[3], cle[3], ctot;
-          ls_grad3(al, a0, b0, bmag, mine, lo, hi, g, mag, cle, ctot);
-          double nlo = lo, nhi = hi, below = 0.0, upto = ctot;
-          int first_pos = 3;
+        for (int round = 0; round < 40 && inside > 6.0; ++round) {
+          double cand = -1.0;
 #pragma unroll
-          for (int p = 2; p >= 0; --p)
-            if (g[p] > SURE * mag[p])
-              first_pos = p;
-          if (first_pos < 3) {
-            nhi = al[first_pos];
-            upto = cle[first_pos];
+          for (int r = NBP - 1; r >= 0; --r)
+            if (mine[r] > lo && mine[r] < hi)
+              cand = mine[r];
+          const unsigned long long m = __ballot(cand > 0 ? 1 : 0);
+          if (m == 0ull)
+            break; // (what is left are ties with hi)
+          const int rank = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (WAVE - lane))));
+          const unsigned long long pick = __ballot((cand > 0 && rank == (__popcll(m) >> 1)) ? 1 : 0);
+          const double pv = wave_bcast(cand, __ffsll((long long)pick) - 1);
+          const double a1[1] = { pv };
+          double ai[1], bi[1];
+          ls_terms<1>(a1, ai, bi);
+          const double g = (a0 + ai[0]) * pv + (b0 + bi[0]), mag = fabs((a0 + ai[0]) * pv) + fabs(b0) + bmag;
+          double cb = 0, below = 0;
+#pragma unroll
+          for (int r = 0; r < NBP; ++r) {
+            if (mine[r] > lo && mine[r] <= pv)
+              cb += 1.0;
+            if (mine[r] < pv)
+              below = fmax(below, mine[r]);
           }
-          bool moved = first_pos < 3;
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            if (p < first_pos && g[p] < -SURE * mag[p]) {
-              nlo = al[p];
-              below = cle[p];
-              moved = true;
-            }
-          if (!(nlo < nhi)) {
-            give_up = true;
+          if (g > SURE * mag) {
+            hi = pv;
+            inside = wave_sum(cb);
+          } else if (g < -SURE * mag) {
+            lo = pv;
+            inside -= wave_sum(cb);
+          } else {
+            // too close to the zero to trust the sign: the zero is at this breakpoint or right beside it
+            lo = wave_max(below);
+            hi = pv;
+            inside = 1.0;
             break;
           }
-          lo = nlo;
-          hi = nhi;
-          inside = upto - below;
-          if (!moved)
-            break;
         }
         if (inside > double(WCAP - 3))
           give_up = true;
@@ -828,12 +832,12 @@ struct DiagSolver
       }
     }
     if (do_cert) {
-      cgptr dxs = P.dlt_x();
-      cgptr dcs = dlt_c();
       double sx[E], sc_[E];
-      vload(sx, dxs, 1.0);
-      if (hasc)
-        vload(sc_, dcs, 1.0);
+      PQP_E(k)
+      {
+        sx[k] = lv(LV_SX, k);
+        sc_[k] = lv(LV_SC, k);
+      }
       PQP_E(k) if (in(k))
       {
         const double sc = sx[k] * c;
@@ -841,7 +845,7 @@ struct DiagSolver
         lb2 = fmax(lb2, fabs(0.0 + CTdz[k]));
         Hdx[k] /= sc;
         nhdx = fmax(nhdx, fabs(Hdx[k]));
-        gdx += dx[k] * gs[k];
+        gdx += dx[k] * lv(LV_GS, k);
         dx[k] *= sx[k];
         ndx = fmax(ndx, fabs(dx[k]));
       }
@@ -849,14 +853,15 @@ struct DiagSolver
         PQP_E(k) if (in(k))
         {
           const double v = dz[k];
-          lb1 += (v > 0 ? v : 0.0) * ub[k];
-          lb1 -= (v < 0 ? v : 0.0) * lb[k];
+          const double ubk = lv(LV_UB, k), lbk = lv(LV_LB, k);
+          lb1 += (v > 0 ? v : 0.0) * ubk;
+          lb1 -= (v < 0 ? v : 0.0) * lbk;
           dz[k] = cform ? v * sc_[k] / c : sc_[k] * v / c;
           nrm_dz = fmax(nrm_dz, fabs(dz[k]));
           Cdx[k] /= sc_[k];
           // utils.hpp:381-398: two-sided bound -> |w| <= bound; no upper bound -> -w <= bound; no lower -> w <= bound
           const double w = cform ? Cdx[k] : dx[k]; // (box form: the unscaled dx itself)
-          const double val = (ub[k] <= 1.E20 && lb[k] >= -1.E20) ? fabs(w) : ((ub[k] > 1.E20) ? -w : w);
+          const double val = (ubk <= 1.E20 && lbk >= -1.E20) ? fabs(w) : ((ubk > 1.E20) ? -w : w);
           mviol = fmax(mviol, val);
         }
       }
@@ -972,19 +977,18 @@ struct DiagSolver
   {
     double m_in0 = 0, m_inl = 0;
     if (cform) {
-      cgptr di = P.dlt_in();
       cgptr uu = P.u(), ll = P.l();
-      double dv[E], uv[E], lv[E];
-      vload(dv, di, 1.0);
+      double dv[E], uv[E], lwv[E];
+      PQP_E(k) dv[k] = lv(LV_SC, k);
       vload(uv, uu);
-      vload(lv, ll);
+      vload(lwv, ll);
       PQP_E(k) if (in(k))
       {
         CTdz[k] = zd[k] * z[k];
         const double v = (zd[k] * x[k]) / dv[k]; // unscaled C x
         rup[k] = v;
         m_in0 = fmax(m_in0, fabs(v));
-        const double pu = v - uv[k], pl = v - lv[k];
+        const double pu = v - uv[k], pl = v - lwv[k];
         const double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
         si[k] = sv;
         m_inl = fmax(m_inl, fabs(sv));
@@ -993,17 +997,16 @@ struct DiagSolver
       vzero(CTdz);
     }
     if (boxf) {
-      cgptr dxs = P.dlt_x();
       cgptr ubx = P.u_box(), lbx = P.l_box();
-      double dv[E], uv[E], lv[E];
-      vload(dv, dxs, 1.0);
+      double dv[E], uv[E], lwv[E];
+      PQP_E(k) dv[k] = lv(LV_SX, k);
       vload(uv, ubx);
-      vload(lv, lbx);
+      vload(lwv, lbx);
       PQP_E(k) if (in(k))
       {
         const double v = x[k] * dv[k]; // unscaled x
         rup[k] = v;
-        const double pu = v - uv[k], pl = v - lv[k];
+        const double pu = v - uv[k], pl = v - lwv[k];
         const double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
         si[k] = sv;
         m_inl = fmax(m_inl, fabs(sv));
@@ -1036,20 +1039,23 @@ struct DiagSolver
     const double c = ruiz_c;
     double m0 = 0, m3 = 0, ml = 0, xHx = 0, gx = 0, zu = 0, zl = 0;
     const double ib = 1.3407807929942596e+154; // sqrt(DBL_MAX), helpers/common.hpp:17-25
-    double sx[E], gv[E], sc_[E], uv[E], lv[E];
-    vload(sx, P.dlt_x(), 1.0);
-    vload(gv, P.g());
+    double sx[E], gv[E], sc_[E], uv[E], lwv[E];
     if (hasc) {
-      vload(sc_, dlt_c(), 1.0);
       vload(uv, cform ? P.u() : P.u_box());
-      vload(lv, cform ? P.l() : P.l_box());
+      vload(lwv, cform ? P.l() : P.l_box());
     }
     const bool have_products = aty_fresh;
     bytes(((hess() == PQP_HESSIAN_ZERO ? 0L : (long)n) + (have_products ? 0L : (long)d.n_in)) * 8);
+    PQP_E(k)
+    {
+      sx[k] = lv(LV_SX, k);
+      gv[k] = lv(LV_GU, k);
+      sc_[k] = lv(LV_SC, k);
+    }
     PQP_E(k) if (in(k))
     {
       const double sc = sx[k] * c;
-      const double hx = (hess() == PQP_HESSIAN_DIAGONAL) ? hd[k] * x[k] : 0.0;
+      const double hx = (hess() == PQP_HESSIAN_DIAGONAL) ? lv(LV_HD, k) * x[k] : 0.0;
       double ctz = cform ? (have_products ? CTdz[k] : zd[k] * z[k]) : 0.0;
       const double v = hx / sc; // unscaled H x (utils.hpp:469-471)
       m0 = fmax(m0, fabs(v));
@@ -1063,14 +1069,14 @@ struct DiagSolver
         m3k = fmax(m3k, fabs(zb / sc));
       }
       m3 = fmax(m3, m3k);
-      const double dr = gs[k] + hx + 0.0 + ctz;
+      const double dr = lv(LV_GS, k) + hx + 0.0 + ctz;
       dres[k] = dr;
       ml = fmax(ml, fabs(dr / sc));
       if (hasc) {
         // duality gap terms (utils.hpp:482-586)
         const double zi = cform ? z[k] * sc_[k] / c : sc_[k] * z[k] / c;
         const double uk = uv[k] < ib ? uv[k] : ib;
-        const double lk = lv[k] > -ib ? lv[k] : -ib;
+        const double lk = lwv[k] > -ib ? lwv[k] : -ib;
         if (fl[k] & 1)
           zu += zi * uk;
         if (fl[k] & 2)
@@ -1136,8 +1142,10 @@ struct DiagSolver
     // code runs over all E slots of all lanes, and the reductions take whatever those slots hold
     PQP_E(c)
     {
-      xp[c] = zp[c] = dres[c] = rup[c] = si[c] = 0.0;
-      dx[c] = dz[c] = Hdx[c] = Cdx[c] = CTdz[c] = CTzin[c] = rx[c] = rd[c] = ex[c] = ed[c] = sd[c] = zfull[c] = 0.0;
+      dres[c] = rup[c] = si[c] = 0.0;
+      dx[c] = dz[c] = Hdx[c] = Cdx[c] = CTdz[c] = ex[c] = ed[c] = sd[c] = 0.0;
+      lv_set(LV_XP, c, 0.0);
+      lv_set(LV_ZP, c, 0.0);
     }
     // results -> registers (the warm-start modes read them)
     vload(x, P.x());
@@ -1150,6 +1158,7 @@ struct DiagSolver
       const PQP_GLOBAL int* ga = P.act();
       PQP_E(c) fl[c] = (hasc && in(c)) ? act_flags(ga[idx(c)]) : 0;
     }
+    tic();
     const int ig = st.initial_guess;
     const bool wswpr = (ig == PQP_WARM_START_WITH_PREVIOUS_RESULT);
     const bool dirty = W.dirty != 0;
@@ -1194,44 +1203,51 @@ struct DiagSolver
       }
     }
     if (do_rescale) {
-      tic();
+      toc(ST_CYC_F_LOAD); // (instrumented build: prologue, outer-loop logic and epilogue of this kernel are billed to the
+                          // three counters the dense path uses for its blocked factorisation: f_load, f_update, f_writeback)
       rescale(W.scaled_valid == 0);
       toc(ST_CYC_SCALE);
     }
     // the equilibrated model: g_s, the bounds, the diagonals of H_s and of the constraint rows
-    vload(gs, P.gs());
-    vload(hd, P.F());
+    lv_load(LV_GS, P.gs());
+    lv_load(LV_HD, P.F());
+    lv_load(LV_SX, P.dlt_x(), 1.0);
+    lv_load(LV_GU, P.g());
+    if (hasc) {
+      lv_load(LV_SC, dlt_c(), 1.0);
+    } else {
+      PQP_E(c) lv_set(LV_SC, c, 1.0);
+    }
     if (cform) {
-      vload(ub, P.us());
-      vload(lb, P.ls());
+      lv_load(LV_UB, P.us());
+      lv_load(LV_LB, P.ls());
       vload(zd, P.CTs());
     } else if (boxf) {
-      vload(ub, P.ubs());
-      vload(lb, P.lbs());
+      lv_load(LV_UB, P.ubs());
+      lv_load(LV_LB, P.lbs());
       vload(zd, P.is());
     } else {
-      vzero(ub);
-      vzero(lb);
+      PQP_E(c)
+      {
+        lv_set(LV_UB, c, 0.0);
+        lv_set(LV_LB, c, 0.0);
+      }
       vzero(zd);
     }
     if (do_scale_ws) {
       // solver.hpp:1137-1146: the warm start into the equilibrated space
-      double sx[E], sc_[E];
-      vload(sx, P.dlt_x(), 1.0);
-      PQP_E(k) x[k] /= sx[k];
+      PQP_E(k) x[k] /= lv(LV_SX, k);
       if (hasc) {
-        vload(sc_, dlt_c(), 1.0);
-        PQP_E(k) z[k] = z[k] / sc_[k] * ruiz_c;
+        PQP_E(k) z[k] = z[k] / lv(LV_SC, k) * ruiz_c;
       }
     }
     PQP_E(c)
     {
       dF[c] = 1.0;
       dS[c] = 1.0;
-      gd[c] = 0.0;
     }
     if (do_factor) {
-      tic();
+      toc(ST_CYC_F_LOAD);
       factor_primal_block();
       toc(ST_CYC_FACTOR_H);
       n_c = 0;
@@ -1241,8 +1257,6 @@ struct DiagSolver
       // WARM_START_WITH_PREVIOUS_RESULT on an unchanged model: the state the previous solve left in HBM
       // (solver.hpp:1173-1187, 1343-1375): D, the Gram entries, the slot list and D_S by slot
       vload(dF, P.dF(), 1.0);
-      if (hasc)
-        vload(gd, P.G());
       n_c = W.n_c;
       const int n_slots = W.n_slots;
       {
@@ -1300,8 +1314,9 @@ struct DiagSolver
     bool gpr_fresh = false, gdr_fresh = false;
     aty_fresh = false;
     UD pl_cache = 0, dl_cache = 0;
+    toc(ST_CYC_F_LOAD);
     while (!done) {
-      tic();
+      toc(ST_CYC_F_UPDATE);
       if (st.primal_infeasibility_solving)
         gpr_fresh = false;
       UD pl = pl_cache, dl = dl_cache;
@@ -1351,15 +1366,12 @@ struct DiagSolver
         if (PQP_UNLIKELY(st.verbose != 0)) {
           // solver.hpp:1469-1510: the reference's report block unscales x, y, z and scales them back
           trace_line(1.0, double(info.iter_ext + 1), info.pri_res, info.dua_res, info.duality_gap, info.mu_in, info.rho);
-          double sx[E], sc_[E];
-          vload(sx, P.dlt_x(), 1.0);
-          PQP_E(k) x[k] = (x[k] * sx[k]) / sx[k];
+          PQP_E(k) x[k] = (x[k] * lv(LV_SX, k)) / lv(LV_SX, k);
           if (hasc) {
-            vload(sc_, dlt_c(), 1.0);
             if (cform) {
-              PQP_E(k) z[k] = (z[k] * sc_[k] / ruiz_c) / sc_[k] * ruiz_c;
+              PQP_E(k) z[k] = (z[k] * lv(LV_SC, k) / ruiz_c) / lv(LV_SC, k) * ruiz_c;
             } else {
-              PQP_E(k) z[k] = (sc_[k] * z[k] / ruiz_c) / sc_[k] * ruiz_c;
+              PQP_E(k) z[k] = (lv(LV_SC, k) * z[k] / ruiz_c) / lv(LV_SC, k) * ruiz_c;
             }
           }
         }
@@ -1377,22 +1389,25 @@ struct DiagSolver
           }
         }
         info.iter_ext += 1;
-        vcopy(xp, x);
-        vcopy(zp, z);
+        PQP_E(c)
+        {
+          lv_set(LV_XP, c, x[c]);
+          lv_set(LV_ZP, c, z[c]);
+        }
         // shifted inequality residuals (solver.hpp:1523-1559)
         if (hasc) {
-          double sc_[E];
-          vload(sc_, dlt_c(), 1.0);
           PQP_E(i) if (in(i))
           {
-            double v = rup[i] * sc_[i] + z[i] * info.mu_in;
+            double v = rup[i] * lv(LV_SC, i) + z[i] * info.mu_in;
             if (st.merit_function_type == PQP_MERIT_GPDAL)
               v += (st.alpha_gpdal - 1.) * info.mu_in * z[i];
-            rup[i] = v - ub[i];
-            si[i] = v - lb[i];
+            rup[i] = v - lv(LV_UB, i);
+            si[i] = v - lv(LV_LB, i);
           }
         }
+        toc(ST_CYC_F_UPDATE);
         newton_semi_smooth(bcl_eta_in);
+        tic();
         gpr_fresh = false;
         gdr_fresh = false;
         aty_fresh = false;
@@ -1440,7 +1455,7 @@ struct DiagSolver
             bcl_eta_ext *= pow(info.mu_in, st.beta_bcl);
             bcl_eta_in = fmax(bcl_eta_in * info.mu_in, eps_in_min);
           } else {
-            vcopy(z, zp);
+            PQP_E(c) z[c] = lv(LV_ZP, c);
             gdr_fresh = false; // z was reset
             aty_fresh = false;
             new_bcl_mu_in = fmax(info.mu_in * st.mu_update_factor, st.mu_min_in);
@@ -1490,27 +1505,24 @@ struct DiagSolver
 
     // unscale the solution (solver.hpp:1749-1767)
     {
-      double sx[E], sc_[E];
-      vload(sx, P.dlt_x(), 1.0);
-      PQP_E(k) x[k] *= sx[k];
+      tic();
+      PQP_E(k) x[k] *= lv(LV_SX, k);
       if (hasc) {
-        vload(sc_, dlt_c(), 1.0);
         if (cform) {
-          PQP_E(k) z[k] = z[k] * sc_[k] / ruiz_c;
+          PQP_E(k) z[k] = z[k] * lv(LV_SC, k) / ruiz_c;
         } else {
-          PQP_E(k) z[k] = sc_[k] * z[k] / ruiz_c;
+          PQP_E(k) z[k] = lv(LV_SC, k) * z[k] / ruiz_c;
         }
         if (st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE) {
-          PQP_E(k) si[k] /= sc_[k];
+          PQP_E(k) si[k] /= lv(LV_SC, k);
         }
       }
     }
     // objective on the unscaled model (solver.hpp:1771-1780)
     {
       double obj = 0;
-      cgptr g = P.g();
       cgptr H = P.H();
-      PQP_E(k) if (in(k)) obj += 0.5 * x[k] * x[k] * H[(long)idx(k) * n + idx(k)] + g[idx(k)] * x[k];
+      PQP_E(k) if (in(k)) obj += 0.5 * x[k] * x[k] * H[(long)idx(k) * n + idx(k)] + lv(LV_GU, k) * x[k];
       bytes((long)n * 8);
       info.objValue = wave_sum(obj);
     }
@@ -1546,6 +1558,7 @@ struct DiagSolver
       PQP_GLOBAL int* ga = P.act();
       PQP_E(c) if (in(c)) ga[idx(c)] = act_pack(lds_i[idx(c)], fl[c] & 3);
     }
+    toc(ST_CYC_F_WRITEBACK);
     if (lane == 0) {
       if (st.compute_timings) {
         info.solve_time = (double)(wall_clock64() - wall0) * batch.wall_us_per_tick;
@@ -1581,6 +1594,7 @@ struct DiagSolver
 };
 
 #undef PQP_E
+#undef PQP_KEEP
 
 template<int E>
 __device__ __forceinline__ void

@@ -36,6 +36,13 @@
 #if (PQP_TU == 1 || PQP_TU == 4 || PQP_TU == 8 || PQP_TU == 9) && !defined(PQP_ZG_DEPTH)
 #define PQP_ZG_DEPTH 4
 #endif
+// (the one-wavefront diagonal kernel is not short of scalar registers: its per-QP pointers are ordinary values -- the
+// optimisation barriers that keep them from being hoisted in the workgroup kernels would pin them to SGPRs inside
+// lane-divergent code here)
+#if PQP_TU == 16
+#define PQP_OPAQUE_SCALAR(v)
+#define PQP_OPAQUE_VECTOR(v)
+#endif
 #include "pqp_host.hpp"
 #include "pqp_diag.hpp"
 
@@ -414,7 +421,8 @@ pqp_launch_solve(pqp_batch* h)
           all_diag = h->c_diag[q] != 0;
         if (all_diag) {
           // (PQP_DIAG_KERNEL=workgroup: the 256-thread form of the same solver, kept as the A/B partner of the tests)
-          static const bool wg = [] { const char* e = std::getenv("PQP_DIAG_KERNEL"); return e && e[0] == 'w'; }();
+          const char* e = std::getenv("PQP_DIAG_KERNEL"); // (read per launch: the tests switch it between two solves)
+          const bool wg = e && e[0] == 'w';
           return (!wg && dd.n <= 256) ? pqp_launch_solve_diag_wave(h) : pqp_launch_solve_256_s2(h);
         }
         return (h->range_count <= (long)h->n_cu) ? pqp_launch_solve_256_s0_one(h) : pqp_launch_solve_256_s0(h);

@@ -3126,10 +3126,7 @@ struct Solver
   // in (lo, al[p]] and in (lo, hi], all in ONE fused reduction.  `mag` bounds the size of the terms of each value.
   // `bmag`: an alpha-independent bound on the sum of the MAGNITUDES of the terms of the b-sums (they cancel; the a-sums
   // are sums of squares), see primal_dual_ls.
-  // breakpoints a thread owns in the bracket line search: two with at least 256 threads (2 n_c <= 2 NT); the one-wavefront
-  // kernel of the diagonal-structure path (NT = 64, rows <= 256) owns up to eight
-  static constexpr int LS_MINE = (NT >= 256) ? 2 : 512 / NT;
-  __device__ __forceinline__ void ls_grad3(const double (&al)[3], double a0, double b0, double bmag, const double (&mine)[LS_MINE],
+  __device__ __forceinline__ void ls_grad3(const double (&al)[3], double a0, double b0, double bmag, const double (&mine)[2],
                                            double lo, double hi, double (&g)[3], double (&mag)[3], double (&cle)[3], double& ctot)
   {
     const int nc = d.nc;
@@ -3157,7 +3154,7 @@ struct Solver
       }
     }
 #pragma unroll
-    for (int r = 0; r < LS_MINE; ++r)
+    for (int r = 0; r < 2; ++r)
       if (mine[r] > lo && mine[r] <= hi) {
         sv[15] += 1.0;
 #pragma unroll
@@ -3213,12 +3210,11 @@ struct Solver
     // (|b_in| itself underestimates it) -- and the factor below is sixteen times the bound
     const double SURE = 3.6e-15 * (double)(nc + d.n + d.n_eq);
     // this thread's breakpoints (as in the full evaluation below)
-    double mine[LS_MINE];
+    double mine[2] = { -1.0, -1.0 };
     double cnt = 0, amax = 0, amin_neg = -INF;
 #pragma unroll
-    for (int rep = 0; rep < LS_MINE; ++rep) {
+    for (int rep = 0; rep < 2; ++rep) {
       const int t = threadIdx.x + rep * NT;
-      mine[rep] = -1.0;
       if (t < 2 * nc) {
         const int i = t >> 1;
         const double cdx = L.Cdx()[i];
@@ -3314,7 +3310,7 @@ struct Solver
     if (!all_negative) {
       double below = 0.0, above = -INF;
 #pragma unroll
-      for (int rep = 0; rep < LS_MINE; ++rep)
+      for (int rep = 0; rep < 2; ++rep)
         if (mine[rep] > 0) {
           if (mine[rep] <= lo)
             below = fmax(below, mine[rep]);
@@ -3345,7 +3341,7 @@ struct Solver
       if (threadIdx.x == 0)
         list[0] = 0.0;
 #pragma unroll
-      for (int rep = 0; rep < LS_MINE; ++rep) {
+      for (int rep = 0; rep < 2; ++rep) {
         const double a = mine[rep];
         const bool take = all_negative ? (a > 0 && a == amax) : (a > 0 && ((a > lo && a <= hi) || a == pred || a == succ));
         if (take) {
@@ -3490,7 +3486,7 @@ struct Solver
     }
     // (kernels with the bracket line search: an alpha-independent bound on sum_i |term_i| of the inequality b-sums --
     // apz_i is 0, rup_i, si_i or their sum, e_i is 0 or Cdx_i; PDAL adds (e_i - mu dz_i)(apz_i - mu z_i) -- ls_bracket)
-    constexpr bool BRACKET = PQP_LS_BRACKET && SPEC != 1 && NT <= 256;
+    constexpr bool BRACKET = PQP_LS_BRACKET && SPEC != 1 && NT == 256;
     double s_bmag = 0;
     for (int k = threadIdx.x; k < nc; k += NT) {
       dwm = fmax(dwm, fabs(L.dz()[k]));
@@ -3540,8 +3536,8 @@ struct Solver
     // an exact value that contradicts the bracket) falls back to the full evaluation.
     // (the kernels that serve such shapes; in the kernel of the common signature -- C2, 200 breakpoints on 256 threads -- the bracket
     // is 6.7 % SLOWER than one pass with every breakpoint on its own thread: profiles/r03_ab_linesearch_bracket.txt)
-    if constexpr (BRACKET)
-    if (2 * nc > NT && 2 * nc <= LS_MINE * NT) { // (its per-thread lists hold LS_MINE breakpoints)
+    if constexpr (PQP_LS_BRACKET && SPEC != 1 && NT == 256)
+    if (2 * nc > NT && nc <= NT) { // (its per-thread lists hold two breakpoints)
       double alpha_b;
       sub_tic(ST_CYC_LS_EVAL);
       const bool ok = ls_bracket(a0, b0, gpdal ? info.mu_in_inv * s_bmag / st.alpha_gpdal : info.mu_in_inv * s_bmag, alpha_b);
@@ -3550,7 +3546,7 @@ struct Solver
         return alpha_b;
     }
     // more breakpoints than two per thread (n_c > NT: only the 1024-thread kernels meet such shapes, above 1024 rows)
-    if constexpr (NT == 1024 || NT < 256 || PQP_CHUNK_ALL)
+    if constexpr (NT == 1024 || PQP_CHUNK_ALL)
       if (PQP_UNLIKELY(nc > NT))
         return ls_all_breakpoints_wide(a0, b0);
     // breakpoints (linesearch.hpp:378-391): every breakpoint gets its own thread and

@@ -143,6 +143,22 @@ def test_c5_forms_small(lib, oracle, randqp):
     assert np.max(np.abs(xa - xb)) <= 1e-7 * (1 + np.max(np.abs(xa)))
 
 
+@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
+    """the diagonal-structure solver as one wavefront per QP with its vectors in registers (csrc/pqp_diag.hpp) -- and, as
+    its A/B partner (PQP_DIAG_KERNEL=workgroup), the 256-thread form of the same solver -- through the whole solve
+    state machine against the oracle: both forms of the bounds, diagonal and zero Hessian, no inequality at all, PDAL"""
+    monkeypatch.setenv("PQP_DIAG_KERNEL", kernel)
+    pc.case_diag_wave_flows(lib, oracle, randqp, 24, box=False)
+    pc.case_diag_wave_flows(lib, oracle, randqp, 70, box=True)
+    pc.case_diag_wave_flows(lib, oracle, randqp, 130, box=False, B=2)
+    pc.case_diag_wave_flows(lib, oracle, randqp, 40, box=True, hessian=HessianType.Zero)
+    pc.case_diag_wave_flows(lib, oracle, randqp, 30, box=False, constrained=False)
+    forked = pc.case_diag_wave_flows(lib, oracle, randqp, 36, box=True, merit=1) + pc.case_diag_wave_flows(lib, oracle, randqp, 36, box=False, merit=1)
+    assert forked <= 6, forked
+    assert pc.case_diag_wave_infeasible(lib, oracle) != int(pc.QPSolverOutput.PROXQP_SOLVED)
+
+
 def test_primal_ldlt_engine(lib, oracle, randqp):
     pc.case_primal_ldlt(lib, oracle, randqp, dim=12, B=2)
 

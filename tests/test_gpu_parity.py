@@ -178,9 +178,25 @@ def test_full_size_c4_all_against_oracle(lib, oracle, randqp):
 
 @pytest.mark.parametrize("box", [False, True])
 def test_full_shape_c5_against_oracle(lib, oracle, randqp, box):
-    """BASELINE.json configs[4] (n = 200, diagonal Hessian, 200 bound pairs) at a batch that fills
-    the GPU (768 = 3 workgroups x 256 CUs), both forms; every QP against the oracle and KKT-gated."""
-    pc.case_c5(lib, oracle, randqp, B=768, sample=768, box=box)
+    """BASELINE.json configs[4] at its real size: ALL 4096 QPs (n = 200, diagonal Hessian, 200 bound pairs), both forms,
+    through the one-wavefront kernel; every QP against the oracle (1e-10, equal Info) and KKT-gated in numpy."""
+    pc.case_c5(lib, oracle, randqp, B=4096, sample=4096, box=box)
+
+
+@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
+    """the one-wavefront, register-resident diagonal-structure kernel (csrc/pqp_diag.hpp) and its 256-thread A/B partner
+    through the whole solve state machine against the oracle, at the sizes of BASELINE.json configs[4] and at the edges of
+    the kernel's range (dim 256 = four register slots per lane, dim 1)"""
+    monkeypatch.setenv("PQP_DIAG_KERNEL", kernel)
+    for dim, box in ((200, False), (200, True), (256, True), (256, False), (65, False), (1, True)):
+        pc.case_diag_wave_flows(lib, oracle, randqp, dim, box=box, B=6 if dim > 1 else 2)
+    pc.case_diag_wave_flows(lib, oracle, randqp, 200, box=True, hessian=pc.HessianType.Zero)
+    pc.case_diag_wave_flows(lib, oracle, randqp, 120, box=False, constrained=False)
+    forked = pc.case_diag_wave_flows(lib, oracle, randqp, 150, box=True, merit=1, B=8) + pc.case_diag_wave_flows(lib, oracle, randqp, 150, box=False, merit=1, B=8)
+    print("PDAL flows on the diagonal kernel (%s): %d forked results of %d" % (kernel, forked, 2 * 8 * 8))
+    assert forked <= 13, forked
+    assert pc.case_diag_wave_infeasible(lib, oracle) != int(pc.QPSolverOutput.PROXQP_SOLVED)
 
 
 def test_infeasibility_statuses(lib, oracle):
