@@ -228,6 +228,28 @@ struct Ldlt
       ctr->level2_flops += 2.0 * double(m) * double(m);
   }
 
+  template<int K>
+  static void rank_chunk_columns(double* __restrict__ inout_l, double* __restrict__ w0, isize w_stride, isize rem,
+                                 const double* p_array, const double* mu_array)
+  {
+    double p[K], mu[K];
+    for (int k = 0; k < K; ++k) {
+      p[k] = p_array[k];
+      mu[k] = mu_array[k];
+    }
+#pragma omp simd
+    for (isize i = 0; i < rem; ++i) {
+      double in_l = inout_l[i];
+      for (int k = 0; k < K; ++k) {
+        double wr = w0[k * w_stride + i];
+        wr = std::fma(-p[k], in_l, wr);
+        in_l = std::fma(mu[k], wr, in_l);
+        w0[k * w_stride + i] = wr;
+      }
+      inout_l[i] = in_l;
+    }
+  }
+
   // update.hpp:219-287.  `r_fn()` is called once per column and returns how
   // many of the r updates are active from this column on.
   template<typename RFn>
@@ -262,15 +284,21 @@ struct Ldlt
         isize rem = ln - j - 1;
         double* inout_l = l + j * stride + j + 1;
         double* w0 = pw + 1 + r_done * w_stride;
-        for (isize i = 0; i < rem; ++i) {
-          double in_l = inout_l[i];
-          for (isize k = 0; k < r_chunk; ++k) {
-            double wr = w0[k * w_stride + i];
-            wr = std::fma(-p_array[k], in_l, wr);
-            in_l = std::fma(mu_array[k], wr, in_l);
-            w0[k * w_stride + i] = wr;
-          }
-          inout_l[i] = in_l;
+        // (one instance per chunk width, the column loop vectorised over i -- the reference does the same with explicit
+        // SIMD packs, update.hpp:155-204; every element still sees the same chain of fused multiply-adds: same bits)
+        switch (r_chunk) {
+          case 1:
+            rank_chunk_columns<1>(inout_l, w0, w_stride, rem, p_array, mu_array);
+            break;
+          case 2:
+            rank_chunk_columns<2>(inout_l, w0, w_stride, rem, p_array, mu_array);
+            break;
+          case 3:
+            rank_chunk_columns<3>(inout_l, w0, w_stride, rem, p_array, mu_array);
+            break;
+          default:
+            rank_chunk_columns<4>(inout_l, w0, w_stride, rem, p_array, mu_array);
+            break;
         }
         if (ctr)
           ctr->level2_flops += 4.0 * double(rem) * double(r_chunk);

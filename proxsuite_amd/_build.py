@@ -226,6 +226,17 @@ def build_oracle(force: bool = False) -> Path:
     return lib
 
 
+def kernel_sources_sha(diag: bool = False) -> str:
+    """sha256 (first 16 hex digits) of the device sources a solve kernel is compiled from: what a PMC traffic figure in
+    profiles/pmc_traffic.json was measured on (scripts/merge_pmc_traffic.py stamps it, bench.py compares)"""
+    import hashlib
+    files = ["pqp_solver.hpp", "pqp_block.hpp"] + (["pqp_diag.hpp"] if diag else [])
+    h = hashlib.sha256()
+    for f in files:
+        h.update((CSRC / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def freeze_kernel_resources():
     """tests/golden/kernel_resources_expected.json <- the record of the current product build (run after a kernel
     change has been measured on the GPU and accepted: tests/test_kernel_resources.py then guards it)"""

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "pqp_host.hpp"
+#include "pqp_diag.hpp"
 
 namespace {
 
@@ -1453,10 +1454,11 @@ pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes)
 {
   if (!h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
+  const bool wave = pqp_diag_dispatch(h) == 1; // (known once the set-up kernel has run: pqp_batch_flush)
   if (threads)
-    *threads = h->nt;
+    *threads = wave ? 64 : h->nt;
   if (lds_bytes)
-    *lds_bytes = int64_t(h->lds_solve);
+    *lds_bytes = wave ? int64_t(pqp::diag_lds_bytes(4)) : int64_t(h->lds_solve);
   return PQP_OK;
 }
 

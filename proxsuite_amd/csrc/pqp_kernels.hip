@@ -403,6 +403,22 @@ pqp_launch_pack(pqp_batch* h, long first, long count, double* out, hipStream_t s
   return PQP_OK;
 }
 
+// 0: the workgroup kernels; 1: every QP of the batch has diagonal structure (signature + the flags the set-up kernel left)
+// and the launch goes to the one-wavefront kernel of pqp_diag.hpp; 2: the same, forced to the 256-thread form of that
+// solver by PQP_DIAG_KERNEL=workgroup (its A/B partner in the tests; read per launch: they switch it between two solves)
+int
+pqp_diag_dispatch(const pqp_batch* h)
+{
+  const pqp::Dims& dd = h->dev.d;
+  if (h->nt != 256 || h->vec_scratch || !pqp::diag_structure_signature(dd.hessian, dd.n_eq, dd.n_in, dd.box) || h->c_diag.empty())
+    return 0;
+  for (size_t q = 0; q < h->c_diag.size(); ++q)
+    if (!h->c_diag[q])
+      return 0;
+  const char* e = std::getenv("PQP_DIAG_KERNEL");
+  return (e && e[0] == 'w') || dd.n > 256 ? 2 : 1;
+}
+
 int
 pqp_launch_solve(pqp_batch* h)
 {
@@ -414,17 +430,8 @@ pqp_launch_solve(pqp_batch* h)
   switch (h->nt) {
     case 256:
       if (!common) {
-        // every QP of the batch in diagonal structure (signature + the flags the set-up kernel left): the dedicated kernel
-        const pqp::Dims& dd = h->dev.d;
-        bool all_diag = pqp::diag_structure_signature(dd.hessian, dd.n_eq, dd.n_in, dd.box) && !h->c_diag.empty();
-        for (size_t q = 0; all_diag && q < h->c_diag.size(); ++q)
-          all_diag = h->c_diag[q] != 0;
-        if (all_diag) {
-          // (PQP_DIAG_KERNEL=workgroup: the 256-thread form of the same solver, kept as the A/B partner of the tests)
-          const char* e = std::getenv("PQP_DIAG_KERNEL"); // (read per launch: the tests switch it between two solves)
-          const bool wg = e && e[0] == 'w';
-          return (!wg && dd.n <= 256) ? pqp_launch_solve_diag_wave(h) : pqp_launch_solve_256_s2(h);
-        }
+        if (const int dg = pqp_diag_dispatch(h))
+          return dg == 1 ? pqp_launch_solve_diag_wave(h) : pqp_launch_solve_256_s2(h);
         return (h->range_count <= (long)h->n_cu) ? pqp_launch_solve_256_s0_one(h) : pqp_launch_solve_256_s0(h);
       }
       // more workgroups than three per CU can hold at once: the four-per-CU build; otherwise the

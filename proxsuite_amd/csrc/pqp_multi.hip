@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pqp_host.hpp"
@@ -59,6 +60,41 @@ off(double* p, int64_t first, size_t per_qp)
 typedef int (*setup_fn)(pqp_batch*, int64_t, const double*, const double*, const double*, const double*, const double*,
                         const double*, const double*, const double*, const double*, int, double, double, double, double);
 
+// Runs `work(s)` for every shard that holds QPs, all of them at once: one host thread per shard (the caller's takes the
+// first).  A set-up is a blocking copy of the shard's slice of the model from pageable host memory plus, at flush time,
+// the set-up kernel and a read-back of its flags -- walked shard after shard (rounds 3-4) the G devices of a node worked
+// one at a time: 8 x (H2D + Ruiz) in front of an 8 ms solve (reference parallel/qp_solve.hpp:41-59 sets
+// up on every core at once).  Every entry of the batch C-ABI switches to its handle's device for the calling thread only
+// (DeviceGuard) and reports errors through a thread-local message: the first failure is re-raised on the caller's thread.
+template<class F>
+int
+for_shards(pqp_multi* m, F&& work)
+{
+  std::vector<size_t> live;
+  for (size_t s = 0; s < m->shard.size(); ++s)
+    if (m->count[s] > 0)
+      live.push_back(s);
+  if (live.empty())
+    return PQP_OK;
+  std::vector<int> rc(live.size(), PQP_OK);
+  std::vector<std::string> msg(live.size());
+  auto run = [&](size_t k) {
+    rc[k] = work(live[k]);
+    if (rc[k])
+      msg[k] = pqp_last_error();
+  };
+  std::vector<std::thread> helpers;
+  for (size_t k = 1; k < live.size(); ++k)
+    helpers.emplace_back(run, k);
+  run(0);
+  for (std::thread& t : helpers)
+    t.join();
+  for (size_t k = 0; k < live.size(); ++k)
+    if (rc[k])
+      return fail(rc[k], msg[k]);
+  return PQP_OK;
+}
+
 int
 multi_setup(pqp_multi* m, setup_fn fn, int64_t idx, const double* H, const double* g, const double* A, const double* b,
             const double* C, const double* l, const double* u, const double* l_box, const double* u_box, int flag,
@@ -72,15 +108,13 @@ multi_setup(pqp_multi* m, setup_fn fn, int64_t idx, const double* H, const doubl
               min_eig);
   }
   const size_t n = size_t(m->d.n), ne = size_t(m->d.n_eq), ni = size_t(m->d.n_in);
-  for (size_t s = 0; s < m->shard.size(); ++s) {
-    if (m->count[s] == 0)
-      continue;
+  // every shard takes its slice of the model at the same time (see for_shards): the host-to-device copies of the G
+  // devices overlap instead of queueing behind one another
+  return for_shards(m, [&](size_t s) {
     const int64_t f = m->first[s];
-    if (int rc = fn(m->shard[s], -1, off(H, f, n * n), off(g, f, n), off(A, f, ne * n), off(b, f, ne), off(C, f, ni * n),
-                    off(l, f, ni), off(u, f, ni), off(l_box, f, n), off(u_box, f, n), flag, rho, mu_eq, mu_in, min_eig))
-      return rc;
-  }
-  return PQP_OK;
+    return fn(m->shard[s], -1, off(H, f, n * n), off(g, f, n), off(A, f, ne * n), off(b, f, ne), off(C, f, ni * n),
+              off(l, f, ni), off(u, f, ni), off(l_box, f, n), off(u_box, f, n), flag, rho, mu_eq, mu_in, min_eig);
+  });
 }
 
 } // namespace
@@ -267,10 +301,8 @@ pqp_multi_flush(pqp_multi* m)
 {
   if (!m)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null multi-device handle");
-  for (pqp_batch* h : m->shard)
-    if (int rc = pqp_batch_flush(h))
-      return rc;
-  return PQP_OK;
+  // (set-up kernel + its synchronisation + the read-back of the structure flags, every shard at the same time)
+  return for_shards(m, [&](size_t s) { return pqp_batch_flush(m->shard[s]); });
 }
 
 int
@@ -384,38 +416,62 @@ pqp_multi_gather_device(pqp_multi* m, int root_shard, double* out)
   const size_t width = size_t(m->d.n) + size_t(m->d.n_eq) + size_t(m->d.nc) + 2;
   const int root_dev = m->shard[size_t(root_shard)]->device;
   // pack on every shard's stream (ordered behind a solve in flight on that stream), then the copy into place on the
-  // same stream: G independent chains, one synchronisation each at the end
-  for (size_t s = 0; s < m->shard.size(); ++s) {
+  // same stream: G independent chains, one synchronisation each at the end.  A failure on one shard does not return
+  // before the chains already enqueued on the others have drained: they write into the caller's buffer.
+  int rc = PQP_OK;
+  std::string msg;
+  auto bad = [&](int code, const std::string& what) {
+    if (rc == PQP_OK) {
+      rc = code;
+      msg = what;
+    }
+  };
+  for (size_t s = 0; s < m->shard.size() && rc == PQP_OK; ++s) {
     if (m->count[s] == 0)
       continue;
     pqp_batch* h = m->shard[s];
     DeviceGuard guard(h->device);
-    if (!guard.ok())
-      return fail(PQP_ERR_HIP, "hipSetDevice failed in pqp_multi_gather_device");
+    if (!guard.ok()) {
+      bad(PQP_ERR_HIP, "hipSetDevice failed in pqp_multi_gather_device");
+      break;
+    }
     double* dst = out + size_t(m->first[s]) * width;
     const size_t bytes = size_t(m->count[s]) * width * sizeof(double);
     if (h->device == root_dev) {
       // same device: the pack kernel writes straight into the caller's buffer
-      if (int rc = pqp_batch_pack_results(h, 0, m->count[s], dst, m->stream[s]))
-        return rc;
+      if (int r = pqp_batch_pack_results(h, 0, m->count[s], dst, m->stream[s]))
+        bad(r, pqp_last_error());
       continue;
     }
-    if (!m->pack[s])
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->pack[s]), bytes));
-    if (int rc = pqp_batch_pack_results(h, 0, m->count[s], m->pack[s], m->stream[s]))
-      return rc;
-    HIP_TRY(hipMemcpyPeerAsync(dst, root_dev, m->pack[s], h->device, bytes, m->stream[s]));
+    hipError_t e = hipSuccess;
+    if (!m->pack[s] && (e = hipMalloc(reinterpret_cast<void**>(&m->pack[s]), bytes)) != hipSuccess) {
+      bad(PQP_ERR_HIP, std::string("hipMalloc of the pack buffer: ") + hipGetErrorString(e));
+      break;
+    }
+    if (int r = pqp_batch_pack_results(h, 0, m->count[s], m->pack[s], m->stream[s])) {
+      bad(r, pqp_last_error());
+      break;
+    }
+    if ((e = hipMemcpyPeerAsync(dst, root_dev, m->pack[s], h->device, bytes, m->stream[s])) != hipSuccess)
+      bad(PQP_ERR_HIP, std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e));
   }
   for (size_t s = 0; s < m->shard.size(); ++s) {
     if (m->count[s] == 0)
       continue;
     DeviceGuard guard(m->shard[s]->device);
-    if (!guard.ok())
-      return fail(PQP_ERR_HIP, "hipSetDevice failed in pqp_multi_gather_device");
-    HIP_TRY(hipStreamSynchronize(m->stream[s]));
+    if (!guard.ok()) {
+      bad(PQP_ERR_HIP, "hipSetDevice failed in pqp_multi_gather_device");
+      continue;
+    }
+    const hipError_t e = hipStreamSynchronize(m->stream[s]);
+    if (e != hipSuccess)
+      bad(PQP_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
   }
   // (the solves those streams carried have finished with them: run their host-side bookkeeping)
-  return pqp_multi_wait(m);
+  const int wrc = pqp_multi_wait(m);
+  if (rc != PQP_OK)
+    return fail(rc, msg);
+  return wrc;
 }
 
 double

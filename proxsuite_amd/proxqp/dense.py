@@ -150,9 +150,12 @@ class _Pool:
         self.batch = _native.Batch(capacity, n, n_eq, n_in, box_constraints=box, hessian_type=int(hessian_type),
                                    dense_backend=int(dense_backend), device=device)
         # results are host members when a solve returns (reference parallel/qp_solve.hpp:33-37): the solve kernel writes
-        # them into pinned host mirrors; a stream of its own lets this pool overlap with the others
-        self.batch.enable_host_results(True)
-        self.batch.own_stream()
+        # them into pinned host mirrors; a stream of its own lets this pool overlap with the others.  A pool of ONE slot
+        # (a standalone QP, a one-shot dense.solve()) gets neither before its first asynchronous solve: a Python list of
+        # N standalone QPs would otherwise mean N streams and 6 N pinned allocations before anything is solved.
+        self._overlap = False
+        if capacity > 1:
+            self._enable_overlap()
         self.device = device
         self.capacity = capacity
         self.used = 0
@@ -160,12 +163,26 @@ class _Pool:
         self._cache_epoch = -1
         self._cache = None
 
+    def _enable_overlap(self):
+        if not self._overlap:
+            self.batch.enable_host_results(True)
+            self.batch.own_stream()
+            self._overlap = True
+
     def touch(self):
         self._epoch += 1
 
+    def _mirrors_fresh(self):
+        """the pinned mirrors hold the results of every USED slot (a partially filled pool never solves its free slots)"""
+        if not self._overlap:
+            return False
+        if self.batch.host_results_fresh(-1):
+            return True
+        return 0 < self.used < self.capacity and all(self.batch.host_results_fresh(i) for i in range(self.used))
+
     def fetch(self):
         if self._cache_epoch != self._epoch:
-            if self.batch.host_results_fresh():
+            if self._mirrors_fresh():
                 # one host copy out of the pinned mirrors (a snapshot: a Results object handed out earlier must not change
                 # under a later solve); the Info records as a ctypes array like results() returns
                 hx, hy, hz, hse, hsi, hinfo = self.batch.host_results()
@@ -187,6 +204,7 @@ class _Pool:
 
     def solve_async(self, slots=None):
         """every used slot (or the listed ones, one launch) enqueued; `wait()` completes it"""
+        self._enable_overlap()
         if slots is None:
             if self.used:
                 self.batch.solve_async(0, self.used)
@@ -333,8 +351,18 @@ class BatchQP:
         self._capacity = max(int(batch_size), 1)
         if devices is None:
             if device is None:
+                # PQP_BATCH_DEVICES=0 | 0,2,3 | all overrides the default (all visible devices) for a process that
+                # must not allocate on GPUs it does not use
+                import os
+                env = os.environ.get("PQP_BATCH_DEVICES", "all").strip().lower()
                 nd = _native.load().L.pqp_device_count()
-                devices = list(range(nd)) if nd > 1 else [0]
+                if env in ("", "all"):
+                    devices = list(range(nd)) if nd > 1 else [0]
+                else:
+                    devices = [int(t) for t in env.split(",") if t.strip() != ""]
+                    bad = [d_ for d_ in devices if d_ < 0 or d_ >= max(nd, 1)]
+                    if bad or not devices:
+                        raise ValueError("PQP_BATCH_DEVICES=%r: device ordinals must be in [0, %d)" % (env, max(nd, 1)))
             else:
                 devices = [int(device)]
         self._devices = [int(d) for d in devices]
@@ -419,10 +447,14 @@ def solve_in_parallel(qps, num_threads=None):
     pools = {}
     for qp in qps:
         pools.setdefault(id(qp._pool), (qp._pool, []))[1].append(qp._slot)
-    for pool, slots in pools.values():
-        pool.solve_async(sorted(slots))  # the listed slots of a pool in ONE launch
-    for pool, _ in pools.values():
-        pool.wait()
+    launched = []
+    try:
+        for pool, slots in pools.values():
+            launched.append(pool)
+            pool.solve_async(sorted(set(slots)))  # the listed slots of a pool in ONE launch (a QP listed twice is solved once)
+    finally:
+        for pool in launched:  # (also when a later pool refused its launch: nothing stays in flight behind an exception)
+            pool.wait()
 
 
 def estimate_minimal_eigen_value_of_symmetric_matrix(H, estimate_method_option=EigenValueEstimateMethodOption.ExactMethod,

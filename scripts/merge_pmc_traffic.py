@@ -4,6 +4,7 @@ per-workload table profiles/pmc_traffic.json that bench.py reports as `roofline.
 import glob
 import json
 import os
+import subprocess
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
@@ -20,7 +21,16 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_traffic_*.json")
     dst = os.path.join(root, "profiles", "%s_pmc_%s.json" % (tag, w))
     json.dump(j, open(dst, "w"), indent=1)
     if "hbm_bytes_per_launch" in j:
+        sys.path.insert(0, root)
+        from proxsuite_amd import _build
+        diag = any("diag" in k for k in j["kernel"])
+        try:
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            commit = None
         table["workloads"][w] = {"hbm_bytes_per_launch": j["hbm_bytes_per_launch"], "kernel": j["kernel"],
+                                 # what it was measured on: bench.py prints traffic_stale when the kernel sources have changed since
+                                 "kernel_sources_sha": _build.kernel_sources_sha(diag), "measured_at_commit": commit,
                                  "source": "profiles/%s_pmc_%s.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
                                            "separate passes; bytes = 1024*(2*FETCH_SIZE+WRITE_SIZE))" % (tag, w)}
     print("merged", w)
