@@ -197,7 +197,7 @@ def build_hip_variants(force: bool = False):
     return out
 
 
-def build_tu_variant(tu: int, extra_flags, out: Path) -> Path:
+def build_tu_variant(tu, extra_flags, out: Path) -> Path:
     """A/B partner that differs from the product in ONE kernel family: translation unit `tu` recompiled with
     `extra_flags`, every other object taken from the product build (seconds instead of minutes)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -205,12 +205,17 @@ def build_tu_variant(tu: int, extra_flags, out: Path) -> Path:
     base = OBJ_DIR / "default"
     out = Path(out)
     out.parent.mkdir(parents=True, exist_ok=True)
-    o = base / ("kernels_%d_%08x.o" % (tu, hash(tuple(extra_flags)) & 0xffffffff))
-    r = _run([hipcc, *hip_flags(tuple(extra_flags)), *TU_FLAGS.get(tu, []), "-DPQP_TU=%d" % tu, "-c",
-              str(CSRC / "pqp_kernels.hip"), "-o", str(o)])
-    objs = [base / "capi.o", base / "multi.o", base / "calib.o"] + [o if k == tu else base / ("kernels_%d.o" % k) for k in KERNEL_TUS]
+    tus = [tu] if isinstance(tu, int) else list(tu)
+    repl, res = {}, {}
+    for t in tus:
+        o = base / ("kernels_%d_%08x.o" % (t, hash(tuple(extra_flags)) & 0xffffffff))
+        r = _run([hipcc, *hip_flags(tuple(extra_flags)), *TU_FLAGS.get(t, []), "-DPQP_TU=%d" % t, "-c",
+                  str(CSRC / "pqp_kernels.hip"), "-o", str(o)])
+        repl[t] = o
+        res.update({kernel_label(k): v for k, v in parse_kernel_resources(r.stderr).items()})
+    objs = [base / "capi.o", base / "multi.o", base / "calib.o"] + [repl.get(k, base / ("kernels_%d.o" % k)) for k in KERNEL_TUS]
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *map(str, objs)])
-    return out, {kernel_label(k): v for k, v in parse_kernel_resources(r.stderr).items()}
+    return out, res
 
 
 def build_oracle(force: bool = False) -> Path:

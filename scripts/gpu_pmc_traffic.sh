@@ -34,7 +34,7 @@ for w in sys.argv[1:]:
     for f in newest.values():
         per = collections.defaultdict(float)
         for row in csv.DictReader(open(f)):
-            if 'pqp_solve_kernel' not in row.get('Kernel_Name', ''):
+            if 'pqp_solve_kernel' not in row.get('Kernel_Name', '') and 'pqp_diag_kernel' not in row.get('Kernel_Name', ''):
                 continue
             names.add(row['Kernel_Name'])
             per[(row['Counter_Name'], row['Dispatch_Id'])] += float(row['Counter_Value'])
@@ -43,7 +43,7 @@ for w in sys.argv[1:]:
     traces = glob.glob('gpurun_out/pmct_%s_FETCH_SIZE/**/*kernel_trace.csv' % w, recursive=True)
     for f in sorted(traces, key=os.path.getmtime)[-1:]:
         for row in csv.DictReader(open(f)):
-            if 'pqp_solve_kernel' in row.get('Kernel_Name', ''):
+            if 'pqp_solve_kernel' in row.get('Kernel_Name', '') or 'pqp_diag_kernel' in row.get('Kernel_Name', ''):
                 dur.append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) * 1e-6)
     # per launch: the MEDIAN over the launches of the run -- the steady-state dirty re-solve of an init-ed batch that the
     # timed region of bench.py consists of (the launches that follow a fresh init rewrite the equilibrated matrices and
@@ -63,6 +63,14 @@ for w in sys.argv[1:]:
     if 'SQ_WAVE_CYCLES' in mean and mean['SQ_WAVE_CYCLES']:
         out["wait_any_over_wave_cycles"] = mean.get('SQ_WAIT_ANY', 0) / mean['SQ_WAVE_CYCLES']
         out["valu_active_over_wave_cycles"] = mean.get('SQ_ACTIVE_INST_VALU', 0) / mean['SQ_WAVE_CYCLES']
+    if mean.get('SQ_INSTS_VALU') and dur:
+        # vector-ALU issue: a wave64 instruction occupies its SIMD's 16 lanes for 4 cycles; 1024 SIMDs; SQ_INSTS_VALU counts
+        # instructions per wavefront summed over the device.  Against the kernel's duration at the shader clock the
+        # calibration kernels imply (~1.94 GHz under load, profiles/r05_box_calibration.txt)
+        cyc = (sum(dur) / len(dur)) * 1e-3 * 1.94e9
+        out["valu_insts_per_launch"] = mean['SQ_INSTS_VALU']
+        out["valu_issue_frac_of_peak"] = mean['SQ_INSTS_VALU'] * 4.0 / (1024.0 * cyc)
+        out["valu_issue_note"] = "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel duration x 1.94 GHz)"
     if mean.get('TCC_HIT_sum') is not None and mean.get('TCC_MISS_sum') is not None:
         t = mean['TCC_HIT_sum'] + mean['TCC_MISS_sum']
         out["l2_hit_rate"] = mean['TCC_HIT_sum'] / t if t else None

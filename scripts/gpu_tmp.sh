@@ -1,5 +1,4 @@
 export TMPDIR=/tmp
-for l in build/variants/libproxqp_hip_diagw1.so build/variants/libproxqp_hip_diagw3.so; do
-  echo "== $l"; B=512 timeout 60 python scripts/gpu_time_libs.py c5 1 $l 2>&1 | grep -v amdgpu.ids | tail -3; echo "rc=$?"
-done
-echo "== both product+w1"; B=512 timeout 90 python scripts/gpu_time_libs.py c5 1 proxsuite_amd/csrc/libproxqp_hip.so build/variants/libproxqp_hip_diagw1.so 2>&1 | grep -v amdgpu.ids | tail -3
+NS=build/variants/libproxqp_hip_nostage.so
+P=proxsuite_amd/csrc/libproxqp_hip.so
+for off in 0 1; do echo "PQP_STAGE_OFF=$off"; for B in 1 128; do PQP_STAGE_OFF=$off timeout 120 python scripts/gpu_time_shape.py $B 100 50 100 0 0 3 $NS $P 2>&1 | grep -v "amdgpu.ids\|bit-id"; done;  PQP_STAGE_OFF=$off timeout 120 python scripts/gpu_time_libs.py c1 3 $NS $P 2>&1 | grep -v amdgpu.ids; done
