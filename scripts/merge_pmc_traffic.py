@@ -31,6 +31,10 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_traffic_*.json")
         table["workloads"][w] = {"hbm_bytes_per_launch": j["hbm_bytes_per_launch"], "kernel": j["kernel"],
                                  # what it was measured on: bench.py prints traffic_stale when the kernel sources have changed since
                                  "kernel_sources_sha": _build.kernel_sources_sha(diag), "measured_at_commit": commit,
+                                 # what the kernel waits for, from the same passes (SQ_* / TCC_* counters)
+                                 "counters": {k: j.get(k) for k in ("wait_any_over_wave_cycles", "valu_active_over_wave_cycles",
+                                                                     "valu_issue_frac_of_peak", "l2_hit_rate",
+                                                                     "kernel_ms_under_profiler") if j.get(k) is not None},
                                  "source": "profiles/%s_pmc_%s.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
                                            "separate passes; bytes = 1024*(2*FETCH_SIZE+WRITE_SIZE))" % (tag, w)}
     print("merged", w)
