@@ -20,6 +20,7 @@ python bench.py --gpus 1 --total-batch 16384 --steps 5 --warmup 1 --mpc-steps 0 
 tail -1 gpurun_out/final/${TAG}_bench_c3_1gpu.log > gpurun_out/final/${TAG}_bench_c3_1gpu.json
 # the in-process multi-device path (pqp_multi_*), shards mapped onto the one GPU of the box
 PQP_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --inprocess --steps 5 --warmup 1 > gpurun_out/final/${TAG}_bench_inprocess_2shards_one_gpu.log 2>&1
+PQP_BENCH_ONE_DEVICE=1 python bench.py --gpus 4 --inprocess --steps 5 --warmup 1 > gpurun_out/final/${TAG}_bench_inprocess_4shards_one_gpu.log 2>&1
 PQP_BENCH_ONE_DEVICE=1 python bench.py --gpus 8 --inprocess --total-batch 16384 --steps 3 --warmup 1 > gpurun_out/final/${TAG}_bench_inprocess_c3_8shards_one_gpu.log 2>&1
 cd /tmp
 rm -rf $R/gpurun_out/final/trace
@@ -27,7 +28,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 cd $R
 f=$(find gpurun_out/final/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f gpurun_out/final/${TAG}_kernel_stats.csv
-scripts/gpu_pmc_traffic.sh c2 c1 c4 c5 c5box 2>&1 | tail -6
+# the same for the one-wavefront diagonal kernel (the dominant kernel of the C5 bench line)
+cd /tmp
+rm -rf $R/gpurun_out/final/trace_c5
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/trace_c5 -- python $R/bench.py --workload c5 --steps 10 --warmup 2 --no-cpu-baseline --mpc-steps 0 > $R/gpurun_out/final/${TAG}_trace_bench_c5.log 2>&1
+cd $R
+f=$(find gpurun_out/final/trace_c5 -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f gpurun_out/final/${TAG}_kernel_stats_c5.csv
+[ -z "$SKIP_PMC" ] && scripts/gpu_pmc_traffic.sh c2 c1 c4 c5 c5box 2>&1 | tail -6
 for w in c2 c1 c4 c5 c5box; do python - $w $TAG <<'PY'
 import json, sys
 w, tag = sys.argv[1:3]

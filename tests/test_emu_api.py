@@ -88,3 +88,16 @@ def test_timings_and_verbose(dense, randqp, capfd):
 
 def test_alias_package(dense):
     ac.case_alias_package()
+
+
+def test_box_calibration_is_refused_on_the_emulator():
+    """pqp_box_calibrate has no machine to measure under the emulator: an error code and a message, no kernels"""
+    import ctypes as C
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import build as emu_build
+    from proxsuite_amd import _native as N
+    lib = N.NativeLib(emu_build.build())
+    out = (C.c_double * 8)()
+    assert lib.L.pqp_box_calibrate(0, out, 8) != 0
+    assert b"emulator" in lib.L.pqp_last_error()

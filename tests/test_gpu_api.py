@@ -72,3 +72,16 @@ def test_timings_and_verbose(dense, randqp, capfd):
 
 def test_alias_package(dense):
     ac.case_alias_package()
+
+
+def test_box_calibration(dense):
+    """pqp_box_calibrate (include/proxqp_hip.h): the three fixed kernels report sane figures for an MI355X, twice the same
+    within a few percent, and a bad argument is an error, not a crash"""
+    from proxsuite_amd import _native as N
+    a, b = N.box_calibration(0), N.box_calibration(0)
+    for c in (a, b):
+        assert 1000.0 < c["hbm_read_gbs"] < 8000.0 and 0.2 < c["chain_ms"] < 10.0 and 500.0 < c["sclk_mhz_est"] < 3000.0, c
+        assert c["n_cu"] >= 64
+    assert abs(a["chain_ms"] / b["chain_ms"] - 1.0) < 0.1, (a, b)
+    lib = N.load()
+    assert lib.L.pqp_box_calibrate(0, None, 0) != 0

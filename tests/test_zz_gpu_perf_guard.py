@@ -4,8 +4,8 @@ alter silently, so the C2 / C4 / C5 kernel times are guarded -- but the boxes of
 binary (8.05 ms on the builder's boxes, 8.87 ms on the driver's), and an absolute limit in milliseconds goes
 red, or stays green, because of the lease.  Each limit is therefore the time recorded on the REFERENCE box
 (profiles/perf_guard.json: kernel times + that box's pqp_box_calibrate figures) scaled by how much slower THIS box runs
-the fixed latency-chain kernel of the calibration (C4, which is bandwidth-bound on real traffic: the larger of that and
-the HBM read-rate ratio), plus the margin (7 %)."""
+the fixed latency-chain kernel of the calibration or its dependent-FMA chain, whichever is further off (C4, which is
+bandwidth-bound on real traffic: the larger of that and the HBM read-rate ratio), plus the margin (7 %)."""
 import json
 import os
 
@@ -24,9 +24,11 @@ def box():
     guard = json.load(open(os.path.join(ROOT, "profiles", "perf_guard.json")))
     cal = [N.box_calibration(0), N.box_calibration(0)]
     chain = min(c["chain_ms"] for c in cal)
+    valu = min(c["valu_ms"] for c in cal)
     hbm = max(c["hbm_read_gbs"] for c in cal)
     ref = guard["reference_box"]
-    f_lat = chain / ref["chain_ms"]
+    # (latency side: the chain kernel or the dependent-FMA chain = the shader clock the box sustains, whichever is further off)
+    f_lat = max(chain / ref["chain_ms"], valu / ref["valu_ms"])
     f_bw = ref["hbm_read_gbs"] / hbm
     print("\nbox: chain %.3f ms (reference %.3f), HBM read %.0f GB/s (reference %.0f), sclk ~%.0f MHz -> latency factor %.3f, "
           "bandwidth factor %.3f" % (chain, ref["chain_ms"], hbm, ref["hbm_read_gbs"], cal[0]["sclk_mhz_est"], f_lat, f_bw))
