@@ -39,6 +39,56 @@ diag_lds_bytes(int E)
   return (size_t)(64 * E) * sizeof(int) + (size_t)(64 * E) * sizeof(double) * 9 + (ST_COUNT + 2) * sizeof(long long);
 }
 
+// Sum over the wavefront for THIS kernel (bound by vector-ALU issue: 65 % of the peak, profiles/r05_pmc_c5.json): the DPP
+// scan of pqp_block.hpp without the two identity moves per step -- the four steps inside a row read zero where no source
+// lane exists (bound_ctrl) instead of keeping a pre-loaded identity; the two cross-row steps keep it.  (ds_swizzle for
+// the data movement -- a third of the vector instructions -- was measured: 0.81 -> 0.90 ms, the LDS crossbar's latency
+// costs more than the issue slots it frees, even where eight independent reductions run together: 0.84 ms.)
+#ifndef PQP_EMULATED_MFMA
+template<int CTRL>
+__device__ __forceinline__ double
+dpp_shift_zero(double v)
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double
+lane_sum(double v)
+{
+  v += dpp_shift_zero<0x111>(v); // row_shr:1
+  v += dpp_shift_zero<0x112>(v); // row_shr:2
+  v += dpp_shift_zero<0x114>(v); // row_shr:4
+  v += dpp_shift_zero<0x118>(v); // row_shr:8
+  v += dpp_move<0x142, 0xa>(0.0, v); // row_bcast:15 -> rows 1, 3
+  v += dpp_move<0x143, 0xc>(0.0, v); // row_bcast:31 -> rows 2, 3
+  return readlane_f64(v, 63);
+}
+// the same for the maximum of NON-NEGATIVE values (norms, counts, step lengths: zero is their identity)
+__device__ __forceinline__ double
+lane_max0(double v)
+{
+  v = fmax(v, dpp_shift_zero<0x111>(v));
+  v = fmax(v, dpp_shift_zero<0x112>(v));
+  v = fmax(v, dpp_shift_zero<0x114>(v));
+  v = fmax(v, dpp_shift_zero<0x118>(v));
+  v = fmax(v, dpp_move<0x142, 0xa>(0.0, v));
+  v = fmax(v, dpp_move<0x143, 0xc>(0.0, v));
+  return readlane_f64(v, 63);
+}
+#else
+__device__ __forceinline__ double
+lane_sum(double v)
+{
+  return wave_sum(v);
+}
+__device__ __forceinline__ double
+lane_max0(double v)
+{
+  return wave_max(v);
+}
+#endif
+
 // value of lane `src` (uniform) in every lane
 __device__ __forceinline__ double
 wave_bcast(double v, int src)
@@ -347,30 +397,27 @@ struct DiagSolver
   __device__ __forceinline__ void apply_active_set()
   {
     tic();
-    double n_add = 0, n_rm = 0;
+    // (counts on the scalar unit: a ballot and a population count per slot)
+    int changed = 0;
     if (hasc) {
       PQP_E(c)
       {
         const bool want = (fl[c] & 4) != 0, had = (fl[c] & 8) != 0;
-        n_add += (want && !had) ? 1.0 : 0.0;
-        n_rm += (!want && had) ? 1.0 : 0.0;
+        changed += __popcll(__ballot((want != had) ? 1 : 0));
       }
     }
-    n_add = wave_sum(n_add);
-    n_rm = wave_sum(n_rm);
-    const int na = (int)n_add, nr = (int)n_rm;
-    if (na + nr == 0 && !schur_dirty) {
+    if (changed == 0 && !schur_dirty) {
       toc(ST_CYC_ZG);
       return;
     }
-    double tot = 0;
+    int tot = 0;
     PQP_E(c)
     {
       const bool want = (fl[c] & 4) != 0;
       fl[c] = (fl[c] & 7) | (want ? 8 : 0);
-      tot += want ? 1.0 : 0.0;
+      tot += __popcll(__ballot(want ? 1 : 0));
     }
-    n_c = (int)wave_sum(tot);
+    n_c = uni(tot);
     schur_dirty = true;
     toc(ST_CYC_ZG);
     if (n_c > 0) {
@@ -425,7 +472,7 @@ struct DiagSolver
       }
     }
     bytes(((long)n + (long)d.n_in) * 8);
-    return wave_max(m);
+    return lane_max0(m);
   }
 
   // reference solver.hpp:406-541 (Solver::iterative_solve): solve + refinement on the unfactorised operator
@@ -529,14 +576,14 @@ struct DiagSolver
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      sa[p] = wave_sum(sa[p]);
-      sb[p] = wave_sum(sb[p]);
+      sa[p] = lane_sum(sa[p]);
+      sb[p] = lane_sum(sb[p]);
       if (gpdal) {
         a_in[p] = info.mu_in_inv * sa[p] / st.alpha_gpdal;
         b_in[p] = info.mu_in_inv * sb[p] / st.alpha_gpdal;
       } else {
-        sa2[p] = wave_sum(sa2[p]);
-        sb2[p] = wave_sum(sb2[p]);
+        sa2[p] = lane_sum(sa2[p]);
+        sb2[p] = lane_sum(sb2[p]);
         a_in[p] = info.mu_in_inv * sa[p] + info.nu * info.mu_in_inv * sa2[p];
         b_in[p] = info.mu_in_inv * sb[p] + info.nu * info.mu_in_inv * sb2[p];
       }
@@ -600,7 +647,7 @@ struct DiagSolver
       for (int r = 0; r < NBP; ++r)
         if (take[r])
           aln = fmax(aln, mine[r]);
-      aln = wave_max(aln);
+      aln = lane_max0(aln);
       double a1[1] = { 2 * aln + 1 }, ai[1], bi[1];
       ls_terms<1>(a1, ai, bi);
       result = -(b0 + bi[0]) / (a0 + ai[0]);
@@ -618,7 +665,7 @@ struct DiagSolver
           aln = fmax(aln, mine[r]);
       }
     gfp = wave_max(gfp);
-    aln = wave_max(aln);
+    aln = lane_max0(aln);
     double gln = -INF;
 #pragma unroll
     for (int r = 0; r < NBP; ++r)
@@ -660,14 +707,14 @@ struct DiagSolver
       if (!gpdal)
         s_bmag = fma(double(info.nu) * (ar + fabs(z[c]) * info.mu_in), ac + fabs(dz[c]) * info.mu_in, s_bmag);
     }
-    dw_max = wave_max(dwm);
-    s_dxHdx = wave_sum(s_dxHdx);
-    s_dx2 = wave_sum(s_dx2);
-    s_xHdx = wave_sum(s_xHdx);
-    s_errdx = wave_sum(s_errdx);
-    s_dz2 = wave_sum(s_dz2);
-    s_dzz = wave_sum(s_dzz);
-    s_bmag = wave_sum(s_bmag);
+    dw_max = lane_max0(dwm);
+    s_dxHdx = lane_sum(s_dxHdx);
+    s_dx2 = lane_sum(s_dx2);
+    s_xHdx = lane_sum(s_xHdx);
+    s_errdx = lane_sum(s_errdx);
+    s_dz2 = lane_sum(s_dz2);
+    s_dzz = lane_sum(s_dzz);
+    s_bmag = lane_sum(s_bmag);
     const double nu = gpdal ? 1.0 : double(info.nu);
     double a0 = s_dxHdx + info.mu_eq_inv * 0.0 + info.rho * s_dx2 + 0.0 * info.mu_eq_inv * nu;
     double b0 = s_xHdx + s_errdx + info.mu_eq_inv * 0.0 + nu * info.mu_eq_inv * 0.0;
@@ -679,7 +726,8 @@ struct DiagSolver
     sub_tic(ST_CYC_LS_EVAL);
     // this lane's breakpoints (linesearch.hpp:378-391): two per constraint
     double mine[NBP];
-    double cnt = 0, amax = 0, amin_neg = -INF;
+    double amax = 0;
+    int cnti = 0;
     PQP_E(c)
     {
 #pragma unroll
@@ -691,16 +739,14 @@ struct DiagSolver
         }
         const bool ok = al > MACHINE_EPS;
         mine[2 * c + h] = ok ? al : -1.0;
+        cnti += __popcll(__ballot(ok ? 1 : 0));
         if (ok) {
-          cnt += 1.0;
           amax = fmax(amax, al);
-          amin_neg = fmax(amin_neg, -al);
         }
       }
     }
-    cnt = wave_sum(cnt);
-    amax = wave_max(amax);
-    amin_neg = wave_max(amin_neg);
+    const double cnt = (double)cnti;
+    amax = lane_max0(amax);
     double result = 0;
     if (cnt == 0.0) { // linesearch.hpp:405-419
       double a1[1] = { 0.0 }, ai[1], bi[1];
@@ -752,23 +798,27 @@ struct DiagSolver
           double ai[1], bi[1];
           ls_terms<1>(a1, ai, bi);
           const double g = (a0 + ai[0]) * pv + (b0 + bi[0]), mag = fabs((a0 + ai[0]) * pv) + fabs(b0) + bmag;
-          double cb = 0, below = 0;
+          // breakpoints in (lo, pv]: counted on the scalar unit (a ballot and a population count per slot) -- no vector
+          // accumulation, no wavefront reduction
+          int cbi = 0;
 #pragma unroll
-          for (int r = 0; r < NBP; ++r) {
-            if (mine[r] > lo && mine[r] <= pv)
-              cb += 1.0;
-            if (mine[r] < pv)
-              below = fmax(below, mine[r]);
-          }
+          for (int r = 0; r < NBP; ++r)
+            cbi += __popcll(__ballot((mine[r] > lo && mine[r] <= pv) ? 1 : 0));
+          const double cb = (double)cbi;
           if (g > SURE * mag) {
             hi = pv;
-            inside = wave_sum(cb);
+            inside = cb;
           } else if (g < -SURE * mag) {
             lo = pv;
-            inside -= wave_sum(cb);
+            inside -= cb;
           } else {
             // too close to the zero to trust the sign: the zero is at this breakpoint or right beside it
-            lo = wave_max(below);
+            double below = 0;
+#pragma unroll
+            for (int r = 0; r < NBP; ++r)
+              if (mine[r] < pv)
+                below = fmax(below, mine[r]);
+            lo = lane_max0(below);
             hi = pv;
             inside = 1.0;
             break;
@@ -789,7 +839,7 @@ struct DiagSolver
               if (mine[r] > hi)
                 above = fmax(above, -mine[r]);
             }
-          pred = wave_max(below);
+          pred = lane_max0(below);
           succ = -wave_max(above);
         }
 #pragma unroll
@@ -866,15 +916,15 @@ struct DiagSolver
         }
       }
     }
-    lb1 = wave_sum(lb1);
-    gdx = wave_sum(gdx);
-    nrm_dz = wave_max(nrm_dz);
-    lb2 = wave_max(lb2);
-    ndx = wave_max(ndx);
-    nhdx = wave_max(nhdx);
+    lb1 = lane_sum(lb1);
+    gdx = lane_sum(gdx);
+    nrm_dz = lane_max0(nrm_dz);
+    lb2 = lane_max0(lb2);
+    ndx = lane_max0(ndx);
+    nhdx = lane_max0(nhdx);
     mviol = wave_max(mviol);
-    e1 = wave_max(e1);
-    e3 = wave_max(e3);
+    e1 = lane_max0(e1);
+    e3 = lane_max0(e3);
     err_in = fmax(e1, fmax(0.0, e3));
     primal_infeasible = false;
     dual_infeasible = false;
@@ -913,7 +963,7 @@ struct DiagSolver
         alpha = primal_dual_ls(dw_max);
       } else {
         PQP_E(c) dw_max = fmax(dw_max, fabs(dx[c]));
-        dw_max = wave_max(dw_max);
+        dw_max = lane_max0(dw_max);
       }
       toc(ST_CYC_LINESEARCH);
       sub_tic(ST_CYC_UPDATE);
@@ -1017,9 +1067,9 @@ struct DiagSolver
     aty_fresh = true;
     bytes((long)d.n_in * 8);
     eq_rhs_0 = 0.0;
-    in_rhs_0 = wave_max(m_in0);
+    in_rhs_0 = lane_max0(m_in0);
     eq_lhs = 0.0;
-    in_lhs = wave_max(m_inl);
+    in_lhs = lane_max0(m_inl);
     lhs = fmax(eq_lhs, in_lhs);
     if (PQP_UNLIKELY(st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)) {
       // utils.hpp:241-248 : || A^T se + C^T si ||_inf on the unscaled model (C is diagonal here)
@@ -1028,7 +1078,7 @@ struct DiagSolver
         cgptr C = P.C();
         PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + C[(long)idx(k) * n + idx(k)] * si[k]));
       }
-      lhs = wave_max(m);
+      lhs = lane_max0(m);
     }
   }
 
@@ -1083,13 +1133,13 @@ struct DiagSolver
           zl += zi * lk;
       }
     }
-    gx = wave_sum(gx);
-    xHx = wave_sum(xHx);
-    zu = wave_sum(zu);
-    zl = wave_sum(zl);
-    m0 = wave_max(m0);
-    m3 = wave_max(m3);
-    ml = wave_max(ml);
+    gx = lane_sum(gx);
+    xHx = lane_sum(xHx);
+    zu = lane_sum(zu);
+    zl = lane_sum(zl);
+    m0 = lane_max0(m0);
+    m3 = lane_max0(m3);
+    ml = lane_max0(ml);
     rhs_0 = (hess() == PQP_HESSIAN_ZERO) ? 0.0 : m0;
     rhs_1 = 0.0;
     rhs_3 = m3;
@@ -1429,7 +1479,7 @@ struct DiagSolver
           } else if (boxf) {
             PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + 0.0 + zd[k]));
           }
-          scaled_eps = wave_max(m) * st.eps_abs;
+          scaled_eps = lane_max0(m) * st.eps_abs;
         }
         stage = 1;
         continue;
@@ -1524,7 +1574,7 @@ struct DiagSolver
       cgptr H = P.H();
       PQP_E(k) if (in(k)) obj += 0.5 * x[k] * x[k] * H[(long)idx(k) * n + idx(k)] + lv(LV_GU, k) * x[k];
       bytes((long)n * 8);
-      info.objValue = wave_sum(obj);
+      info.objValue = lane_sum(obj);
     }
     // write back
     vstore(P.x(), x);

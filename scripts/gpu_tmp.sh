@@ -1,4 +1,4 @@
 export TMPDIR=/tmp
-NS=build/variants/libproxqp_hip_nostage.so
-P=proxsuite_amd/csrc/libproxqp_hip.so
-for off in 0 1; do echo "PQP_STAGE_OFF=$off"; for B in 1 128; do PQP_STAGE_OFF=$off timeout 120 python scripts/gpu_time_shape.py $B 100 50 100 0 0 3 $NS $P 2>&1 | grep -v "amdgpu.ids\|bit-id"; done;  PQP_STAGE_OFF=$off timeout 120 python scripts/gpu_time_libs.py c1 3 $NS $P 2>&1 | grep -v amdgpu.ids; done
+python scripts/gpu_box_probe.py c2 c5 c5box 2>&1 | grep BOX
+for bx in 0 1; do timeout 300 python scripts/gpu_c5_check.py 200 1024 $bx 2>&1 | tail -1; done
+timeout 300 python scripts/diag_kernel_sweep.py 2 60 2>&1 | grep "MISMATCH\|sweep seed" | cut -c1-400

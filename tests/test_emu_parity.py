@@ -250,3 +250,14 @@ def test_line_search_bracket_is_bit_identical_to_the_full_evaluation(randqp):
         assert a[3] == f[3], (n, ne, ni, box, hess, merit, a[3], f[3])
         for u, v in zip(a[:3], f[:3]):
             assert np.array_equal(u, v), (n, ne, ni, box, hess, merit, float(np.max(np.abs(u - v))))
+
+
+def test_diag_kernel_settings_sweep(lib):
+    """the one-wavefront diagonal kernel against its 256-thread partner and the oracle over rarely-used settings (Martinez
+    rule, duality-gap criterion, relative tolerance, infeasibility-check frequency, closest-feasible solving on empty boxes,
+    iteration caps, no preconditioner, alpha_gpdal; both forms of the bounds, zero / diagonal Hessian; cold and dirty solves)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_kernel_sweep.py"), "1", "40"], capture_output=True, text=True,
+                       env=dict(os.environ, LIB=lib.path), timeout=1200)
+    assert "40 shapes, 0 mismatches" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

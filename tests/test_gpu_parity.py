@@ -274,3 +274,14 @@ def test_vectors_in_hbm_path(lib, oracle, randqp, monkeypatch):
     pc.case_random_batch(lib, oracle, randqp, 100, 50, 100, B=64)
     pc.case_random_batch(lib, oracle, randqp, 300, 40, 120, B=8)
     pc.case_box_constraints(lib, oracle, randqp, seeds=8)
+
+
+def test_diag_kernel_settings_sweep():
+    """tests/test_emu_parity.py::test_diag_kernel_settings_sweep on the MI355X, dimensions up to 200"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "LIB"}
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_kernel_sweep.py"), "2", "60"], capture_output=True, text=True,
+                       env=env, timeout=1200)
+    assert "60 shapes, 0 mismatches" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

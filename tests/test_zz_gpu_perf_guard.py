@@ -5,7 +5,7 @@ binary (8.05 ms on the builder's boxes, 8.87 ms on the driver's), an
 red, or stays green, because of the lease.  Each limit is therefore the time recorded on the REFERENCE box
 (profiles/perf_guard.json: kernel times + that box's pqp_box_calibrate figures) scaled by how much slower THIS box runs
 the fixed latency-chain kernel of the calibration or its dependent-FMA chain, whichever is further off (C4, which is
-bandwidth-bound on real traffic: the larger of that and the HBM read-rate ratio), plus the margin (7 %)."""
+bandwidth-bound on real traffic: the larger of that and the HBM read-rate ratio), plus the margin (12 %, profiles/perf_guard.json `margin_note`)."""
 import json
 import os
 
