@@ -1,4 +1,10 @@
 export TMPDIR=/tmp
-python scripts/gpu_box_probe.py c2 c5 c5box 2>&1 | grep BOX
-for bx in 0 1; do timeout 300 python scripts/gpu_c5_check.py 200 1024 $bx 2>&1 | tail -1; done
-timeout 300 python scripts/diag_kernel_sweep.py 2 60 2>&1 | grep "MISMATCH\|sweep seed" | cut -c1-400
+mkdir -p gpurun_out/r5e
+python scripts/gpu_box_probe.py c2 c5 c5box c1 2>&1 | grep BOX
+timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -6
+for w in c5 c5box; do timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --stats > gpurun_out/r5e/bench_$w.log 2>&1; tail -1 gpurun_out/r5e/bench_$w.log > gpurun_out/r5e/bench_$w.json; done
+python - <<'PY'
+import json
+for w in ("c5","c5box"):
+    d=json.loads(open("gpurun_out/r5e/bench_%s.json"%w).read()); print(w, round(d["value"]), "norm", round(d["value_normalised"]), "ms %.3f kernel %.3f"%(d["ms_per_step"], d["roofline"]["kernel_ms"]), "unsolved", d["unsolved"], "delta", d["max_abs_delta_vs_cpu"])
+PY
