@@ -84,8 +84,13 @@ for_shards(pqp_multi* m, F&& work)
       msg[k] = pqp_last_error();
   };
   std::vector<std::thread> helpers;
-  for (size_t k = 1; k < live.size(); ++k)
-    helpers.emplace_back(run, k);
+  for (size_t k = 1; k < live.size(); ++k) {
+    try {
+      helpers.emplace_back(run, k);
+    } catch (...) { // (no thread to be had: this shard is set up on the caller's thread -- nothing crosses the C boundary)
+      run(k);
+    }
+  }
   run(0);
   for (std::thread& t : helpers)
     t.join();
