@@ -236,9 +236,14 @@ def kernel_sources_sha(diag: bool = False) -> str:
     profiles/pmc_traffic.json was measured on (scripts/merge_pmc_traffic.py stamps it, bench.py compares)"""
     import hashlib
     files = ["pqp_solver.hpp", "pqp_block.hpp"] + (["pqp_diag.hpp"] if diag else [])
+    import re
     h = hashlib.sha256()
     for f in files:
-        h.update((CSRC / f).read_bytes())
+        # the CODE: comments and blank lines do not make a measurement stale
+        text = (CSRC / f).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        lines = [re.sub(r"//.*$", "", ln).rstrip() for ln in text.splitlines()]
+        h.update("\n".join(ln for ln in lines if ln.strip()).encode())
     return h.hexdigest()[:16]
 
 

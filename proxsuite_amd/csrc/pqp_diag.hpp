@@ -11,12 +11,15 @@
 //   * element k of every vector lives in lane k % 64, register slot k / 64 (E slots: dim <= 64 E); constraint k and
 //     variable k share a lane, so the KKT solve, the residuals, the active-set bookkeeping and the iterate update
 //     never leave the lane;
-//   * reductions are the DPP wavefront reductions of pqp_block.hpp -- no LDS round trip, no barrier anywhere in the
-//     kernel (a workgroup IS one wavefront);
-//   * the exact line search (reference linesearch.hpp:320-538) brackets the zero of phi' as the workgroup kernel does
-//     (ls_bracket), and evaluates phi' at the few breakpoints around it with every lane summing its own constraints'
-//     terms + one wavefront reduction per sum, instead of one lane walking all constraints in a serial chain;
-//   * LDS: 2.3 KB per QP (slot lists for the persistent state) against 62.8 KB.
+//   * reductions are DPP wavefront reductions (pqp_block.hpp's scan without its identity moves) -- no LDS round trip, no
+//     barrier anywhere in the kernel (a workgroup IS one wavefront); counts are ballots + population counts on the scalar unit;
+//   * the exact line search (reference linesearch.hpp:320-538) brackets the zero of phi' by quickselect on the breakpoints
+//     themselves (a pivot of arbitrary rank a round, phi' there with every lane summing its own constraints' terms + one
+//     wavefront reduction per sum), evaluates the <= 8 breakpoints that remain the same way, and applies the reference's
+//     selections to them: no lane ever walks all constraints in a serial chain;
+//   * LDS: 19 KB per QP (the nine vectors that are read at most a few times per Newton step, the slot list of the persistent
+//     state) against 62.8 KB: eight QPs per CU instead of two.
+// Bound by vector-ALU issue (61 k instructions per QP, 0.58 of the peak: profiles/r05_pmc_c5.json), not by memory or latency.
 // Same algorithm, same decisions, same HBM state as the workgroup kernels (a QP may be solved by either, in any order:
 // warm starts, the QPLayer backward and pqp_batch_get_schur_factor read what this kernel leaves).  Sums are taken in
 // a different order (lane-serial over the E slots, then the wavefront tree), so results agree with the other kernels

@@ -194,7 +194,8 @@ def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     pc.case_diag_wave_flows(lib, oracle, randqp, 200, box=True, hessian=pc.HessianType.Zero)
     pc.case_diag_wave_flows(lib, oracle, randqp, 120, box=False, constrained=False)
     forked = pc.case_diag_wave_flows(lib, oracle, randqp, 150, box=True, merit=1, B=8) + pc.case_diag_wave_flows(lib, oracle, randqp, 150, box=False, merit=1, B=8)
-    print("PDAL flows on the diagonal kernel (%s): %d forked results of %d" % (kernel, forked, 2 * 8 * 8))
+    import warnings
+    warnings.warn(UserWarning("PDAL flows on the diagonal kernel (%s): %d forked results of %d" % (kernel, forked, 2 * 8 * 8)))
     assert forked <= 13, forked
     assert pc.case_diag_wave_infeasible(lib, oracle) != int(pc.QPSolverOutput.PROXQP_SOLVED)
 

@@ -14,8 +14,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_random_sweep(oracle, randqp, seed):
+    import warnings
     r = pc.case_random_sweep(N.load(), oracle, randqp, seed, 60)
     print("sweep seed", seed, r)
+    # (in the warnings summary, i.e. in the tail of a quiet run: the parity residue stays visible -- VERDICT r4 item 7)
+    warnings.warn(UserWarning("random sweep seed %d: PDAL paths forked on %d of %d QPs (full gate on the others); %d solved with the "
+                              "oracle's Info, %d infeasible alike, %d status forks among the unsolved"
+                              % (seed, r["pdal_forked"], r["pdal_same_path"] + r["pdal_forked"], r["solved"], r["unsolved_alike"], r["forks"])))
     assert r["failures"] == 0, r
     assert r["info_mismatch"] == 0, r
     assert r["solved"] >= 150, r
