@@ -1,9 +1,7 @@
 export TMPDIR=/tmp
-A=build/variants/libproxqp_hip_base.so
-P=proxsuite_amd/csrc/libproxqp_hip.so
-python scripts/gpu_box_probe.py c2 2>&1 | grep BOX
-timeout 200 python scripts/gpu_time_libs.py c2 4 $A $P 2>&1 | grep -v amdgpu.ids
-timeout 100 python scripts/gpu_bitcompare.py c2 $A $P 2>&1 | grep -v amdgpu.ids | tail -1
-timeout 100 python scripts/gpu_time_libs.py c1 4 $A $P 2>&1 | grep -v amdgpu.ids
-timeout 300 python scripts/gpu_time_libs.py c4 2 $A $P 2>&1 | grep -v amdgpu.ids
-timeout 100 python scripts/gpu_bitcompare.py c4 $A $P 2>&1 | grep -v amdgpu.ids | tail -1
+python scripts/gpu_box_probe.py c2 c5 c4 c1 2>&1 | grep BOX
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -4
+timeout 400 python bench.py 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench default:', round(d['value']), 'norm', round(d['value_normalised']), 'ms', round(d['ms_per_step'],3), 'unsolved', d['unsolved'], 'stale', d['roofline'].get('traffic_stale'), 'gpu/cpu', d.get('gpu_over_cpu'))"

@@ -865,6 +865,34 @@ def case_diag_wave_flows(lib, oracle, randqp, dim, box, hessian=HessianType.Diag
     return forked[0]
 
 
+def case_diag_wave_backward(lib, oracle, randqp, dim=24, B=3):
+    """QPLayer backward (reference dense/compute_ECJ.hpp:29-189) on diagonal-structure QPs (C = I form): the backward
+    kernel reads the state the SOLVE kernel left in HBM -- solution, slot list, persistent active-set flags -- whichever
+    solve kernel that was.  The seven loss jacobians after a solve by the one-wavefront kernel against the oracle's."""
+    H, g, Cm, l, u = c5_models(randqp, B, dim, seed0=3)
+    b = N.Batch(B, dim, 0, dim, hessian_type=int(HessianType.Diagonal), lib=lib)
+    settings_all(b, eps_abs=EPS, eps_rel=0)
+    b.init(-1, H, g, None, None, Cm, l, u)
+    b.solve()
+    rng = np.random.default_rng(9)
+    ld = np.zeros((B, 2 * dim))
+    ld[:, :dim] = rng.standard_normal((B, dim))
+    ld[:, dim:] = 0.1 * rng.standard_normal((B, dim))
+    b.backward(ld, 1e-5, 1e-7, 1e-7)
+    got = b.backward_results(-1)
+    for i in range(B):
+        q = oracle.QP(dim, 0, dim, hessian_type=HessianType.Diagonal)
+        q.settings.eps_abs, q.settings.eps_rel = EPS, 0
+        q.init(H[i], g[i], None, None, Cm[i], l[i], u[i])
+        q.solve()
+        ref = q.compute_backward(ld[i], 1e-5, 1e-7, 1e-7)
+        for k, v in ref.items():
+            scale = 1 + (np.max(np.abs(v)) if v.size else 0.0)
+            assert np.max(np.abs(got[k][i] - v), initial=0.0) <= 1e-6 * scale, (i, k)
+    b.close()
+    return got
+
+
 def case_diag_wave_infeasible(lib, oracle):
     """the one-wavefront diagonal kernel on an unbounded problem -- a linear objective (zero Hessian) that decreases along a
     coordinate whose upper bound is infinite: the reference's certificate test never fires on it (both sides run into

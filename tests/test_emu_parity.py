@@ -157,6 +157,7 @@ def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     forked = pc.case_diag_wave_flows(lib, oracle, randqp, 36, box=True, merit=1) + pc.case_diag_wave_flows(lib, oracle, randqp, 36, box=False, merit=1)
     assert forked <= 6, forked
     assert pc.case_diag_wave_infeasible(lib, oracle) != int(pc.QPSolverOutput.PROXQP_SOLVED)
+    pc.case_diag_wave_backward(lib, oracle, randqp)
 
 
 def test_primal_ldlt_engine(lib, oracle, randqp):

@@ -198,6 +198,7 @@ def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     warnings.warn(UserWarning("PDAL flows on the diagonal kernel (%s): %d forked results of %d" % (kernel, forked, 2 * 8 * 8)))
     assert forked <= 13, forked
     assert pc.case_diag_wave_infeasible(lib, oracle) != int(pc.QPSolverOutput.PROXQP_SOLVED)
+    pc.case_diag_wave_backward(lib, oracle, randqp, dim=200, B=4)
 
 
 def test_infeasibility_statuses(lib, oracle):
