@@ -304,9 +304,9 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   // limit, dense/model.hpp:65-68; linalg/dense/factorize.hpp:360-370 switches to a blocked factorisation there).  What
   // bounds a batch here: the 16-bit constraint ids of the persistent slot list and the LDS of the set-up kernel
   // (2 (n + n_eq + n_c) doubles of Ruiz scaling).
-  if (need > pqp::MAX_ROWS || pqp::setup_lds_bytes(d, 1024) > 160 * 1024) {
+  if (need > PQP_MAX_ROWS || pqp::setup_lds_bytes(d, 1024) > 160 * 1024) {
     delete h;
-    return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq + n_in (+ n)) > " + std::to_string(pqp::MAX_ROWS) +
+    return fail(PQP_ERR_UNSUPPORTED, "max(n, n_eq + n_in (+ n)) > " + std::to_string(PQP_MAX_ROWS) +
                                        " (or n + n_eq + n_in (+ n) > ~10000) is not supported by this build");
   }
 #if PQP_CHUNK_ALL

@@ -20,6 +20,14 @@
 #include "proxqp_hip.h"
 #include "pqp_solver.hpp"
 
+// max(n, n_eq + n_c) a batch may have (pqp_batch_create).  The reference has no size limit (dense/model.hpp:65-68); here the
+// persistent slot list packs constraint ids into 16 bits (pqp::act_pack) and the set-up kernel keeps 2 (n + n_eq + n_c)
+// doubles of Ruiz scaling in LDS (n + n_eq + n_c below ~10 000); above 1024 rows the 1024-thread kernel walks its
+// one-thread-per-row stages in chunks and keeps its vectors in HBM when they outgrow the LDS.  Tested against the oracle
+// at 4500 and 7000 constraint rows (tests/test_*_parity.py::test_rows_above_4096).
+constexpr int PQP_MAX_ROWS = 8192;
+static_assert(PQP_MAX_ROWS + 1 < (1 << 16), "act[] packs constraint ids into 16 bits");
+
 // records `msg` for pqp_last_error() of the calling thread and returns `code`
 int pqp_fail(int code, const std::string& msg);
 #define fail pqp_fail

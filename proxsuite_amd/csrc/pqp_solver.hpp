@@ -86,7 +86,7 @@ incr_max(int r)
 #ifndef PQP_CHUNK_ALL
 #define PQP_CHUNK_ALL 0
 #endif
-constexpr int MAX_ROWS = 4096; // max(n, n_eq + n_c) a batch may have (pqp_batch_create)
+constexpr int MAX_ROWS = 4096; // (the row limit of round 4; a batch is created under PQP_MAX_ROWS of pqp_host.hpp: nothing on the device depends on either)
 // the persistent slot list packs (constraint id + 1) of a slot in bits 0-15 and the active_set_up / active_set_low
 // flags of constraint i in bits 16-17 of act[i] (solver, backward, pqp_batch_get_schur_factor)
 static_assert(MAX_ROWS + 1 < (1 << 16), "act[] packs constraint ids into 16 bits");

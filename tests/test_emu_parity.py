@@ -262,3 +262,12 @@ def test_diag_kernel_settings_sweep(lib):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_kernel_sweep.py"), "1", "40"], capture_output=True, text=True,
                        env=dict(os.environ, LIB=lib.path), timeout=1200)
     assert "40 shapes, 0 mismatches" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_rows_above_4096(lib, oracle, randqp):
+    """4500 constraint rows on six variables through the emulated 1024-thread kernel (chunked row stages, per-QP vectors on a
+    heap slice as in pqp_solve_hbm_kernel): the limit of a batch is PQP_MAX_ROWS = 8192 (csrc/pqp_host.hpp; round 4: 4096),
+    and beyond it the library says so"""
+    pc.case_random_batch(lib, oracle, randqp, 6, 0, 4500, B=1, compare="all", info_residuals=False)
+    with pytest.raises(N.NativeError):
+        N.Batch(1, 10, 0, 9000, lib=lib)
