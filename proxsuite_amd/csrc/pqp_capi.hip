@@ -1458,7 +1458,7 @@ pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes)
   if (threads)
     *threads = wave ? 64 : h->nt;
   if (lds_bytes)
-    *lds_bytes = wave ? int64_t(pqp::diag_lds_bytes(4)) : int64_t(h->lds_solve);
+    *lds_bytes = wave ? int64_t(pqp::diag_lds_bytes(pqp_diag_wave_slots(h->dev.d.n))) : int64_t(h->lds_solve);
   return PQP_OK;
 }
 

@@ -147,6 +147,7 @@ struct DeviceGuard
 // launchers (pqp_kernels.hip); each picks the instantiation for h->nt / the model signature
 int pqp_launch_setup(pqp_batch* h);
 int pqp_launch_solve(pqp_batch* h);
+int pqp_diag_wave_slots(int dim); // register slots per vector of that kernel for a dimension (1, 2 or 4)
 int pqp_diag_dispatch(const pqp_batch* h); // 1: the launch goes to the one-wavefront diagonal kernel (pqp_diag.hpp)
 int pqp_launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count);
 int pqp_launch_order(pqp_batch* h, long count);

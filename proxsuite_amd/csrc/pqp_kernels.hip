@@ -105,6 +105,7 @@ int pqp_launch_solve_256_s1_two(pqp_batch* h);
 int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_256_s2(pqp_batch* h);
 int pqp_launch_solve_diag_wave(pqp_batch* h);
+int pqp_diag_wave_slots(int dim);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
@@ -182,10 +183,10 @@ pqp_diag_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
   pqp::diag_solve_body<E>(batch, first + slot, (pqp::lptr)smem);
 }
 
-int
-pqp_launch_solve_diag_wave(pqp_batch* h)
+template<int E>
+static int
+launch_diag_wave(pqp_batch* h)
 {
-  constexpr int E = 4;
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
   const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
@@ -194,6 +195,27 @@ pqp_launch_solve_diag_wave(pqp_batch* h)
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
   return PQP_OK;
+}
+
+// register slots per vector by dimension: 1 (dim <= 64), 2 (<= 128), 4 (<= 256) -- a slot is a pass of every element-wise
+// loop over all 64 lanes, so a QP of dim 60 does a quarter of the vector instructions of one of dim 200
+int
+pqp_diag_wave_slots(int dim)
+{
+  return dim <= 64 ? 1 : (dim <= 128 ? 2 : 4);
+}
+
+int
+pqp_launch_solve_diag_wave(pqp_batch* h)
+{
+  switch (pqp_diag_wave_slots(h->dev.d.n)) {
+    case 1:
+      return launch_diag_wave<1>(h);
+    case 2:
+      return launch_diag_wave<2>(h);
+    default:
+      return launch_diag_wave<4>(h);
+  }
 }
 #endif
 #if PQP_TU_HAS(3)
