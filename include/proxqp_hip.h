@@ -135,6 +135,9 @@ int pqp_batch_enable_host_results(pqp_batch* h, int enable);
 int pqp_batch_host_results(pqp_batch* h, const double** x, const double** y, const double** z, const double** se,
                            const double** si, const pqp_info** info);
 int pqp_batch_host_results_fresh(pqp_batch* h, int64_t idx);
+/* the same over the QPs [first, first + count): a pool that is only partly filled never solves its free slots, and
+ * must not lose the mirror path for the ones it uses */
+int pqp_batch_host_results_fresh_range(pqp_batch* h, int64_t first, int64_t count);
 
 /* Copy construction / assignment of a QP (reference dense/wrapper.hpp: QP<T> is copyable and
  * BatchQP / std::vector<QP> rely on it): every per-QP device array, the settings and the

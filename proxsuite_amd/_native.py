@@ -61,7 +61,8 @@ class NativeLib:
                "pqp_multi_locate", "pqp_multi_settings", "pqp_multi_init", "pqp_multi_update", "pqp_multi_warm_start",
                "pqp_multi_cleanup", "pqp_multi_flush", "pqp_multi_solve", "pqp_multi_solve_range",
                "pqp_multi_solve_async", "pqp_multi_solve_range_async", "pqp_multi_wait", "pqp_multi_get_results",
-               "pqp_multi_gather_device", "pqp_multi_get_trace", "pqp_multi_last_solve_ms", "pqp_box_calibrate")
+               "pqp_multi_gather_device", "pqp_multi_get_trace", "pqp_multi_last_solve_ms", "pqp_box_calibrate",
+               "pqp_batch_host_results_fresh_range")
 
     def __init__(self, path, legacy=False):
         """legacy=True (A/B scripts only): an older build of the library that lacks the newer entries can still be
@@ -138,6 +139,7 @@ class NativeLib:
         L.pqp_multi_last_solve_ms.restype = C.c_double
         L.pqp_multi_get_trace.argtypes = [vp, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pqp_box_calibrate.argtypes = [C.c_int, _DP, C.c_int]
+        L.pqp_batch_host_results_fresh_range.argtypes = [vp, C.c_int64, C.c_int64]
         self.L = real
 
     def check(self, rc):
@@ -354,7 +356,10 @@ class Batch:
             info = np.zeros(0, dtype=np.dtype(pqp_info))
         return (*out, info)
 
-    def host_results_fresh(self, idx=-1):
+    def host_results_fresh(self, idx=-1, count=None):
+        """the pinned mirrors hold the device's results of QP idx (-1: every QP); `count`: of the QPs idx .. idx+count-1"""
+        if count is not None:
+            return bool(self.lib.L.pqp_batch_host_results_fresh_range(self._h, int(idx), int(count)))
         return bool(self.lib.L.pqp_batch_host_results_fresh(self._h, int(idx)))
 
     def backward(self, loss_derivatives, eps=1e-4, rho_backward=1e-6, mu_backward=1e-6, first=None, count=None):

@@ -1084,6 +1084,19 @@ pqp_batch_host_results_fresh(pqp_batch* h, int64_t idx)
 }
 
 int
+pqp_batch_host_results_fresh_range(pqp_batch* h, int64_t first, int64_t count)
+{
+  if (!h || !h->host_results || first < 0 || count < 0 || first + count > h->dev.B)
+    return 0;
+  if (settle(h))
+    return 0;
+  for (int64_t q = first; q < first + count; ++q)
+    if (!h->mirror_fresh[size_t(q)])
+      return 0;
+  return 1;
+}
+
+int
 pqp_batch_copy_qp(pqp_batch* dst, int64_t dst_idx, pqp_batch* src, int64_t src_idx)
 {
   if (!dst || !src)

@@ -176,9 +176,7 @@ class _Pool:
         """the pinned mirrors hold the results of every USED slot (a partially filled pool never solves its free slots)"""
         if not self._overlap:
             return False
-        if self.batch.host_results_fresh(-1):
-            return True
-        return 0 < self.used < self.capacity and all(self.batch.host_results_fresh(i) for i in range(self.used))
+        return self.used > 0 and self.batch.host_results_fresh(0, self.used)
 
     def fetch(self):
         if self._cache_epoch != self._epoch:
