@@ -46,8 +46,8 @@ def test_headline_kernel_budget():
     rec = _record()
     c2 = rec["pqp_solve_kernel<256,4,1>"]
     assert c2["VGPRs"] <= 128 and c2["Occupancy"] == 4  # four workgroups of four wavefronts per CU
-    # scratch of the 4096 resident wavefronts: 492 B/lane = 129 MB runs at 8.1 ms per C2 launch, 1072 B/lane = 281 MB at
-    # 27.6 ms with 60 GB of spill stores reaching HBM per launch (profiles/r05_ab_gj_two_pivots.txt)
+    # a loop that the unroller leaves rolled puts the register tile it indexes into scratch memory: 492 -> 1072 B/lane took
+    # a C2 launch from 8.1 to 27.6 ms, 60 GB of scratch stores reaching HBM (profiles/r05_ab_gj_two_pivots.txt)
     assert c2["ScratchSize"] <= 560, c2
     for k, v in rec.items():  # kernels that must not spill a single vector register
         if k in ("pqp_solve_kernel<256,1,1>", "pqp_solve_kernel<256,2,1>", "pqp_solve_kernel<256,2,2>", "pqp_solve_kernel<256,1,0>"):
