@@ -5,7 +5,10 @@
 #ifndef PROXSUITE_AMD_PROXQP_DENSE_MODEL_HPP
 #define PROXSUITE_AMD_PROXQP_DENSE_MODEL_HPP
 
+#include <cmath>
+#include <limits>
 #include <stdexcept>
+#include <string>
 
 #include "proxsuite/proxqp/dense/views.hpp"
 
@@ -72,13 +75,54 @@ struct Model
     }
   }
 
-  // reference model.hpp:126-145 (symmetry of H; sizes are fixed by construction here)
-  bool is_valid(bool /*box_constraints*/ = false) const
+  // reference model.hpp:104-148: sizes, symmetry of H to machine precision (Eigen's isApprox: ||H - H^T||_F <= eps ||H||_F),
+  // C not identically zero when there are inequality rows; std::invalid_argument with the reference's messages
+  bool is_valid(bool box_constraints = false) const
   {
-    for (isize i = 0; i < dim; ++i)
-      for (isize j = 0; j < i; ++j)
-        if (std::fabs(H(i, j) - H(j, i)) > T(1e-12) * (T(1) + std::fabs(H(i, j))))
-          return false;
+    auto size_is = [](isize got, isize want, const char* what) {
+      if (got != want)
+        throw std::invalid_argument(std::string("wrong argument size: expected ") + std::to_string(want) + ", got " +
+                                    std::to_string(got) + "\n" + what);
+    };
+    size_is(g.size(), dim, "g has not the expected size.");
+    size_is(b.size(), n_eq, "b has not the expected size.");
+    size_is(l.size(), n_in, "l has not the expected size.");
+    size_is(u.size(), n_in, "u has not the expected size.");
+    if (box_constraints) {
+      size_is(u_box.size(), dim, "u_box has not the expected size");
+      size_is(l_box.size(), dim, "l_box has not the expected size");
+    }
+    if (H.rows() * H.cols() != 0) {
+      size_is(H.rows(), dim, "H has not the expected number of rows.");
+      size_is(H.cols(), dim, "H has not the expected number of cols.");
+      T diff2 = T(0), norm2 = T(0);
+      for (isize i = 0; i < dim; ++i)
+        for (isize j = 0; j < dim; ++j) {
+          const T e = H(i, j) - H(j, i);
+          diff2 += e * e;
+          norm2 += H(i, j) * H(i, j);
+        }
+      const T eps = std::numeric_limits<T>::epsilon();
+      if (diff2 > eps * eps * norm2)
+        throw std::invalid_argument("H is not symmetric.");
+    }
+    if (A.rows() * A.cols() != 0) {
+      size_is(A.rows(), n_eq, "A has not the expected number of rows.");
+      size_is(A.cols(), dim, "A has not the expected number of cols.");
+    }
+    if (C.rows() * C.cols() != 0) {
+      size_is(C.rows(), n_in, "C has not the expected number of rows.");
+      size_is(C.cols(), dim, "C has not the expected number of cols.");
+      bool zero = true;
+      for (isize i = 0; i < C.rows() && zero; ++i)
+        for (isize j = 0; j < C.cols(); ++j)
+          if (std::fabs(C(i, j)) > T(1e-12)) {
+            zero = false;
+            break;
+          }
+      if (zero)
+        throw std::invalid_argument("C is zero, while n_in != 0.");
+    }
     return true;
   }
 };

@@ -140,7 +140,34 @@ class Model:
             self.u_box = np.zeros(dim)
 
     def is_valid(self, box_constraints=False):
-        return bool(np.allclose(self.H, self.H.T))
+        """reference dense/model.hpp:104-148: sizes, symmetry of H to machine precision (Eigen's isApprox:
+        ||H - H^T||_F <= eps ||H||_F), C not identically zero when there are inequality rows; raises ValueError (the
+        binding's translation of std::invalid_argument) with the reference's messages, returns True otherwise"""
+        def size_is(got, want, what):
+            if got != want:
+                raise ValueError("wrong argument size: expected %d, got %d\n%s" % (want, got, what))
+        size_is(np.size(self.g), self.dim, "g has not the expected size.")
+        size_is(np.size(self.b), self.n_eq, "b has not the expected size.")
+        size_is(np.size(self.l), self.n_in, "l has not the expected size.")
+        size_is(np.size(self.u), self.n_in, "u has not the expected size.")
+        if box_constraints:
+            size_is(np.size(getattr(self, "u_box", ())), self.dim, "u_box has not the expected size")
+            size_is(np.size(getattr(self, "l_box", ())), self.dim, "l_box has not the expected size")
+        H, A, C = (np.atleast_2d(np.asarray(m, dtype=np.float64)) for m in (self.H, self.A, self.C))
+        if H.size:
+            size_is(H.shape[0], self.dim, "H has not the expected number of rows.")
+            size_is(H.shape[1], self.dim, "H has not the expected number of cols.")
+            if np.sum((H - H.T) ** 2) > np.finfo(np.float64).eps ** 2 * np.sum(H ** 2):
+                raise ValueError("H is not symmetric.")
+        if A.size:
+            size_is(A.shape[0], self.n_eq, "A has not the expected number of rows.")
+            size_is(A.shape[1], self.dim, "A has not the expected number of cols.")
+        if C.size:
+            size_is(C.shape[0], self.n_in, "C has not the expected number of rows.")
+            size_is(C.shape[1], self.dim, "C has not the expected number of cols.")
+            if np.all(np.abs(C) <= 1e-12):
+                raise ValueError("C is zero, while n_in != 0.")
+        return True
 
 
 class _Pool:

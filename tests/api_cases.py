@@ -82,6 +82,26 @@ def case_errors(dense):
                 l_box=np.zeros(4), u_box=np.ones(4))
     with pytest.raises(AttributeError):
         qp.settings.no_such_field = 1
+    # reference test/src/dense_qp_wrapper.cpp:7569-7591 "check that model.is_valid function for symmetric matrices works
+    # for epsilon precision": H symmetric up to one ulp in one entry initialises and is a valid model (model.hpp:121-132)
+    rng = np.random.default_rng(5)
+    M = rng.uniform(-1, 1, (3, 3))
+    S = M + M.T
+    S[0, 1] = S[1, 0] + np.finfo(np.float64).eps
+    assert not np.array_equal(S, S.T)
+    q3 = dense.QP(3, 0, 0)
+    q3.init(S, None, None, None, None, None, None)
+    assert q3.model.is_valid(False) is True
+    q3.model.H = S + np.triu(np.ones((3, 3)), 1)
+    with pytest.raises(ValueError, match="H is not symmetric"):
+        q3.model.is_valid(False)
+    q3.model.H = S
+    q3.model.g = np.zeros(4)
+    with pytest.raises(ValueError, match="g has not the expected size"):
+        q3.model.is_valid(False)
+    q5 = dense.QP(3, 0, 2)
+    with pytest.raises(ValueError, match="C is zero, while n_in != 0"):  # (model.hpp:144-145; a fresh model holds zeros)
+        q5.model.is_valid(False)
 
 
 def case_box(dense, oracle, randqp):

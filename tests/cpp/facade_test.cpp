@@ -245,6 +245,37 @@ main(int argc, char** argv)
     CHECK(threw);
   }
 
+  // --- reference test/src/dense_qp_wrapper.cpp:7569-7591: a Hessian symmetric up to one ulp in one entry is a valid
+  //     model (model.hpp:121-132: isApprox to machine precision), a plainly asymmetric one is std::invalid_argument
+  {
+    dense::Mat<T> S(3, 3);
+    const T vals[3][3] = { { 0.4, -0.7, 0.2 }, { -0.7, 1.1, 0.5 }, { 0.2, 0.5, -0.3 } };
+    for (isize i = 0; i < 3; ++i)
+      for (isize j = 0; j < 3; ++j)
+        S(i, j) = vals[i][j];
+    S(0, 1) = S(1, 0) + std::numeric_limits<T>::epsilon();
+    CHECK(S(0, 1) != S(1, 0));
+    dense::QP<T> qp(3, 0, 0);
+    qp.init(S, nullopt, nullopt, nullopt, nullopt, nullopt, nullopt);
+    CHECK(qp.model.is_valid(false));
+    qp.model.H(0, 2) += 1.0;
+    bool threw = false;
+    try {
+      qp.model.is_valid(false);
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    CHECK(threw);
+    dense::QP<T> q5(3, 0, 2);
+    threw = false;
+    try {
+      q5.model.is_valid(false); // C is zero, while n_in != 0 (model.hpp:144-145)
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
   // --- strided (column-major) input is repacked: H^T of a symmetric H is H
   {
     const auto& m = models[3];
