@@ -604,8 +604,10 @@ struct DiagSolver
 
   // The breakpoints flagged in `take` evaluated exactly, then the selections of linesearch.hpp:427-536.  `pred`: the
   // largest breakpoint at or below the bracket (0: none).  false: the caller must evaluate every breakpoint.
+  // `succ`: the first breakpoint above the bracket (INF: none) -- evaluated only when no breakpoint of `take` has phi' >= 0.
   __device__ __forceinline__ bool ls_select(const double (&mine)[NBP], const bool (&take)[NBP], double a0, double b0, double pred,
-                                            bool all_negative, double amax, bool everything, double& result)
+                                            bool all_negative, double amax, bool everything, double& result,
+                                            double succ = __builtin_inf())
   {
     const double INF = __builtin_inf();
     double gr[NBP];
@@ -633,6 +635,13 @@ struct DiagSolver
       if (take[r] && !(gr[r] < 0) && mine[r] < afp)
         afp = mine[r];
     afp = wave_min(afp);
+    double g_succ = -INF;
+    if (!all_negative && !(afp < INF) && succ < INF) {
+      g_succ = ls_grad(succ, a0, b0);
+      count(ST_N_LS_BREAKPOINTS, 1);
+      if (!(g_succ < 0))
+        afp = succ;
+    }
     if (all_negative) {
       if (afp < INF)
         return false; // the exact value at the largest breakpoint is not negative after all
@@ -668,6 +677,8 @@ struct DiagSolver
           aln = fmax(aln, mine[r]);
       }
     gfp = wave_max(gfp);
+    if (afp == succ && !(g_succ < 0))
+      gfp = fmax(gfp, g_succ);
     aln = lane_max0(aln);
     double gln = -INF;
 #pragma unroll
@@ -769,38 +780,52 @@ struct DiagSolver
       // geometric quarter-steps of the workgroup kernel cost three evaluations, a division and two square roots a round).
       // Nothing here is trusted: the exact evaluation of the few breakpoints that remain validates the bracket (ls_select).
       const double SURE = 3.6e-15 * (double)(d.nc + d.n + d.n_eq);
-      double lo = 0.0, hi = amax, inside = cnt;
+      double lo = 0.0, hi = INF, inside = cnt; // (hi = INF: no point with phi' > 0 seen yet)
       bool all_negative = false, give_up = false;
+      double newt = -1.0; // zero of the linear piece of phi' at the last probe: the semismooth Newton step on phi'
       {
-        const double al[2] = { 0.0, amax };
-        double ai[2], bi[2];
-        ls_terms<2>(al, ai, bi);
+        const double al[1] = { 0.0 };
+        double ai[1], bi[1];
+        ls_terms<1>(al, ai, bi);
         const double g0 = b0 + bi[0], mag0 = fabs(b0) + bmag;
-        const double gh = (a0 + ai[1]) * amax + (b0 + bi[1]), magh = fabs((a0 + ai[1]) * amax) + fabs(b0) + bmag;
+        if (a0 + ai[0] > 0.)
+          newt = -g0 / (a0 + ai[0]);
         if (!(g0 < -SURE * mag0))
-          give_up = true;
-        else if (gh < -SURE * magh)
-          all_negative = true; // no breakpoint with phi' >= 0: linesearch.hpp:496-526
-        else if (!(gh > SURE * magh))
           give_up = true;
       }
       if (!give_up && !all_negative) {
-        for (int round = 0; round < 40 && inside > 6.0; ++round) {
-          double cand = -1.0;
+        bool newton_ok = true;
+        for (int round = 0; round < 40 && (inside > 6.0 || !(hi < INF)); ++round) {
+          // the probe: the Newton point when it lies strictly inside the bracket (phi' is piecewise linear: from a probe on
+          // the zero's own piece the step lands on the zero, and a handful of steps get there from anywhere) -- else, or
+          // when the last Newton probe kept more than half of the breakpoints, a breakpoint of middle rank
+          // While no point with phi' > 0 is known, a Newton point beyond the last breakpoint -- and the last probe of a
+          // bracket that has come down to a few breakpoints -- is the last breakpoint itself: phi' < 0 there is the case
+          // of linesearch.hpp:496-526 (the zero lies beyond every breakpoint).
+          double pv;
+          const bool by_newton = newton_ok && newt > lo && newt < hi;
+          if (!(hi < INF) && (!(inside > 6.0) || (by_newton && !(newt < amax)))) {
+            pv = amax;
+          } else if (by_newton) {
+            pv = newt;
+          } else {
+            double cand = -1.0;
 #pragma unroll
-          for (int r = NBP - 1; r >= 0; --r)
-            if (mine[r] > lo && mine[r] < hi)
-              cand = mine[r];
-          const unsigned long long m = __ballot(cand > 0 ? 1 : 0);
-          if (m == 0ull)
-            break; // (what is left are ties with hi)
-          const int rank = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (WAVE - lane))));
-          const unsigned long long pick = __ballot((cand > 0 && rank == (__popcll(m) >> 1)) ? 1 : 0);
-          const double pv = wave_bcast(cand, __ffsll((long long)pick) - 1);
+            for (int r = NBP - 1; r >= 0; --r)
+              if (mine[r] > lo && mine[r] < hi)
+                cand = mine[r];
+            const unsigned long long m = __ballot(cand > 0 ? 1 : 0);
+            if (m == 0ull)
+              break; // (what is left are ties with hi)
+            const int rank = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (WAVE - lane))));
+            const unsigned long long pick = __ballot((cand > 0 && rank == (__popcll(m) >> 1)) ? 1 : 0);
+            pv = wave_bcast(cand, __ffsll((long long)pick) - 1);
+          }
           const double a1[1] = { pv };
           double ai[1], bi[1];
           ls_terms<1>(a1, ai, bi);
-          const double g = (a0 + ai[0]) * pv + (b0 + bi[0]), mag = fabs((a0 + ai[0]) * pv) + fabs(b0) + bmag;
+          const double slope = a0 + ai[0];
+          const double g = slope * pv + (b0 + bi[0]), mag = fabs(slope * pv) + fabs(b0) + bmag;
           // breakpoints in (lo, pv]: counted on the scalar unit (a ballot and a population count per slot) -- no vector
           // accumulation, no wavefront reduction
           int cbi = 0;
@@ -808,6 +833,7 @@ struct DiagSolver
           for (int r = 0; r < NBP; ++r)
             cbi += __popcll(__ballot((mine[r] > lo && mine[r] <= pv) ? 1 : 0));
           const double cb = (double)cbi;
+          const double before = inside;
           if (g > SURE * mag) {
             hi = pv;
             inside = cb;
@@ -815,15 +841,25 @@ struct DiagSolver
             lo = pv;
             inside -= cb;
           } else {
-            // too close to the zero to trust the sign: the zero is at this breakpoint or right beside it
-            double below = 0;
+            // too close to the zero to trust the sign: the zero is at this point or right beside it -- between the
+            // breakpoint below it and the first one at or above it
+            double below = 0, above = -INF;
 #pragma unroll
-            for (int r = 0; r < NBP; ++r)
+            for (int r = 0; r < NBP; ++r) {
               if (mine[r] < pv)
                 below = fmax(below, mine[r]);
+              if (mine[r] >= pv)
+                above = fmax(above, -mine[r]);
+            }
             lo = lane_max0(below);
-            hi = pv;
+            hi = -wave_max(above);
             inside = 1.0;
+            break;
+          }
+          newt = slope > 0. ? -(b0 + bi[0]) / slope : -1.0;
+          newton_ok = !by_newton || inside <= 0.5 * before;
+          if (!(lo < amax)) {
+            all_negative = true;
             break;
           }
         }
@@ -848,9 +884,9 @@ struct DiagSolver
 #pragma unroll
         for (int r = 0; r < NBP; ++r) {
           const double a = mine[r];
-          take[r] = all_negative ? (a > 0 && a == amax) : (a > 0 && ((a > lo && a <= hi) || a == pred || a == succ));
+          take[r] = all_negative ? (a > 0 && a == amax) : (a > 0 && ((a > lo && a <= hi) || a == pred));
         }
-        done = ls_select(mine, take, a0, b0, pred, all_negative, amax, false, result);
+        done = ls_select(mine, take, a0, b0, pred, all_negative, amax, false, result, succ);
       }
     }
     if (!done) {
