@@ -52,3 +52,14 @@ def test_headline_kernel_budget():
     for k, v in rec.items():  # kernels that must not spill a single vector register
         if k in ("pqp_solve_kernel<256,1,1>", "pqp_solve_kernel<256,2,1>", "pqp_solve_kernel<256,2,2>", "pqp_solve_kernel<256,1,0>"):
             assert v["VGPRs_Spill"] == 0 and v["ScratchSize"] == 0, (k, v)
+
+
+def test_no_register_array_lives_in_scratch_memory():
+    """Scratch beyond what the spilled registers need means a private array that the compiler could not keep in registers
+    (a loop left rolled by the unroller's size limit indexes it dynamically): the two-pivot Gauss-Jordan experiment of round 5
+    had 464 B of it with NO spilled register, and the C2 launch went from 8.1 to 27.6 ms
+    (profiles/r05_ab_gj_two_pivots.txt).  Spill slots are 4 bytes per register and are shared, never more."""
+    rec = _record()
+    bad = {k: (v["ScratchSize"], v["VGPRs_Spill"]) for k, v in rec.items()
+           if k.startswith("pqp_") and v.get("ScratchSize", 0) > 4 * v.get("VGPRs_Spill", 0) + 16}
+    assert not bad, "kernels with private arrays in scratch memory (ScratchSize, VGPRs_Spill): %s" % bad
