@@ -47,6 +47,36 @@ diag_lds_bytes(int E)
 // lane exists (bound_ctrl) instead of keeping a pre-loaded identity; the two cross-row steps keep it.  (ds_swizzle for
 // the data movement -- a third of the vector instructions -- was measured: 0.81 -> 0.90 ms, the LDS crossbar's latency
 // costs more than the issue slots it frees, even where eight independent reductions run together: 0.84 ms.)
+// max(a, b) and max(a, |x|) of values in vector registers as ONE v_max_f64: fmax() canonicalises an operand the compiler
+// cannot prove quiet (a DPP move, a loaded value) with a v_max_f64 x, x, x of its own first -- 561 of the 999 v_max_f64 of
+// the E = 4 kernel were those.  Same results: the hardware instruction returns the other operand for a NaN, as fmax does.
+#ifndef PQP_EMULATED_MFMA
+__device__ __forceinline__ double
+vmax(double a, double b)
+{
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double
+vmax_abs(double a, double x)
+{
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(x));
+  return r;
+}
+#else
+__device__ __forceinline__ double
+vmax(double a, double b)
+{
+  return fmax(a, b);
+}
+__device__ __forceinline__ double
+vmax_abs(double a, double x)
+{
+  return fmax(a, fabs(x));
+}
+#endif
 #ifndef PQP_EMULATED_MFMA
 template<int CTRL>
 __device__ __forceinline__ double
@@ -71,12 +101,12 @@ lane_sum(double v)
 __device__ __forceinline__ double
 lane_max0(double v)
 {
-  v = fmax(v, dpp_shift_zero<0x111>(v));
-  v = fmax(v, dpp_shift_zero<0x112>(v));
-  v = fmax(v, dpp_shift_zero<0x114>(v));
-  v = fmax(v, dpp_shift_zero<0x118>(v));
-  v = fmax(v, dpp_move<0x142, 0xa>(0.0, v));
-  v = fmax(v, dpp_move<0x143, 0xc>(0.0, v));
+  v = vmax(v, dpp_shift_zero<0x111>(v));
+  v = vmax(v, dpp_shift_zero<0x112>(v));
+  v = vmax(v, dpp_shift_zero<0x114>(v));
+  v = vmax(v, dpp_shift_zero<0x118>(v));
+  v = vmax(v, dpp_move<0x142, 0xa>(0.0, v));
+  v = vmax(v, dpp_move<0x143, 0xc>(0.0, v));
   return readlane_f64(v, 63);
 }
 #else
@@ -467,11 +497,11 @@ struct DiagSolver
       }
       const double e = rhs_x(c, mode) - rho * dx[c] - Hdx[c] - CTdz[c];
       ex[c] = e;
-      m = fmax(m, fabs(e));
+      m = vmax_abs(m, e);
       if (active(c)) {
         const double e2 = rhs_d(c, mode) - (Cdx[c] - sd[c] * mu_in);
         ed[c] = e2;
-        m = fmax(m, fabs(e2));
+        m = vmax_abs(m, e2);
       }
     }
     bytes(((long)n + (long)d.n_in) * 8);
@@ -658,7 +688,7 @@ struct DiagSolver
 #pragma unroll
       for (int r = 0; r < NBP; ++r)
         if (take[r])
-          aln = fmax(aln, mine[r]);
+          aln = vmax(aln, mine[r]);
       aln = lane_max0(aln);
       double a1[1] = { 2 * aln + 1 }, ai[1], bi[1];
       ls_terms<1>(a1, ai, bi);
@@ -672,19 +702,19 @@ struct DiagSolver
     for (int r = 0; r < NBP; ++r)
       if (take[r]) {
         if (mine[r] == afp && !(gr[r] < 0))
-          gfp = fmax(gfp, gr[r]);
+          gfp = vmax(gfp, gr[r]);
         if (mine[r] < afp)
-          aln = fmax(aln, mine[r]);
+          aln = vmax(aln, mine[r]);
       }
     gfp = wave_max(gfp);
     if (afp == succ && !(g_succ < 0))
-      gfp = fmax(gfp, g_succ);
+      gfp = vmax(gfp, g_succ);
     aln = lane_max0(aln);
     double gln = -INF;
 #pragma unroll
     for (int r = 0; r < NBP; ++r)
       if (take[r] && mine[r] == aln)
-        gln = fmax(gln, gr[r]);
+        gln = vmax(gln, gr[r]);
     gln = wave_max(gln);
     if (aln == 0.0) { // no breakpoint before afp: linesearch.hpp:477-495
       if (pred > 0.0)
@@ -705,7 +735,7 @@ struct DiagSolver
     PQP_E(c)
     {
       const double dxk = dx[c];
-      dwm = fmax(dwm, fabs(dxk));
+      dwm = vmax_abs(dwm, dxk);
       s_dxHdx += dxk * Hdx[c];
       s_dx2 += dxk * dxk;
       s_xHdx += x[c] * Hdx[c];
@@ -713,7 +743,7 @@ struct DiagSolver
     }
     PQP_E(c)
     {
-      dwm = fmax(dwm, fabs(dz[c]));
+      dwm = vmax_abs(dwm, dz[c]);
       s_dz2 += dz[c] * dz[c];
       s_dzz += dz[c] * z[c];
       const double ac = fabs(Cdx[c]), ar = fabs(rup[c]) + fabs(si[c]);
@@ -755,7 +785,7 @@ struct DiagSolver
         mine[2 * c + h] = ok ? al : -1.0;
         cnti += __popcll(__ballot(ok ? 1 : 0));
         if (ok) {
-          amax = fmax(amax, al);
+          amax = vmax(amax, al);
         }
       }
     }
@@ -847,9 +877,9 @@ struct DiagSolver
 #pragma unroll
             for (int r = 0; r < NBP; ++r) {
               if (mine[r] < pv)
-                below = fmax(below, mine[r]);
+                below = vmax(below, mine[r]);
               if (mine[r] >= pv)
-                above = fmax(above, -mine[r]);
+                above = vmax(above, -mine[r]);
             }
             lo = lane_max0(below);
             hi = -wave_max(above);
@@ -874,9 +904,9 @@ struct DiagSolver
           for (int r = 0; r < NBP; ++r)
             if (mine[r] > 0) {
               if (mine[r] <= lo)
-                below = fmax(below, mine[r]);
+                below = vmax(below, mine[r]);
               if (mine[r] > hi)
-                above = fmax(above, -mine[r]);
+                above = vmax(above, -mine[r]);
             }
           pred = lane_max0(below);
           succ = -wave_max(above);
@@ -915,9 +945,9 @@ struct DiagSolver
         if (hasc && in(k)) {
           const double up = rup[k], lo = si[k];
           const double v = (up > 0 ? up : 0.0) + (lo < 0 ? lo : 0.0) - zf * z[k] * info.mu_in;
-          e1 = fmax(e1, fabs(v));
+          e1 = vmax_abs(e1, v);
         }
-        e3 = fmax(e3, fabs(dres[k]));
+        e3 = vmax_abs(e3, dres[k]);
       }
     }
     if (do_cert) {
@@ -931,12 +961,12 @@ struct DiagSolver
       {
         const double sc = sx[k] * c;
         CTdz[k] /= sc;
-        lb2 = fmax(lb2, fabs(0.0 + CTdz[k]));
+        lb2 = vmax_abs(lb2, 0.0 + CTdz[k]);
         Hdx[k] /= sc;
-        nhdx = fmax(nhdx, fabs(Hdx[k]));
+        nhdx = vmax_abs(nhdx, Hdx[k]);
         gdx += dx[k] * lv(LV_GS, k);
         dx[k] *= sx[k];
-        ndx = fmax(ndx, fabs(dx[k]));
+        ndx = vmax_abs(ndx, dx[k]);
       }
       if (hasc) {
         PQP_E(k) if (in(k))
@@ -946,12 +976,12 @@ struct DiagSolver
           lb1 += (v > 0 ? v : 0.0) * ubk;
           lb1 -= (v < 0 ? v : 0.0) * lbk;
           dz[k] = cform ? v * sc_[k] / c : sc_[k] * v / c;
-          nrm_dz = fmax(nrm_dz, fabs(dz[k]));
+          nrm_dz = vmax_abs(nrm_dz, dz[k]);
           Cdx[k] /= sc_[k];
           // utils.hpp:381-398: two-sided bound -> |w| <= bound; no upper bound -> -w <= bound; no lower -> w <= bound
           const double w = cform ? Cdx[k] : dx[k]; // (box form: the unscaled dx itself)
           const double val = (ubk <= 1.E20 && lbk >= -1.E20) ? fabs(w) : ((ubk > 1.E20) ? -w : w);
-          mviol = fmax(mviol, val);
+          mviol = vmax(mviol, val);
         }
       }
     }
@@ -1001,7 +1031,7 @@ struct DiagSolver
       if (hasc) {
         alpha = primal_dual_ls(dw_max);
       } else {
-        PQP_E(c) dw_max = fmax(dw_max, fabs(dx[c]));
+        PQP_E(c) dw_max = vmax_abs(dw_max, dx[c]);
         dw_max = lane_max0(dw_max);
       }
       toc(ST_CYC_LINESEARCH);
@@ -1076,11 +1106,11 @@ struct DiagSolver
         CTdz[k] = zd[k] * z[k];
         const double v = (zd[k] * x[k]) / dv[k]; // unscaled C x
         rup[k] = v;
-        m_in0 = fmax(m_in0, fabs(v));
+        m_in0 = vmax_abs(m_in0, v);
         const double pu = v - uv[k], pl = v - lwv[k];
         const double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
         si[k] = sv;
-        m_inl = fmax(m_inl, fabs(sv));
+        m_inl = vmax_abs(m_inl, sv);
       }
     } else {
       vzero(CTdz);
@@ -1098,9 +1128,9 @@ struct DiagSolver
         const double pu = v - uv[k], pl = v - lwv[k];
         const double sv = (pu > 0 ? pu : 0.0) + (pl < 0 ? pl : 0.0);
         si[k] = sv;
-        m_inl = fmax(m_inl, fabs(sv));
-        m_in0 = fmax(m_in0, fabs(x[k] - sv)); // utils.hpp:225-229 (as written)
-        m_in0 = fmax(m_in0, fabs(x[k]));      // utils.hpp:230-231
+        m_inl = vmax_abs(m_inl, sv);
+        m_in0 = vmax_abs(m_in0, x[k] - sv); // utils.hpp:225-229 (as written)
+        m_in0 = vmax_abs(m_in0, x[k]);      // utils.hpp:230-231
       }
     }
     aty_fresh = true;
@@ -1115,7 +1145,7 @@ struct DiagSolver
       double m = 0;
       if (cform) {
         cgptr C = P.C();
-        PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + C[(long)idx(k) * n + idx(k)] * si[k]));
+        PQP_E(k) if (in(k)) m = vmax_abs(m, 0.0 + C[(long)idx(k) * n + idx(k)] * si[k]);
       }
       lhs = lane_max0(m);
     }
@@ -1147,7 +1177,7 @@ struct DiagSolver
       const double hx = (hess() == PQP_HESSIAN_DIAGONAL) ? lv(LV_HD, k) * x[k] : 0.0;
       double ctz = cform ? (have_products ? CTdz[k] : zd[k] * z[k]) : 0.0;
       const double v = hx / sc; // unscaled H x (utils.hpp:469-471)
-      m0 = fmax(m0, fabs(v));
+      m0 = vmax_abs(m0, v);
       const double xu = x[k] * sx[k];
       xHx += v * xu;
       gx += gv[k] * xu;
@@ -1155,12 +1185,12 @@ struct DiagSolver
       if (boxf) {
         const double zb = z[k] * zd[k];
         ctz += zb;
-        m3k = fmax(m3k, fabs(zb / sc));
+        m3k = vmax_abs(m3k, zb / sc);
       }
-      m3 = fmax(m3, m3k);
+      m3 = vmax(m3, m3k);
       const double dr = lv(LV_GS, k) + hx + 0.0 + ctz;
       dres[k] = dr;
-      ml = fmax(ml, fabs(dr / sc));
+      ml = vmax_abs(ml, dr / sc);
       if (hasc) {
         // duality gap terms (utils.hpp:482-586)
         const double zi = cform ? z[k] * sc_[k] / c : sc_[k] * z[k] / c;
@@ -1514,9 +1544,9 @@ struct DiagSolver
           double m = 0;
           if (cform) {
             cgptr C = P.C();
-            PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + C[(long)idx(k) * n + idx(k)] * 1.0 + 0.0));
+            PQP_E(k) if (in(k)) m = vmax_abs(m, 0.0 + C[(long)idx(k) * n + idx(k)] * 1.0 + 0.0);
           } else if (boxf) {
-            PQP_E(k) if (in(k)) m = fmax(m, fabs(0.0 + 0.0 + zd[k]));
+            PQP_E(k) if (in(k)) m = vmax_abs(m, 0.0 + 0.0 + zd[k]);
           }
           scaled_eps = lane_max0(m) * st.eps_abs;
         }

@@ -14,6 +14,8 @@ WL="$@"; [ -z "$WL" ] && WL="c2 c1 c4 c5 c5box"
 for w in $WL; do
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
     p=$(echo $pass | cut -d' ' -f1)
+    # PMC_QUICK=1: the traffic passes and the issue / wait pass only (three of the six)
+    [ -n "$PMC_QUICK" ] && case $p in FETCH_SIZE|WRITE_SIZE|SQ_WAVE_CYCLES) ;; *) continue ;; esac
     rm -rf $R/gpurun_out/pmct_${w}_$p
     timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmct_${w}_$p -- python $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --mpc-steps 0 > $R/gpurun_out/pmct_${w}_$p.log 2>&1
   done
