@@ -52,7 +52,7 @@ def build_randqp(force: bool = False) -> Path:
 # pqp_kernels.hip is compiled once per kernel family (see its header): every solve kernel is
 # ~350 KB of inlined code and takes about a minute of hipcc time, so the objects are built in
 # parallel and linked into one shared library.
-KERNEL_TUS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 14, 15, 16)
+KERNEL_TUS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 14, 15, 16, 17, 18)
 OBJ_DIR = ROOT / "build" / "obj"
 
 
@@ -73,7 +73,7 @@ CODEGEN_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-ma
 # per translation unit (kernel family, csrc/pqp_kernels.hip): measured on the workload each one serves --
 # C2 +4.3 %, C1 +3.4 %, C4 +2 % with -disable-lsr; the structured / boxed 256-thread kernel (C5: -17 %) and the
 # 512-thread kernels (dense-backend shape: -7 %) keep loop strength reduction
-TU_FLAGS = {1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-mllvm", "-disable-lsr"], 13: ["-mllvm", "-disable-lsr"], 15: ["-mllvm", "-disable-lsr"]}
+TU_FLAGS = {18: ["-mllvm", "-disable-lsr"], 1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-mllvm", "-disable-lsr"], 13: ["-mllvm", "-disable-lsr"], 15: ["-mllvm", "-disable-lsr"]}
 
 
 def hip_flags(extra_flags=()):

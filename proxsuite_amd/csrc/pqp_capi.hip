@@ -1468,10 +1468,15 @@ pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes)
   if (!h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
   const bool wave = pqp_diag_dispatch(h) == 1; // (known once the set-up kernel has run: pqp_batch_flush)
+  // (dense QPs: the configuration of a whole-batch launch; a 256-thread factorisation prologue runs in front of the
+  // one-wavefront iteration kernel)
+  const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE && h->dev.d.backend != PQP_BACKEND_PRIMAL_LDLT;
+  const bool dwave = !wave && common && pqp_dense_wave_dispatch(h, long(h->dev.B)) == 1;
   if (threads)
-    *threads = wave ? 64 : h->nt;
+    *threads = (wave || dwave) ? 64 : h->nt;
   if (lds_bytes)
-    *lds_bytes = wave ? int64_t(pqp::diag_lds_bytes(pqp_diag_wave_slots(h->dev.d.n))) : int64_t(h->lds_solve);
+    *lds_bytes = wave ? int64_t(pqp::diag_lds_bytes(pqp_diag_wave_slots(h->dev.d.n)))
+                      : (dwave ? int64_t(pqp_dense_wave_lds_bytes()) : int64_t(h->lds_solve));
   return PQP_OK;
 }
 

@@ -149,6 +149,8 @@ int pqp_launch_setup(pqp_batch* h);
 int pqp_launch_solve(pqp_batch* h);
 int pqp_diag_wave_slots(int dim); // register slots per vector of that kernel for a dimension (1, 2 or 4)
 int pqp_diag_dispatch(const pqp_batch* h); // 1: the launch goes to the one-wavefront diagonal kernel (pqp_diag.hpp)
+int pqp_dense_wave_dispatch(const pqp_batch* h, long count); // 1: a launch of `count` QPs goes to the one-wavefront dense kernel (pqp_dwave.hpp)
+size_t pqp_dense_wave_lds_bytes();
 int pqp_launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count);
 int pqp_launch_order(pqp_batch* h, long count);
 int pqp_launch_pack(pqp_batch* h, long first, long count, double* out, hipStream_t stream);

@@ -39,12 +39,15 @@
 // (the one-wavefront diagonal kernel is not short of scalar registers: its per-QP pointers are ordinary values -- the
 // optimisation barriers that keep them from being hoisted in the workgroup kernels would pin them to SGPRs inside
 // lane-divergent code here)
-#if PQP_TU == 16
+#if PQP_TU == 16 || PQP_TU == 17
 #define PQP_OPAQUE_SCALAR(v)
 #define PQP_OPAQUE_VECTOR(v)
 #endif
+//  17  pqp_dwave_kernel<WPS>          the DENSE solver as one wavefront per QP (pqp_dwave.hpp): dense Hessian, no box, n, n_eq,
+//                                     n_in <= 128 -- the iteration of a solve; launches that fill the device
+//  18  pqp_prologue_kernel<256>       the factorisation prologue of those solves (Solver::prologue), 256 threads per QP
 #include "pqp_host.hpp"
-#include "pqp_diag.hpp"
+#include "pqp_dwave.hpp"
 
 #define PQP_TU_HAS(k) (PQP_TU == 0 || PQP_TU == (k))
 
@@ -106,6 +109,8 @@ int pqp_launch_solve_256_s0(pqp_batch* h);
 int pqp_launch_solve_256_s2(pqp_batch* h);
 int pqp_launch_solve_diag_wave(pqp_batch* h);
 int pqp_diag_wave_slots(int dim);
+int pqp_launch_dense_wave(pqp_batch* h);
+int pqp_launch_prologue(pqp_batch* h);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
@@ -216,6 +221,62 @@ pqp_launch_solve_diag_wave(pqp_batch* h)
     default:
       return launch_diag_wave<4>(h);
   }
+}
+#endif
+// One WAVEFRONT per QP for DENSE QPs (pqp_dwave.hpp) behind the 256-thread factorisation prologue: two launches on the
+// handle's stream, one pair of events around both.
+#if PQP_TU_HAS(18)
+template<int NT>
+__global__ __launch_bounds__(NT, 4) void
+pqp_prologue_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
+  pqp::Solver<NT, 1> S(batch, first + slot, (pqp::lptr)smem);
+  S.prologue();
+}
+
+int
+pqp_launch_prologue(pqp_batch* h)
+{
+  const size_t lds = (256 == h->nt) ? h->lds_solve : pqp::lds_bytes(h->dev.d, 256);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pqp_prologue_kernel<256>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
+  const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
+  hipLaunchKernelGGL((pqp_prologue_kernel<256>), dim3((unsigned)h->range_count), dim3(256), lds, h->stream, h->dev,
+                     h->range_first, order);
+  HIP_TRY(hipGetLastError());
+  return PQP_OK;
+}
+#endif
+#if PQP_TU_HAS(17)
+#ifndef PQP_WPS_DENSE_WAVE
+#define PQP_WPS_DENSE_WAVE 2
+#endif
+template<int WPS>
+__global__ __launch_bounds__(64, WPS) void
+pqp_dwave_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
+{
+  HIP_DYNAMIC_SHARED(double, smem)
+  const long slot = order ? (long)order[blockIdx.x] : (long)blockIdx.x;
+  pqp::dwave_solve_body(batch, first + slot, (pqp::lptr)smem);
+}
+
+int
+pqp_launch_dense_wave(pqp_batch* h)
+{
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  if (int rc = pqp_launch_prologue(h))
+    return rc;
+  const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
+  const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
+  hipLaunchKernelGGL((pqp_dwave_kernel<PQP_WPS_DENSE_WAVE>), dim3((unsigned)h->range_count), dim3(64), pqp::dwave_lds_bytes(),
+                     h->stream, h->dev, h->range_first, order);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  return PQP_OK;
 }
 #endif
 #if PQP_TU_HAS(3)
@@ -441,6 +502,28 @@ pqp_diag_dispatch(const pqp_batch* h)
   return (e && e[0] == 'w') || dd.n > 256 ? 2 : 1;
 }
 
+// 0: the workgroup kernels; 1: the one-wavefront dense kernel (pqp_dwave.hpp) behind the factorisation prologue.
+// PQP_DENSE_KERNEL=workgroup / wave forces either (the A/B partners of the tests; read per launch).  By default the
+// one-wavefront form takes the launches that fill the device (more workgroups than three per CU).
+size_t
+pqp_dense_wave_lds_bytes()
+{
+  return pqp::dwave_lds_bytes();
+}
+
+int
+pqp_dense_wave_dispatch(const pqp_batch* h, long count)
+{
+  if (h->nt != 256 || h->vec_scratch || !pqp::dwave_signature(h->dev.d))
+    return 0;
+  const char* e = std::getenv("PQP_DENSE_KERNEL");
+  if (e && e[0] == 'w' && e[1] == 'o') // "workgroup"
+    return 0;
+  if (e && e[0] == 'w' && e[1] == 'a') // "wave"
+    return 1;
+  return (count > 3L * h->n_cu) ? 1 : 0;
+}
+
 int
 pqp_launch_solve(pqp_batch* h)
 {
@@ -456,6 +539,8 @@ pqp_launch_solve(pqp_batch* h)
           return dg == 1 ? pqp_launch_solve_diag_wave(h) : pqp_launch_solve_256_s2(h);
         return (h->range_count <= (long)h->n_cu) ? pqp_launch_solve_256_s0_one(h) : pqp_launch_solve_256_s0(h);
       }
+      if (pqp_dense_wave_dispatch(h, h->range_count))
+        return pqp_launch_dense_wave(h);
       // more workgroups than three per CU can hold at once: the four-per-CU build; otherwise the
       // launch is latency-bound and the build with the larger register budget is faster per QP
       if (h->range_count > 3L * h->n_cu && 4 * h->lds_solve <= 160 * 1024)

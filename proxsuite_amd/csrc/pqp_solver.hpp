@@ -4667,6 +4667,60 @@ struct Solver
     }
   }
 
+  // ---- The factorisation prologue of solve() on its own (pqp_prologue_kernel): the re-applied equilibration of a
+  // dirty re-solve (solver.hpp:1192-1214) and setup_factorization (H_s + rho I = L D L^T, W = L^{-1}, Z, G) for the
+  // QPs whose solve will need them, decided exactly as solve() decides (same state, same settings; nothing of the
+  // state is written).  The one-wavefront dense kernel (pqp_dwave.hpp) runs behind it and starts from what it leaves
+  // in HBM (F, dF, WL, WU, Zr, Zc, G and the equilibrated vectors): the GEMM-shaped, once-per-solve part of a solve
+  // keeps its 256-thread form and its own register budget, the iteration gets a kernel of its own.
+  __device__ __forceinline__ void prologue()
+  {
+    const int ne = d.n_eq;
+    const State W = *P.state();
+    set_diag_mode(W);
+    info.load(*P.info());
+    ruiz_c = W.ruiz_c;
+#ifdef PQP_STATS
+    for (int k = threadIdx.x; k < ST_COUNT; k += NT)
+      L.stat()[k] = 0;
+    __syncthreads();
+#endif
+    const int ig = st.initial_guess;
+    const bool wswpr = (ig == PQP_WARM_START_WITH_PREVIOUS_RESULT);
+    const bool dirty = W.dirty != 0;
+    const bool do_rescale = dirty && !wswpr;
+    bool do_factor = true;
+    if (dirty && !wswpr)
+      cold_start(info, st); // (rho of the factorisation: results.cleanup / cold_start, solver.hpp:1125-1170)
+    if (wswpr && !((!dirty && W.refactorize) || !W.factor_valid))
+      do_factor = false;
+    if (do_rescale) {
+      tic();
+      lptr S = L.rd();
+      vload(S, P.delta(), d.ntot);
+      __syncthreads();
+      const bool rewrite_matrices = W.scaled_valid == 0;
+      write_scaled<NT>(batch, q, S, ruiz_c, false, dm(), rewrite_matrices);
+      if (rewrite_matrices)
+        bytes(((long)d.n * d.n * 2 + 3L * ne * d.n + 3L * d.n_in * d.n) * 8);
+      toc(ST_CYC_SCALE);
+    }
+    if (do_factor) {
+      tic();
+      factor_primal_block();
+      toc(ST_CYC_FACTOR_H);
+    }
+#ifdef PQP_STATS
+    // (the statistics of the prologue are handed to the iteration kernel through the QP's slot: it adds its own)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      PQP_GLOBAL long long* gs = P.stats();
+      for (int k = 0; k < ST_COUNT; ++k)
+        gs[k] = L.stat()[k];
+    }
+#endif
+  }
+
   // ---- QPLayer backward: dense::compute_backward + compute_backward_loss_ESG
   // (reference dense/compute_ECJ.hpp:29-132, :134-189), on the state a solve left behind.
   // Same steps as the reference: active sets of the solution on the unscaled model, factorisation

@@ -16,15 +16,14 @@ del _e
 
 
 def omp_get_max_threads() -> int:
-    """reference bindings/python/src/expose-all.cpp:26-28.  There is no OpenMP pool here: the
-    unit of parallelism is one workgroup per QP, so this reports the number of compute units
-    of HIP device 0 times the workgroups resident per CU (an upper bound on QPs in flight)."""
-    try:
-        import torch
-        if torch.cuda.is_available():
-            p = torch.cuda.get_device_properties(0)
-            return int(p.multi_processor_count) * 4
-    except Exception:  # (no torch: the count below)
-        pass
+    """reference bindings/python/src/expose-all.cpp:26-28: the size of the OpenMP pool `solve_in_parallel` may use.
+    There is no OpenMP pool here -- a batch is ONE kernel launch whatever `num_threads` says (one workgroup or one
+    wavefront per QP; `dense.BatchQP` / `pqp_batch_launch_config` report that configuration) -- so what callers do with
+    the number is size HOST thread pools and sweeps (benchmark/timings-parallel.py:96-99, :131: `range(1, n, 2)`,
+    `ThreadPoolExecutor(max_workers=n)` around `dense.solve_no_gil`): it is the number of host threads that can drive
+    the device at once, i.e. the CPUs this process may run on."""
     import os
-    return os.cpu_count() or 1  # (no device visible, e.g. the CPU emulator of the test-suite: callers only pass it back as num_threads)
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1

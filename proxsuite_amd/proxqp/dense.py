@@ -30,7 +30,7 @@ from .. import _native
 from .._ctypes_defs import (DenseBackend, EigenValueEstimateMethodOption, HessianType, InitialGuess,
                             MeritFunctionType, QPSolverOutput, pqp_info, pqp_settings)
 
-__all__ = ["QP", "BatchQP", "VectorQP", "VectorLossDerivatives", "solve_in_parallel", "solve",
+__all__ = ["QP", "BatchQP", "VectorQP", "VectorLossDerivatives", "solve_in_parallel", "solve", "solve_no_gil",
            "compute_backward", "solve_backward_in_parallel", "estimate_minimal_eigen_value_of_symmetric_matrix",
            "EigenValueEstimateMethodOption", "DenseBackend", "HessianType", "InitialGuess",
            "QPSolverOutput", "MeritFunctionType", "Settings", "Results", "Info", "Model", "BackwardData"]
@@ -615,6 +615,14 @@ def solve(*args, **kwargs):
             raise TypeError("solve() got multiple values for argument %r" % k)
         bound[k] = v
     return _solve_impl(**bound)
+
+
+def solve_no_gil(*args, **kwargs):
+    """`dense.solve_no_gil` of the reference binding (bindings/python/src/expose-solve.hpp:144, :206): the one-shot solve
+    "while releasing the Global Interpreter Lock" -- what benchmark/timings-parallel.py:102-137 hands to a
+    ThreadPoolExecutor.  Here every native call already goes through ctypes, which drops the GIL for the duration of
+    the call (set-up, launch, wait), so this IS `solve`: same overloads, same arguments, same Results."""
+    return solve(*args, **kwargs)
 
 
 def _solve_impl(H=None, g=None, A=None, b=None, C=None, l=None, u=None, x=None, y=None, z=None, eps_abs=None,

@@ -22,7 +22,7 @@ def build_variant(tag, defines):
     csrc = ROOT / "proxsuite_amd" / "csrc"
     out = HERE / ("libpqp_emu_%s.so" % tag)
     srcs = [csrc / "pqp_capi.hip", csrc / "pqp_multi.hip", csrc / "pqp_kernels.hip", csrc / "pqp_calib.hip", HERE / "hip_emu.cpp"]
-    deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", csrc / "pqp_host.hpp", csrc / "pqp_diag.hpp", HERE / "hip_emu.hpp", Path(__file__)]
+    deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", csrc / "pqp_host.hpp", csrc / "pqp_diag.hpp", csrc / "pqp_dwave.hpp", HERE / "hip_emu.hpp", Path(__file__)]
     if out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):
         return out
     cmd = ["g++", "-std=gnu++17", "-fPIC", "-shared", "-O2", "-pthread", "-fno-strict-aliasing", "-DPQP_STATS",
@@ -39,7 +39,7 @@ def build_variant(tag, defines):
 def build(force=False, debug=False):
     csrc = ROOT / "proxsuite_amd" / "csrc"
     srcs = [csrc / "pqp_capi.hip", csrc / "pqp_multi.hip", csrc / "pqp_kernels.hip", csrc / "pqp_calib.hip", HERE / "hip_emu.cpp"]
-    deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", csrc / "pqp_host.hpp", csrc / "pqp_diag.hpp", HERE / "hip_emu.hpp",
+    deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", csrc / "pqp_host.hpp", csrc / "pqp_diag.hpp", csrc / "pqp_dwave.hpp", HERE / "hip_emu.hpp",
                    HERE / "include" / "hip" / "hip_runtime.h", ROOT / "include" / "proxqp_hip.h",
                    ROOT / "include" / "pqp_types.h", Path(__file__)]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):

@@ -121,3 +121,30 @@ def test_examples_py(emulated):
         os.chdir(cwd)
         sys.path.remove(ex)
     assert bad == [] and ran >= 17, (ran, bad)
+
+
+def test_benchmark_timings_parallel_py(emulated):
+    """benchmark/timings-parallel.py of the reference -- BatchQP / VectorQP set-up, `solve_in_parallel` over thread
+    counts, `qp.solve()` serially, and `dense.solve_no_gil` serially and under a ThreadPoolExecutor (:102-137) -- run
+    from the reference tree with only its two workload constants made emulator-sized (`problem_specs`, `num_qps`: an AST
+    rewrite of those two assignments at load time; every call the script makes is the reference's)."""
+    import ast
+    path = os.path.join(os.path.dirname(os.path.dirname(REF)), "benchmark", "timings-parallel.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    seen = set()
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
+            if node.targets[0].id == "problem_specs":
+                node.value = ast.parse("[(10, 4, 4), (16, 6, 6)]", mode="eval").body
+                seen.add("problem_specs")
+            elif node.targets[0].id == "num_qps":
+                node.value = ast.Constant(6)
+                seen.add("num_qps")
+    assert seen == {"problem_specs", "num_qps"}
+    ast.fix_missing_locations(tree)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        exec(compile(tree, path, "exec"), {"__name__": "__main__"})
+    text = out.getvalue()
+    for key in ("setup_batch_of_qps", "solve_in_parallel_heuristics_threads", "qp_solve_serial", "solve_fun_serial", "solve_fun_parallel"):
+        assert key in text, (key, text[-400:])
