@@ -77,6 +77,46 @@ dw_load_pair(cgptr p)
 #endif
 }
 
+// Columns col, col + 1 (col even, per lane) of a matrix row whose used columns are [clo, chi): a BUFFER load through a
+// descriptor that ends at column chi -- elements at or beyond it come back as zeros without a memory access (raw buffer
+// range checking, per dword); LOW: lanes wholly left of clo are sent out of range as well (what they would read are the
+// stored zeros of a triangular factor).  No branch, no exec masking.
+template<bool LOW>
+__device__ __forceinline__ DPair
+dw_load_row(cgptr row, int col, int clo, int chi)
+{
+#ifndef PQP_EMULATED_MFMA
+  typedef unsigned pqp_u4 __attribute__((ext_vector_type(4)));
+  typedef double pqp_d2v __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, chi * 8, 0x00020000);
+  int off = col * 8;
+  if (LOW)
+    off = (col + 1 >= clo) ? off : 0x7ffffff0;
+  const pqp_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  const pqp_d2v t = __builtin_bit_cast(pqp_d2v, raw);
+  return DPair{ t.x, t.y };
+#else
+  DPair r{ 0.0, 0.0 };
+  if (!LOW || col + 1 >= clo) {
+    if (col < chi)
+      r.x = row[col];
+    if (col + 1 < chi)
+      r.y = row[col + 1];
+  }
+  return r;
+#endif
+}
+
+// nothing is scheduled across this point: the loads of a batch stay in front of their uses (the machine scheduler
+// otherwise interleaves them to save registers and five loads are in flight instead of sixteen)
+__device__ __forceinline__ void
+dw_sched_fence()
+{
+#ifndef PQP_EMULATED_MFMA
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // value of lane `src` (uniform) of an int in every lane
 __device__ __forceinline__ int
 wave_bcast_i(int v, int src)
@@ -274,15 +314,20 @@ struct DWave
   // -------------------------------------------------------------------------------------------------------------
   // LIST: row t is taken from a list -- rsel holds the list in pair layout (ints), the entry of item t reaches rowptr(t, sel)
   // through scalar registers like the coefficient.
-  template<bool COLS, bool ROWS, int NCB, bool LIST, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass_block(int kb, int t0, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
+  // Loads are BUFFER loads through a per-row descriptor whose extent is the row's used length: lanes beyond it get zeros
+  // without a memory access and without a branch (dw_load_row).  LOW: the row's first used column clo > 0 (an upper
+  // triangular factor): lanes wholly left of it are pushed out of the descriptor's range the same way.
+  // Items past the end of the pass are the last row again with a zero coefficient (cvec is zero beyond its length by
+  // convention and masked here all the same); their row sums are not written.
+  template<bool COLS, bool ROWS, int NCB, bool LIST, bool LOW, typename RowPtr, typename ColRange>
+  __device__ __forceinline__ void mat_pass_block(int kb, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
                                                  const int (&rsel)[2], const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
-    // items of coefficient block kb
-    const int lo_t = (t0 > 128 * kb) ? t0 : 128 * kb;
+    const int lo_t = 128 * kb;
     const int hi_t = (t1 < 128 * kb + 128) ? t1 : 128 * kb + 128;
     if (lo_t >= hi_t)
       return;
+    constexpr int DEPTH = (NCB == 1) ? 16 : 8; // rows whose loads are in flight together
     const int lr = lane & 15, lk = lane >> 4;
     double acc2[NCB][2]; // second accumulator set (odd items): two independent FMA chains per column
 #pragma unroll
@@ -290,34 +335,33 @@ struct DWave
       acc2[cb][0] = 0.0;
       acc2[cb][1] = 0.0;
     }
-    for (int g = (lo_t & ~15); g < hi_t; g += 16) {
+    for (int g = lo_t; g < hi_t; g += 16) {
       double p[16];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        DPair v[8][NCB];
-        double c[8];
+      for (int h0 = 0; h0 < 16; h0 += DEPTH) {
+        DPair v[DEPTH][NCB];
+        double c[DEPTH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = g + 8 * half + u;
-          const bool ok = (t >= lo_t) && (t < hi_t); // uniform
-          const int tc = ok ? t : lo_t;
-          const int sel = LIST ? wave_bcast_i(rsel[u & 1], (tc & 127) >> 1) : 0;
-          cgptr row = rowptr(tc, sel);
+        for (int u = 0; u < DEPTH; ++u) {
+          const int t = g + h0 + u;
+          const bool ok = t < hi_t; // uniform
+          // (an item past the end: the descriptor's extent is zero -- nothing is fetched, whatever the address)
+          const int sel = LIST ? wave_bcast_i(rsel[u & 1], (t & 127) >> 1) : 0;
+          cgptr row = rowptr(t, sel);
           int clo, chi;
-          colrange(tc, clo, chi);
+          colrange(t, clo, chi);
+          chi = ok ? chi : 0;
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            const int col = 128 * cb + 2 * lane;
-            const bool a = ok && (col + 1 >= clo) && (col < chi);
-            v[u][cb] = a ? dw_load_pair(row + col) : DPair{ 0.0, 0.0 };
-          }
+          for (int cb = 0; cb < NCB; ++cb)
+            v[u][cb] = dw_load_row<LOW>(row, 128 * cb + 2 * lane, clo, chi);
           if (COLS) {
-            const double cv = wave_bcast(cvec[u & 1], (tc & 127) >> 1);
+            const double cv = wave_bcast(cvec[u & 1], (t & 127) >> 1);
             c[u] = ok ? cv : 0.0;
           }
         }
+        dw_sched_fence(); // every load of the batch is issued before the first use of one
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DEPTH; ++u) {
           if (COLS) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -335,7 +379,7 @@ struct DWave
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
               pv = fma(v[u][cb].x, xop[cb][0], fma(v[u][cb].y, xop[cb][1], pv));
-            p[8 * half + u] = pv;
+            p[h0 + u] = pv;
           }
         }
       }
@@ -357,7 +401,7 @@ struct DWave
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int t = g + lk + 4 * k;
-            if (t >= lo_t && t < hi_t)
+            if (t < hi_t)
               rout[t] = T2[k];
           }
         }
@@ -373,39 +417,39 @@ struct DWave
   }
   // coefficient vector of up to 256 items (two register blocks)
   template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass2(int t0, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
+  __device__ __forceinline__ void mat_pass2(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
                                             const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
     const int nosel[2] = { 0, 0 };
     auto rp = [&](int t, int) -> cgptr { return rowptr(t); };
-    mat_pass_block<COLS, ROWS, NCB, false>(0, t0, t1, rp, colrange, cvec[0], nosel, xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, false, false>(0, t1, rp, colrange, cvec[0], nosel, xop, cacc, rout);
     if (t1 > 128)
-      mat_pass_block<COLS, ROWS, NCB, false>(1, t0, t1, rp, colrange, cvec[1], nosel, xop, cacc, rout);
+      mat_pass_block<COLS, ROWS, NCB, false, false>(1, t1, rp, colrange, cvec[1], nosel, xop, cacc, rout);
   }
   // the same over listed rows: rowptr(t, sel) with sel = rsel of item t
   template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass2_list(int t0, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
+  __device__ __forceinline__ void mat_pass2_list(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
                                                  const int (&rsel)[2][2], const double (&xop)[NCB][2], double (&cacc)[NCB][2],
                                                  lptr rout)
   {
-    mat_pass_block<COLS, ROWS, NCB, true>(0, t0, t1, rowptr, colrange, cvec[0], rsel[0], xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, true, false>(0, t1, rowptr, colrange, cvec[0], rsel[0], xop, cacc, rout);
     if (t1 > 128)
-      mat_pass_block<COLS, ROWS, NCB, true>(1, t0, t1, rowptr, colrange, cvec[1], rsel[1], xop, cacc, rout);
+      mat_pass_block<COLS, ROWS, NCB, true, false>(1, t1, rowptr, colrange, cvec[1], rsel[1], xop, cacc, rout);
   }
   // coefficient vector of up to 128 items
-  template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass1(int t0, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
+  template<bool COLS, bool ROWS, int NCB, bool LOW = false, typename RowPtr, typename ColRange>
+  __device__ __forceinline__ void mat_pass1(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
                                             const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
     const int nosel[2] = { 0, 0 };
     auto rp = [&](int t, int) -> cgptr { return rowptr(t); };
-    mat_pass_block<COLS, ROWS, NCB, false>(0, t0, t1, rp, colrange, cvec, nosel, xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, false, LOW>(0, t1, rp, colrange, cvec, nosel, xop, cacc, rout);
   }
   template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass1_list(int t0, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
+  __device__ __forceinline__ void mat_pass1_list(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
                                                  const int (&rsel)[2], const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
-    mat_pass_block<COLS, ROWS, NCB, true>(0, t0, t1, rowptr, colrange, cvec, rsel, xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, true, false>(0, t1, rowptr, colrange, cvec, rsel, xop, cacc, rout);
   }
 
   // out = H_s v (symmetric: rows as columns)
@@ -416,7 +460,7 @@ struct DWave
     double acc[1][2] = { { 0.0, 0.0 } };
     const double none[1][2] = { { 0.0, 0.0 } };
     mat_pass1<true, false, 1>(
-      0, nn, [&](int t) -> cgptr { return Hs + (long)t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, v, none, acc,
+      0, nn, [&](int t) -> cgptr { return Hs + (unsigned)(t * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, v, none, acc,
       scr);
     DW_S(s) out[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
   }
@@ -429,7 +473,7 @@ struct DWave
     double acc[1][2] = { { 0.0, 0.0 } };
     const double xop[1][2] = { { xv[0], xv[1] } };
     mat_pass1<COLS, ROWS, 1>(
-      0, R, [&](int t) -> cgptr { return M + (long)t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xop, acc, scr);
+      0, R, [&](int t) -> cgptr { return M + (unsigned)(t * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xop, acc, scr);
     if (COLS) {
       DW_S(s) colout[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
     }
@@ -470,6 +514,252 @@ struct DWave
     __syncthreads();
   }
 
+  // Full factorisation of the current slots for r <= 128, ONE pass: the blocked left-looking LDL^T of S = M_J + G_JJ on the
+  // matrix cores with the gather of S, the factorisation of the diagonal tile and the block row of W_S = L_S^{-1} fused
+  // into the panel step, and every load of a step issued together.  (ldlt_factor_mfma + tri_inverse_mfma_rows of
+  // pqp_block.hpp, which spread tiles over the wavefronts of a workgroup, leave a lone wavefront ~150 dependent memory
+  // round trips per factorisation: 25 % of this kernel's cycles at C2.)  Panel kb (16 slots), tiles in the MFMA result
+  // layout (register q of lane (lr, lk) = element [lk + 4 q][lr]):
+  //   U(kb, x) = S(kb, x) - sum_{p < kb} U(p, kb)^T D_p U(p, x)      x = kb .. : S gathered from the Gram cache into the
+  //                                                                  accumulators, the history read back from LS
+  //   diagonal tile -> LDS, one row per lane, LDL^T by scalar broadcasts; inv(L_kk) by the Neumann product (registers)
+  //   U(kb, x) <- D_k^{-1} inv(L_kk) U(kb, x), stored to LS          x > kb
+  //   W(kb, j) = -inv(L_kk) sum_{p = j}^{kb - 1} L(kb, p) W(p, j)    j < kb : L(kb, p) = U(p, kb)^T, W(p, j) read back from W_S
+  // Leaves W_S (lower, unit diagonal) in HBM, D_S in registers; LS holds the upper factor (scratch).
+  __device__ __forceinline__ void factor_schur_fused()
+  {
+    const int rr = r, ld = nd;
+    const int nbk = (rr + 15) >> 4; // <= 8
+    const int lr = lane & 15, lk = lane >> 4;
+    cgptr G = P.G();
+    gptr U = P.LS();
+    gptr Wg = P.WS();
+    lptr dSl = scr, tile = scr + 256, dinv = scr + 512;
+    const double mu_eq = info.mu_eq, mu_in = info.mu_in;
+    for (int kb = 0; kb < nbk; ++kb) {
+      const int k0 = kb * 16;
+      const int kcol = k0 + lr;
+      const int kcc = (kcol < rr) ? kcol : rr - 1;
+      pqp_d4 acc[8];
+      {
+        int rs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = k0 + lk + 4 * q;
+          rs[q] = sid[(row < rr) ? row : rr - 1];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int x = kb + c;
+          if (x < nbk) { // uniform
+            const int col = 16 * x + lr;
+            const int cs = sid[(col < rr) ? col : rr - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = k0 + lk + 4 * q;
+              const bool live = (rs[q] | cs) >= 0;
+              double v = G[(long)(live ? rs[q] : 0) * ld + (live ? cs : 0)];
+              if (row == col)
+                v = live ? v + ((row < ne) ? mu_eq : mu_in) : 1.0;
+              else
+                v = live ? v : 0.0;
+              acc[c][q] = (row < rr && col < rr) ? v : 0.0;
+            }
+          }
+        }
+      }
+      for (int p = 0; p < kb; ++p) {
+        const int p0 = 16 * p;
+        double ap[4], bp[8][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          ap[q] = U[(long)(p0 + 4 * q + lk) * ld + kcc];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) {
+          const int x = kb + c;
+          if (x < nbk) {
+            const int col = 16 * x + lr;
+            const int cc = (col < rr) ? col : rr - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              bp[c][q] = U[(long)(p0 + 4 * q + lk) * ld + cc];
+          }
+        }
+        double an[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          an[q] = -ap[q] * dSl[p0 + 4 * q + lk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[0] = mfma_f64_16x16x4(an[q], ap[q], acc[0]);
+#pragma unroll
+        for (int c = 1; c < 8; ++c) {
+          if (kb + c < nbk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[c] = mfma_f64_16x16x4(an[q], bp[c][q], acc[c]);
+          }
+        }
+      }
+      // ---- diagonal tile: one row per lane (lanes 0..15), pivot rows through scalar registers
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        tile[(lk + 4 * q) * 16 + lr] = acc[0][q];
+      __syncthreads();
+      TilePair Pm;
+      {
+        const int nb = (rr - k0 < 16) ? (rr - k0) : 16;
+        const int rw = lane & 15;
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const double v = tile[rw * 16 + c];
+          a[c] = (rw < nb && c < nb) ? v : ((rw == c) ? 1.0 : 0.0); // identity padding
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const double dc = lane_bcast(a[c], c);
+          const double l = a[c] / dc;
+#pragma unroll
+          for (int cp = c + 1; cp < 16; ++cp) {
+            const double mcp = lane_bcast(a[c], cp); // A[cp][c] before scaling
+            if (rw >= cp)
+              a[cp] = fma(-l, mcp, a[cp]);
+          }
+          if (rw > c)
+            a[c] = l;
+        }
+        __syncthreads();
+        if (lane < 16) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c)
+            tile[rw * 16 + c] = (c < rw) ? a[c] : 0.0; // strict lower N of L_kk
+          double dr = 1.0;
+#pragma unroll
+          for (int c = 0; c < 16; ++c)
+            if (c == rw)
+              dr = a[c];
+          dinv[rw] = 1.0 / dr;
+          if (rw < nb)
+            dSl[k0 + rw] = dr;
+        }
+        __syncthreads();
+        TilePair N;
+        bool dg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = lk + 4 * q, col = lr;
+          N.x[q] = (row > col) ? tile[row * 16 + col] : 0.0;
+          N.xt[q] = (row < col) ? tile[col * 16 + row] : 0.0;
+          dg[q] = (row == col);
+          Pm.x[q] = (dg[q] ? 1.0 : 0.0) - N.x[q];
+          Pm.xt[q] = (dg[q] ? 1.0 : 0.0) - N.xt[q];
+        }
+        TilePair Sq = tile_mul(N, N);
+#pragma unroll
+        for (int rep = 0; rep < 3; ++rep) {
+          TilePair T = Sq;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (dg[q]) {
+              T.x[q] += 1.0;
+              T.xt[q] += 1.0;
+            }
+          Pm = tile_mul(Pm, T);
+          if (rep < 2)
+            Sq = tile_mul(Sq, Sq);
+        }
+      }
+      const double dcol = dinv[lr];
+      // W(kb, kb) = inv(L_kk)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = lk + 4 * q, col = lr;
+        const int gr = k0 + row, gc = k0 + col;
+        if (gr < rr && gc < rr && row >= col)
+          Wg[(long)gr * ld + gc] = (row > col) ? Pm.x[q] : 1.0;
+      }
+      // ---- the panel to the right of the diagonal tile: U(kb, x) <- D_k^{-1} inv(L_kk) U(kb, x)
+#pragma unroll
+      for (int c = 1; c < 8; ++c) {
+        const int x = kb + c;
+        if (x < nbk) {
+          const int col = 16 * x + lr;
+          pqp_d4 res;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            res[q] = 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            res = mfma_f64_16x16x4(Pm.xt[q] * dcol, (col < rr) ? acc[c][q] : 0.0, res);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (col < rr)
+              U[(long)(k0 + lk + 4 * q) * ld + col] = res[q]; // (block kb is full: a block to its right exists)
+        }
+      }
+      // ---- block row kb of W = L^{-1}, left of the diagonal
+      if (kb > 0) {
+        pqp_d4 T[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            T[c][q] = 0.0;
+        for (int p = 0; p < kb; ++p) {
+          const int p0 = 16 * p;
+          double ap[4], wb[7][4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            ap[q] = U[(long)(p0 + 4 * q + lk) * ld + kcc]; // L[k0 + lr][p0 + 4 q + lk]
+#pragma unroll
+          for (int c = 0; c < 7; ++c) {
+            if (c <= p) { // W(p, j) exists for j <= p (uniform)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                wb[c][q] = Wg[(long)(p0 + 4 * q + lk) * ld + 16 * c + lr];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 7; ++c) {
+            if (c <= p) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                T[c] = mfma_f64_16x16x4(ap[q], wb[c][q], T[c]);
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          if (c < kb) {
+            pqp_d4 Wij;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              Wij[q] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              Wij = mfma_f64_16x16x4(Pm.xt[q], T[c][q], Wij); // inv(L_kk) * T
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = k0 + lk + 4 * q;
+              if (row < rr)
+                Wg[(long)row * ld + 16 * c + lr] = -Wij[q];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    DW_B(b) DW_S(s)
+    {
+      const int a = didx(b, s);
+      dS[b][s] = (a < rr) ? dSl[a] : 1.0;
+    }
+    __syncthreads();
+    bytes((long)rr * rr * 8 * 2);
+  }
+
   // full factorisation of the current slots (holes stay identity rows): blocked LDL^T + row-wise inverse on the matrix
   // cores (pqp_block.hpp, one wavefront); leaves W_S in HBM, D_S in registers
   __device__ __forceinline__ void factor_schur()
@@ -482,6 +772,15 @@ struct DWave
         sid[a] = slot_live(a) ? rowid[a] : -1;
     }
     __syncthreads();
+    if (rr <= 128) {
+      factor_schur_fused();
+      toc(ST_CYC_F_UPDATE);
+      schur_dirty = false;
+      schur_incremental = false;
+      count(ST_N_SCHUR_FACT);
+      count(ST_FLOPS_FACT, (long long)rr * rr * rr / 3);
+      return;
+    }
     lptr dSl = scr, top = scr + 256;
     schur_gather_blocked<WAVE>(P.G(), P.LS(), nd, rr, ne, info.mu_eq, info.mu_in, sid);
     toc(ST_CYC_F_LOAD);
@@ -510,7 +809,7 @@ struct DWave
     const int rr = r, ld = nd;
     cgptr W = P.WS();
     double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-    auto rowp = [&](int t) -> cgptr { return W + (long)t * ld; };
+    auto rowp = [&](int t) -> cgptr { return W + (unsigned)(t * ld); };
     auto tril = [&](int t, int& lo, int& hi) {
       lo = 0;
       hi = t + 1;
@@ -676,7 +975,7 @@ struct DWave
     double delta = scc;
     if (rr > 0) {
       double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-      auto rowp = [&](int t) -> cgptr { return W + (long)t * ld; };
+      auto rowp = [&](int t) -> cgptr { return W + (unsigned)(t * ld); };
       auto tril = [&](int t, int& lo, int& hi) {
         lo = 0;
         hi = t + 1;
@@ -841,8 +1140,8 @@ struct DWave
       // t = L^{-1} bx = sum_k bx_k W[:, k] (row k of WU, columns k .. n-1)
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
-      mat_pass1<true, false, 1>(
-        0, nn, [&](int k) -> cgptr { return WU + (long)k * nn; },
+      mat_pass1<true, false, 1, true>(
+        0, nn, [&](int k) -> cgptr { return WU + (unsigned)(k * nn); },
         [&](int k, int& lo, int& hi) {
           lo = k;
           hi = nn;
@@ -859,7 +1158,7 @@ struct DWave
       // s_a = z_a . (t / D) - bd_a over the slots (rows rowid[a] of Zr)
       int rid[2][2];
       DW_B(b) DW_S(s) rid[b][s] = rowid[didx(b, s)];
-      auto zrow = [&](int, int sel) -> cgptr { return Zr + (long)sel * nn; };
+      auto zrow = [&](int, int sel) -> cgptr { return Zr + (unsigned)(sel * nn); };
       auto full = [&](int, int& lo, int& hi) {
         lo = 0;
         hi = nn;
@@ -894,7 +1193,7 @@ struct DWave
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
       mat_pass1<true, false, 1>(
-        0, nn, [&](int j) -> cgptr { return WL + (long)j * nn; },
+        0, nn, [&](int j) -> cgptr { return WL + (unsigned)(j * nn); },
         [&](int j, int& lo, int& hi) {
           lo = 0;
           hi = j + 1;
@@ -1050,7 +1349,7 @@ struct DWave
         int rs[2];
         DW_S(s) rs[s] = (idx(s) < listed) ? sid[idx(s)] : 0;
         mat_pass1_list<true, false, 1>(
-          0, listed, [&](int, int sel) -> cgptr { return Cs + (long)sel * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, cl,
+          0, listed, [&](int, int sel) -> cgptr { return Cs + (unsigned)(sel * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, cl,
           rs, xn, acc, scr + 512);
         DW_S(s) CTzin[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
         __syncthreads();
@@ -1116,14 +1415,18 @@ struct DWave
 
   // ---- exact line search (reference linesearch.hpp:320-538), as in DiagSolver: every lane sums the terms of its own
   // constraints, one wavefront reduction per sum
-  template<int NP>
-  __device__ __forceinline__ void ls_terms(const double (&al)[NP], double (&a_in)[NP], double (&b_in)[NP])
+  // MAG: also the sum of the MAGNITUDES of the terms of the b-sum at that step length (they cancel; the a-sum is a sum of
+  // squares): what the sign of phi' is trusted against in the bracket.  (An alpha-independent bound, as in the workgroup
+  // kernels' ls_bracket, is useless with one-sided constraints: a bound of -1e20 puts 1e20 |C dx| into it although its
+  // term only enters the sum beyond a breakpoint of that size.)
+  template<int NP, bool MAG = false>
+  __device__ __forceinline__ void ls_terms(const double (&al)[NP], double (&a_in)[NP], double (&b_in)[NP], double* mag_in = nullptr)
   {
     const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
-    double sa[NP], sb[NP], sa2[NP], sb2[NP];
+    double sa[NP], sb[NP], sa2[NP], sb2[NP], sm[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-      sa[p] = sb[p] = sa2[p] = sb2[p] = 0.0;
+      sa[p] = sb[p] = sa2[p] = sb2[p] = sm[p] = 0.0;
     DW_S(c)
     {
       const double cdx = Cdx[c], up0 = rup[c], lo0 = si[c];
@@ -1136,10 +1439,14 @@ struct DWave
         const double apz = (up ? up0 : 0.0) + (lw ? lo0 : 0.0);
         sa[p] = fma(e, e, sa[p]);
         sb[p] = fma(apz, e, sb[p]);
+        if (MAG)
+          sm[p] = fma(fabs(apz), fabs(e), sm[p]);
         if (!gpdal) {
           const double e2 = e - dzi, apz2 = apz - zi;
           sa2[p] = fma(e2, e2, sa2[p]);
           sb2[p] = fma(e2, apz2, sb2[p]);
+          if (MAG)
+            sm[p] = fma(double(info.nu) * fabs(e2), fabs(apz2), sm[p]);
         }
       }
     }
@@ -1147,6 +1454,8 @@ struct DWave
     for (int p = 0; p < NP; ++p) {
       sa[p] = lane_sum(sa[p]);
       sb[p] = lane_sum(sb[p]);
+      if (MAG)
+        mag_in[p] = (gpdal ? info.mu_in_inv * lane_sum(sm[p]) / st.alpha_gpdal : info.mu_in_inv * lane_sum(sm[p]));
       if (gpdal) {
         a_in[p] = info.mu_in_inv * sa[p] / st.alpha_gpdal;
         b_in[p] = info.mu_in_inv * sb[p] / st.alpha_gpdal;
@@ -1265,7 +1574,7 @@ struct DWave
     const bool gpdal = st.merit_function_type == PQP_MERIT_GPDAL;
     const double INF = __builtin_inf();
     double s_dxHdx = 0, s_adx2 = 0, s_dx2 = 0, s_e2 = 0, s_xHdx = 0, s_errdx = 0, s_adxres = 0, s_eres = 0, s_dz2 = 0, s_dzz = 0,
-           s_bmag = 0, dwm = 0;
+           dwm = 0;
     DW_S(c)
     {
       const double dxk = dx[c];
@@ -1290,10 +1599,6 @@ struct DWave
       dwm = vmax_abs(dwm, dz[c]);
       s_dz2 += dz[c] * dz[c];
       s_dzz += dz[c] * z[c];
-      const double ac = fabs(Cdx[c]), ar = fabs(rup[c]) + fabs(si[c]);
-      s_bmag = fma(ar, ac, s_bmag);
-      if (!gpdal)
-        s_bmag = fma(double(info.nu) * (ar + fabs(z[c]) * info.mu_in), ac + fabs(dz[c]) * info.mu_in, s_bmag);
     }
     dw_max = lane_max0(dwm);
     s_dxHdx = lane_sum(s_dxHdx);
@@ -1308,7 +1613,6 @@ struct DWave
     }
     s_dz2 = lane_sum(s_dz2);
     s_dzz = lane_sum(s_dzz);
-    s_bmag = lane_sum(s_bmag);
     const double nu = gpdal ? 1.0 : double(info.nu);
     double a0 = s_dxHdx + info.mu_eq_inv * s_adx2 + info.rho * s_dx2 + s_e2 * info.mu_eq_inv * nu;
     double b0 = s_xHdx + s_errdx + info.mu_eq_inv * s_adxres + nu * info.mu_eq_inv * s_eres;
@@ -1316,7 +1620,6 @@ struct DWave
       a0 += info.mu_in * (1. - st.alpha_gpdal) * s_dz2;
       b0 += info.mu_in * (1. - st.alpha_gpdal) * s_dzz;
     }
-    const double bmag = gpdal ? info.mu_in_inv * s_bmag / st.alpha_gpdal : info.mu_in_inv * s_bmag;
     sub_tic(ST_CYC_LS_EVAL);
     double mine[NBP];
     double amax = 0;
@@ -1358,9 +1661,9 @@ struct DWave
       double newt = -1.0;
       {
         const double al[1] = { 0.0 };
-        double ai[1], bi[1];
-        ls_terms<1>(al, ai, bi);
-        const double g0 = b0 + bi[0], mag0 = fabs(b0) + bmag;
+        double ai[1], bi[1], mi[1];
+        ls_terms<1, true>(al, ai, bi, mi);
+        const double g0 = b0 + bi[0], mag0 = fabs(b0) + mi[0];
         if (a0 + ai[0] > 0.)
           newt = -g0 / (a0 + ai[0]);
         if (!(g0 < -SURE * mag0))
@@ -1389,10 +1692,10 @@ struct DWave
             pv = wave_bcast(cand, __ffsll((long long)pick) - 1);
           }
           const double a1[1] = { pv };
-          double ai[1], bi[1];
-          ls_terms<1>(a1, ai, bi);
+          double ai[1], bi[1], mi[1];
+          ls_terms<1, true>(a1, ai, bi, mi);
           const double slope = a0 + ai[0];
-          const double g = slope * pv + (b0 + bi[0]), mag = fabs(slope * pv) + fabs(b0) + bmag;
+          const double g = slope * pv + (b0 + bi[0]), mag = fabs(slope * pv) + fabs(b0) + mi[0];
           int cbi = 0;
 #pragma unroll
           for (int k = 0; k < NBP; ++k)
@@ -1650,7 +1953,7 @@ struct DWave
     double acc[1][2] = { { 0.0, 0.0 } };
     const double xn[1][2] = { { 0.0, 0.0 } };
     mat_pass1<true, false, 1>(
-      0, R, [&](int t) -> cgptr { return M + (long)t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xn, acc, scr);
+      0, R, [&](int t) -> cgptr { return M + (unsigned)(t * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xn, acc, scr);
     DW_S(s) out[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
   }
 

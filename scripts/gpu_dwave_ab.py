@@ -26,9 +26,10 @@ for i in range(B):
     s.eps_abs, s.eps_rel, s.initial_guess = 1e-9, 0.0, int(InitialGuess.NO_INITIAL_GUESS)
 b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
 res = {}
-times = {"workgroup": [], "wave": []}
+MODES = tuple(os.environ.get("PQP_AB_MODES", "workgroup,wave").split(","))
+times = {k: [] for k in MODES}
 for rep in range(reps):
-    for mode in ("workgroup", "wave"):
+    for mode in MODES:
         os.environ["PQP_DENSE_KERNEL"] = mode
         b.solve()
         times[mode].append(b.last_solve_ms)
@@ -38,6 +39,8 @@ for mode in times:
     t = times[mode]
     print("%-10s kernel ms: %s   best %.3f  median %.3f  -> %.1f k QPs/s" % (mode, " ".join("%.3f" % v for v in t), min(t),
           float(np.median(t)), B / float(np.median(t))), flush=True)
+if len(MODES) < 2:
+    sys.exit(0)
 xa, ya, za, _, _, ia = res["workgroup"]
 xb, yb, zb, _, _, ib = res["wave"]
 dx = float(np.max(np.abs(xa - xb)))
