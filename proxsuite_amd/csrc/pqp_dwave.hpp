@@ -83,20 +83,23 @@ dw_load_pair(cgptr p)
 // stored zeros of a triangular factor).  No branch, no exec masking.
 template<bool LOW>
 __device__ __forceinline__ DPair
-dw_load_row(cgptr row, int col, int clo, int chi)
+dw_load_row(cgptr base, int rowoff, int col, int clo, int chi)
 {
 #ifndef PQP_EMULATED_MFMA
+  // one descriptor base per pass (the matrix); the row travels in the scalar offset, which the range check includes
+  // (scripts/probe/buf_soffset.hip): extent = row offset + used length -- two scalar instructions per row
   typedef unsigned pqp_u4 __attribute__((ext_vector_type(4)));
   typedef double pqp_d2v __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, chi * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (rowoff + chi) * 8, 0x00020000);
   int off = col * 8;
   if (LOW)
     off = (col + 1 >= clo) ? off : 0x7ffffff0;
-  const pqp_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  const pqp_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, rowoff * 8, 0);
   const pqp_d2v t = __builtin_bit_cast(pqp_d2v, raw);
   return DPair{ t.x, t.y };
 #else
   DPair r{ 0.0, 0.0 };
+  cgptr row = base + rowoff;
   if (!LOW || col + 1 >= clo) {
     if (col < chi)
       r.x = row[col];
@@ -320,7 +323,7 @@ struct DWave
   // Items past the end of the pass are the last row again with a zero coefficient (cvec is zero beyond its length by
   // convention and masked here all the same); their row sums are not written.
   template<bool COLS, bool ROWS, int NCB, bool LIST, bool LOW, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass_block(int kb, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
+  __device__ __forceinline__ void mat_pass_block(cgptr base, int kb, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
                                                  const int (&rsel)[2], const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
     const int lo_t = 128 * kb;
@@ -347,13 +350,13 @@ struct DWave
           const bool ok = t < hi_t; // uniform
           // (an item past the end: the descriptor's extent is zero -- nothing is fetched, whatever the address)
           const int sel = LIST ? wave_bcast_i(rsel[u & 1], (t & 127) >> 1) : 0;
-          cgptr row = rowptr(t, sel);
+          const int ro = ok ? rowptr(t, sel) : 0;
           int clo, chi;
           colrange(t, clo, chi);
           chi = ok ? chi : 0;
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb)
-            v[u][cb] = dw_load_row<LOW>(row, 128 * cb + 2 * lane, clo, chi);
+            v[u][cb] = dw_load_row<LOW>(base, ro, 128 * cb + 2 * lane, clo, chi);
           if (COLS) {
             const double cv = wave_bcast(cvec[u & 1], (t & 127) >> 1);
             c[u] = ok ? cv : 0.0;
@@ -417,39 +420,39 @@ struct DWave
   }
   // coefficient vector of up to 256 items (two register blocks)
   template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass2(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
+  __device__ __forceinline__ void mat_pass2(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
                                             const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
     const int nosel[2] = { 0, 0 };
-    auto rp = [&](int t, int) -> cgptr { return rowptr(t); };
-    mat_pass_block<COLS, ROWS, NCB, false, false>(0, t1, rp, colrange, cvec[0], nosel, xop, cacc, rout);
+    auto rp = [&](int t, int) -> int { return rowptr(t); };
+    mat_pass_block<COLS, ROWS, NCB, false, false>(base, 0, t1, rp, colrange, cvec[0], nosel, xop, cacc, rout);
     if (t1 > 128)
-      mat_pass_block<COLS, ROWS, NCB, false, false>(1, t1, rp, colrange, cvec[1], nosel, xop, cacc, rout);
+      mat_pass_block<COLS, ROWS, NCB, false, false>(base, 1, t1, rp, colrange, cvec[1], nosel, xop, cacc, rout);
   }
   // the same over listed rows: rowptr(t, sel) with sel = rsel of item t
   template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass2_list(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
+  __device__ __forceinline__ void mat_pass2_list(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
                                                  const int (&rsel)[2][2], const double (&xop)[NCB][2], double (&cacc)[NCB][2],
                                                  lptr rout)
   {
-    mat_pass_block<COLS, ROWS, NCB, true, false>(0, t1, rowptr, colrange, cvec[0], rsel[0], xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, true, false>(base, 0, t1, rowptr, colrange, cvec[0], rsel[0], xop, cacc, rout);
     if (t1 > 128)
-      mat_pass_block<COLS, ROWS, NCB, true, false>(1, t1, rowptr, colrange, cvec[1], rsel[1], xop, cacc, rout);
+      mat_pass_block<COLS, ROWS, NCB, true, false>(base, 1, t1, rowptr, colrange, cvec[1], rsel[1], xop, cacc, rout);
   }
   // coefficient vector of up to 128 items
   template<bool COLS, bool ROWS, int NCB, bool LOW = false, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass1(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
+  __device__ __forceinline__ void mat_pass1(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
                                             const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
     const int nosel[2] = { 0, 0 };
-    auto rp = [&](int t, int) -> cgptr { return rowptr(t); };
-    mat_pass_block<COLS, ROWS, NCB, false, LOW>(0, t1, rp, colrange, cvec, nosel, xop, cacc, rout);
+    auto rp = [&](int t, int) -> int { return rowptr(t); };
+    mat_pass_block<COLS, ROWS, NCB, false, LOW>(base, 0, t1, rp, colrange, cvec, nosel, xop, cacc, rout);
   }
   template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass1_list(int, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
+  __device__ __forceinline__ void mat_pass1_list(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
                                                  const int (&rsel)[2], const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
-    mat_pass_block<COLS, ROWS, NCB, true, false>(0, t1, rowptr, colrange, cvec, rsel, xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, true, false>(base, 0, t1, rowptr, colrange, cvec, rsel, xop, cacc, rout);
   }
 
   // out = H_s v (symmetric: rows as columns)
@@ -460,7 +463,7 @@ struct DWave
     double acc[1][2] = { { 0.0, 0.0 } };
     const double none[1][2] = { { 0.0, 0.0 } };
     mat_pass1<true, false, 1>(
-      0, nn, [&](int t) -> cgptr { return Hs + (unsigned)(t * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, v, none, acc,
+      Hs, nn, [&](int t) -> int { return t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, v, none, acc,
       scr);
     DW_S(s) out[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
   }
@@ -473,7 +476,7 @@ struct DWave
     double acc[1][2] = { { 0.0, 0.0 } };
     const double xop[1][2] = { { xv[0], xv[1] } };
     mat_pass1<COLS, ROWS, 1>(
-      0, R, [&](int t) -> cgptr { return M + (unsigned)(t * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xop, acc, scr);
+      M, R, [&](int t) -> int { return t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xop, acc, scr);
     if (COLS) {
       DW_S(s) colout[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
     }
@@ -809,18 +812,18 @@ struct DWave
     const int rr = r, ld = nd;
     cgptr W = P.WS();
     double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-    auto rowp = [&](int t) -> cgptr { return W + (unsigned)(t * ld); };
+    auto rowp = [&](int t) -> int { return t * ld; };
     auto tril = [&](int t, int& lo, int& hi) {
       lo = 0;
       hi = t + 1;
     };
     // t = W v (row sums)
     if (rr > 128)
-      mat_pass2<false, true, 2>(0, rr, rowp, tril, none, v, none, scr);
+      mat_pass2<false, true, 2>(W, rr, rowp, tril, none, v, none, scr);
     else {
       const double xop[1][2] = { { v[0][0], v[0][1] } };
       double na[1][2] = { { 0.0, 0.0 } };
-      mat_pass1<false, true, 1>(0, rr, rowp, tril, none[0], xop, na, scr);
+      mat_pass1<false, true, 1>(W, rr, rowp, tril, none[0], xop, na, scr);
     }
     __syncthreads();
     double t[2][2];
@@ -833,12 +836,12 @@ struct DWave
     // v = W^T (t / D) (column sums)
     if (rr > 128) {
       double acc[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-      mat_pass2<true, false, 2>(0, rr, rowp, tril, t, none, acc, scr);
+      mat_pass2<true, false, 2>(W, rr, rowp, tril, t, none, acc, scr);
       DW_B(b) DW_S(s) v[b][s] = (didx(b, s) < rr) ? acc[b][s] : 0.0;
     } else {
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
-      mat_pass1<true, false, 1>(0, rr, rowp, tril, t[0], xn, acc, scr);
+      mat_pass1<true, false, 1>(W, rr, rowp, tril, t[0], xn, acc, scr);
       DW_S(s) v[0][s] = (didx(0, s) < rr) ? acc[0][s] : 0.0;
       DW_S(s) v[1][s] = 0.0;
     }
@@ -975,17 +978,17 @@ struct DWave
     double delta = scc;
     if (rr > 0) {
       double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-      auto rowp = [&](int t) -> cgptr { return W + (unsigned)(t * ld); };
+      auto rowp = [&](int t) -> int { return t * ld; };
       auto tril = [&](int t, int& lo, int& hi) {
         lo = 0;
         hi = t + 1;
       };
       if (rr > 128)
-        mat_pass2<false, true, 2>(0, rr, rowp, tril, none, gv, none, scr);
+        mat_pass2<false, true, 2>(W, rr, rowp, tril, none, gv, none, scr);
       else {
         const double xop[1][2] = { { gv[0][0], gv[0][1] } };
         double na[1][2] = { { 0.0, 0.0 } };
-        mat_pass1<false, true, 1>(0, rr, rowp, tril, none[0], xop, na, scr);
+        mat_pass1<false, true, 1>(W, rr, rowp, tril, none[0], xop, na, scr);
       }
       __syncthreads();
       double tv[2][2], acc = 0.0;
@@ -1001,11 +1004,11 @@ struct DWave
       delta = scc - lane_sum(acc);
       double uacc[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
       if (rr > 128)
-        mat_pass2<true, false, 2>(0, rr, rowp, tril, tv, none, uacc, scr);
+        mat_pass2<true, false, 2>(W, rr, rowp, tril, tv, none, uacc, scr);
       else {
         double a1[1][2] = { { 0.0, 0.0 } };
         const double xn[1][2] = { { 0.0, 0.0 } };
-        mat_pass1<true, false, 1>(0, rr, rowp, tril, tv[0], xn, a1, scr);
+        mat_pass1<true, false, 1>(W, rr, rowp, tril, tv[0], xn, a1, scr);
         uacc[0][0] = a1[0][0];
         uacc[0][1] = a1[0][1];
       }
@@ -1141,7 +1144,7 @@ struct DWave
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
       mat_pass1<true, false, 1, true>(
-        0, nn, [&](int k) -> cgptr { return WU + (unsigned)(k * nn); },
+        WU, nn, [&](int k) -> int { return k * nn; },
         [&](int k, int& lo, int& hi) {
           lo = k;
           hi = nn;
@@ -1158,7 +1161,7 @@ struct DWave
       // s_a = z_a . (t / D) - bd_a over the slots (rows rowid[a] of Zr)
       int rid[2][2];
       DW_B(b) DW_S(s) rid[b][s] = rowid[didx(b, s)];
-      auto zrow = [&](int, int sel) -> cgptr { return Zr + (unsigned)(sel * nn); };
+      auto zrow = [&](int, int sel) -> int { return sel * nn; };
       auto full = [&](int, int& lo, int& hi) {
         lo = 0;
         hi = nn;
@@ -1167,7 +1170,7 @@ struct DWave
         const double xop[1][2] = { { t2[0], t2[1] } };
         double na[1][2] = { { 0.0, 0.0 } };
         double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-        mat_pass2_list<false, true, 1>(0, rr, zrow, full, none, rid, xop, na, scr);
+        mat_pass2_list<false, true, 1>(Zr, rr, zrow, full, none, rid, xop, na, scr);
       }
       __syncthreads();
       DW_B(b) DW_S(s)
@@ -1183,7 +1186,7 @@ struct DWave
       // t1 = (t - Z_J^T dvec) / D
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
-      mat_pass2_list<true, false, 1>(0, rr, zrow, full, bd, rid, xn, acc, scr);
+      mat_pass2_list<true, false, 1>(Zr, rr, zrow, full, bd, rid, xn, acc, scr);
       DW_S(s) t1[s] = (idx(s) < nn) ? (t[s] - acc[0][s]) / dF[s] : 0.0;
     } else {
       DW_S(s) t1[s] = t2[s];
@@ -1193,7 +1196,7 @@ struct DWave
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
       mat_pass1<true, false, 1>(
-        0, nn, [&](int j) -> cgptr { return WL + (unsigned)(j * nn); },
+        WL, nn, [&](int j) -> int { return j * nn; },
         [&](int j, int& lo, int& hi) {
           lo = 0;
           hi = j + 1;
@@ -1349,7 +1352,7 @@ struct DWave
         int rs[2];
         DW_S(s) rs[s] = (idx(s) < listed) ? sid[idx(s)] : 0;
         mat_pass1_list<true, false, 1>(
-          0, listed, [&](int, int sel) -> cgptr { return Cs + (unsigned)(sel * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, cl,
+          Cs, listed, [&](int, int sel) -> int { return sel * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, cl,
           rs, xn, acc, scr + 512);
         DW_S(s) CTzin[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
         __syncthreads();
@@ -1856,16 +1859,22 @@ struct DWave
   }
 
   // reference solver.hpp:882-1077 (Solver::newton_semi_smooth)
-  __device__ __forceinline__ void newton_semi_smooth(double eps_int)
+  // mode != 0: the one linear step in front of the first outer iteration (equality-constrained initial guess, or the active
+  // set of a warm start installed) through the SAME call site of linear_step -- the step's code exists once in the kernel
+  __device__ __forceinline__ void newton_semi_smooth(double eps_int, int mode)
   {
     bool refactorized = false;
     for (long iter = 0; iter <= st.max_iter_in; ++iter) {
-      if (iter == st.max_iter_in) {
+      if (mode == 0 && iter == st.max_iter_in) {
         info.iter += st.max_iter_in + 1;
         break;
       }
-      count(ST_N_NEWTON);
-      if (PQP_UNLIKELY(linear_step(0, eps_int)) && !refactorized) {
+      if (mode == 0)
+        count(ST_N_NEWTON);
+      const bool missed = linear_step(mode, eps_int);
+      if (mode != 0)
+        break;
+      if (PQP_UNLIKELY(missed) && !refactorized) {
         schur_dirty = true; // refinement fallback (solver.hpp:474-532): factor rebuilt, solve + refinement repeated once
         refactorized = true;
         count(ST_N_REFACTORIZE);
@@ -1953,7 +1962,7 @@ struct DWave
     double acc[1][2] = { { 0.0, 0.0 } };
     const double xn[1][2] = { { 0.0, 0.0 } };
     mat_pass1<true, false, 1>(
-      0, R, [&](int t) -> cgptr { return M + (unsigned)(t * nn); }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xn, acc, scr);
+      M, R, [&](int t) -> int { return t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xn, acc, scr);
     DW_S(s) out[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
   }
 
@@ -2267,13 +2276,17 @@ struct DWave
       schur_dirty = !(W.ls_valid && W.mu_eq_fact == info.mu_eq && W.mu_in_fact == info.mu_in);
       schur_incremental = W.ls_edited != 0;
     }
+    bool pend = false; // a Newton loop (or the linear step in front of the first outer iteration) is due: ONE call site below
+    int pend_mode = 0;
+    double pend_eps = 1.0;
     if (do_aset_from_z || do_eq_guess) {
       if (do_aset_from_z) {
         DW_S(c) fl[c] = (fl[c] & 11) | ((idx(c) < ni && z[c] != 0) ? 4 : 0);
       } else {
         DW_S(c) fl[c] = (fl[c] & 11); // (the equality-constrained guess works on the empty active set)
       }
-      linear_step(do_eq_guess ? 1 : 2, 1.0);
+      pend = true;
+      pend_mode = do_eq_guess ? 1 : 2;
     }
 
     // BCL state (solver.hpp:1378-1395)
@@ -2307,7 +2320,59 @@ struct DWave
     }
     UD pl_cache = 0, dl_cache = 0;
     toc(ST_CYC_F_PANEL);
-    while (!done) {
+    for (;;) {
+      if (pend) {
+        newton_semi_smooth(pend_eps, pend_mode);
+        pend = false;
+        tic();
+        if (pend_mode != 0) {
+          // (the iterate the first residual evaluations see)
+          double mz = 0;
+          DW_S(k)
+          {
+            mz = vmax_abs(mz, x[k]);
+            mz = vmax_abs(mz, y[k]);
+            mz = vmax_abs(mz, z[k]);
+          }
+          iterate_zero = lane_max0(mz) == 0.0;
+        } else {
+          iterate_zero = false;
+          gpr_fresh = false;
+          gdr_fresh = false;
+          aty_fresh = false;
+          if (PQP_UNLIKELY(nonfinite)) {
+            info.status = PQP_MAX_ITER_REACHED;
+            break;
+          }
+          if ((info.status == PQP_PRIMAL_INFEASIBLE && !st.primal_infeasibility_solving) || info.status == PQP_DUAL_INFEASIBLE) {
+            vcopy(x, dx); // certificates (solver.hpp:1572-1580)
+            vcopy(y, dy);
+            vcopy(z, dz);
+            break;
+          }
+          if (PQP_UNLIKELY(scaled_eps == st.eps_abs && st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)) {
+            // solver.hpp:1581-1595 : || A^T 1 + C^T 1 ||_inf * eps_abs
+            double one_e[2], one_i[2], t1[2], t2[2];
+            DW_S(k)
+            {
+              one_e[k] = (idx(k) < ne) ? 1.0 : 0.0;
+              one_i[k] = (idx(k) < ni) ? 1.0 : 0.0;
+            }
+            vzero(t1);
+            vzero(t2);
+            if (ne > 0)
+              unscaled_cols(P.A(), ne, one_e, t1);
+            if (ni > 0)
+              unscaled_cols(P.C(), ni, one_i, t2);
+            double m = 0;
+            DW_S(k) if (idx(k) < n) m = vmax_abs(m, t1[k] + t2[k]);
+            scaled_eps = lane_max0(m) * st.eps_abs;
+          }
+          stage = 1;
+        }
+      }
+      if (done)
+        break;
       tic();
       if (st.primal_infeasibility_solving)
         gpr_fresh = false;
@@ -2403,41 +2468,9 @@ struct DWave
           }
         }
         toc(ST_CYC_F_PANEL);
-        newton_semi_smooth(bcl_eta_in);
-        tic();
-        iterate_zero = false;
-        gpr_fresh = false;
-        gdr_fresh = false;
-        aty_fresh = false;
-        if (PQP_UNLIKELY(nonfinite)) {
-          info.status = PQP_MAX_ITER_REACHED;
-          break;
-        }
-        if ((info.status == PQP_PRIMAL_INFEASIBLE && !st.primal_infeasibility_solving) || info.status == PQP_DUAL_INFEASIBLE) {
-          vcopy(x, dx); // certificates (solver.hpp:1572-1580)
-          vcopy(y, dy);
-          vcopy(z, dz);
-          break;
-        }
-        if (PQP_UNLIKELY(scaled_eps == st.eps_abs && st.primal_infeasibility_solving && info.status == PQP_PRIMAL_INFEASIBLE)) {
-          // solver.hpp:1581-1595 : || A^T 1 + C^T 1 ||_inf * eps_abs
-          double one_e[2], one_i[2], t1[2], t2[2];
-          DW_S(k)
-          {
-            one_e[k] = (idx(k) < ne) ? 1.0 : 0.0;
-            one_i[k] = (idx(k) < ni) ? 1.0 : 0.0;
-          }
-          vzero(t1);
-          vzero(t2);
-          if (ne > 0)
-            unscaled_cols(P.A(), ne, one_e, t1);
-          if (ni > 0)
-            unscaled_cols(P.C(), ni, one_i, t2);
-          double m = 0;
-          DW_S(k) if (idx(k) < n) m = vmax_abs(m, t1[k] + t2[k]);
-          scaled_eps = lane_max0(m) * st.eps_abs;
-        }
-        stage = 1;
+        pend = true;
+        pend_mode = 0;
+        pend_eps = bcl_eta_in;
         continue;
       }
       if (stage == 1) {

@@ -10,11 +10,12 @@ mkdir -p $R/gpurun_out
 cd /tmp
 : > $OUT
 rm -rf $R/gpurun_out/dwp_*
-PQP_AB_MODES=wave timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/dwp_trace -- python $R/scripts/gpu_dwave_ab.py 2048 4 > $R/gpurun_out/dwp_trace.log 2>&1
+[ -z "$DWP_ONLY" ] && PQP_AB_MODES=wave timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/dwp_trace -- python $R/scripts/gpu_dwave_ab.py 2048 4 > $R/gpurun_out/dwp_trace.log 2>&1
 tail -4 $R/gpurun_out/dwp_trace.log >> $OUT
 for f in $(find $R/gpurun_out/dwp_trace -name '*kernel_stats.csv'); do echo "== $f" >> $OUT; head -8 $f >> $OUT; done
-for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_ANY SQ_WAVES"; do
   p=$(echo $pass | cut -d' ' -f1)
+  [ -n "$DWP_ONLY" ] && case " $DWP_ONLY " in *" $p "*) ;; *) continue ;; esac
   PQP_AB_MODES=wave timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/dwp_$p -- python $R/scripts/gpu_dwave_ab.py 2048 3 > $R/gpurun_out/dwp_$p.log 2>&1
 done
 cd $R
