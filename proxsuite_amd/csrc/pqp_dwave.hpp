@@ -30,6 +30,9 @@
 
 namespace pqp {
 
+#ifndef PQP_DW_HB
+#define PQP_DW_HB 2
+#endif
 constexpr int DW_MAXDIM = 128; // n, n_eq, n_in <= 128 (one register block each); slots n_eq + n_in <= 256 (two blocks)
 
 // vectors kept in LDS (read at most a few times per Newton step), 128 doubles each, linear by element
@@ -83,23 +86,25 @@ dw_load_pair(cgptr p)
 // stored zeros of a triangular factor).  No branch, no exec masking.
 template<bool LOW>
 __device__ __forceinline__ DPair
-dw_load_row(cgptr base, int rowoff, int col, int clo, int chi)
+dw_load_row(cgptr base, int off8, int nrec8, int col, int clo)
 {
 #ifndef PQP_EMULATED_MFMA
   // one descriptor base per pass (the matrix); the row travels in the scalar offset, which the range check includes
-  // (scripts/probe/buf_soffset.hip): extent = row offset + used length -- two scalar instructions per row
+  // (scripts/probe/buf_soffset.hip): extent = row offset + used bytes.  Both come out of per-pass vectors by v_readlane:
+  // three instructions per row (two broadcasts and the load), no scalar arithmetic
   typedef unsigned pqp_u4 __attribute__((ext_vector_type(4)));
   typedef double pqp_d2v __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (rowoff + chi) * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, nrec8, 0x00020000);
   int off = col * 8;
   if (LOW)
     off = (col + 1 >= clo) ? off : 0x7ffffff0;
-  const pqp_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, rowoff * 8, 0);
+  const pqp_u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, off8, 0);
   const pqp_d2v t = __builtin_bit_cast(pqp_d2v, raw);
   return DPair{ t.x, t.y };
 #else
   DPair r{ 0.0, 0.0 };
-  cgptr row = base + rowoff;
+  cgptr row = base + off8 / 8;
+  const int chi = (nrec8 - off8) / 8;
   if (!LOW || col + 1 >= clo) {
     if (col < chi)
       r.x = row[col];
@@ -315,22 +320,21 @@ struct DWave
   //   T[i][j] += sum_k p_j(16 k + i) * [j == jsel]     one v_mfma_f64_16x16x4 per row (A = the partials, B = a unit column)
   //   rowsum_j = sum_i T[i][j]                          in-lane adds of the four result registers + one more MFMA against ones
   // -------------------------------------------------------------------------------------------------------------
-  // LIST: row t is taken from a list -- rsel holds the list in pair layout (ints), the entry of item t reaches rowptr(t, sel)
-  // through scalar registers like the coefficient.
-  // Loads are BUFFER loads through a per-row descriptor whose extent is the row's used length: lanes beyond it get zeros
-  // without a memory access and without a branch (dw_load_row).  LOW: the row's first used column clo > 0 (an upper
-  // triangular factor): lanes wholly left of it are pushed out of the descriptor's range the same way.
-  // Items past the end of the pass are the last row again with a zero coefficient (cvec is zero beyond its length by
-  // convention and masked here all the same); their row sums are not written.
-  template<bool COLS, bool ROWS, int NCB, bool LIST, bool LOW, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass_block(cgptr base, int kb, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
-                                                 const int (&rsel)[2], const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
+  // The rows of a pass are described by two int vectors in pair layout (Rows1 / Rows2 below): the byte offset of item t's
+  // row from the matrix base and the byte extent its descriptor ends at (offset + used bytes; 0 for an item past the end
+  // of the pass: nothing is fetched) -- contiguous rows, triangular rows and listed rows alike.
+  // Loads are BUFFER loads: lanes beyond the extent get zeros without a memory access and without a branch (dw_load_row).
+  // LOW: row t's first used column is t (an upper triangular factor): lanes wholly left of it are pushed out of range too.
+  // cvec must be zero beyond the length of the pass.
+  template<bool COLS, bool ROWS, int NCB, bool LOW>
+  __device__ __forceinline__ void mat_pass_block(cgptr base, int kb, int t1, const int (&offv)[2], const int (&nrecv)[2],
+                                                 const double (&cvec)[2], const double (&xop)[NCB][2], double (&cacc)[NCB][2],
+                                                 lptr rout)
   {
     const int lo_t = 128 * kb;
     const int hi_t = (t1 < 128 * kb + 128) ? t1 : 128 * kb + 128;
     if (lo_t >= hi_t)
       return;
-    constexpr int DEPTH = (NCB == 1) ? 16 : 8; // rows whose loads are in flight together
     const int lr = lane & 15, lk = lane >> 4;
     double acc2[NCB][2]; // second accumulator set (odd items): two independent FMA chains per column
 #pragma unroll
@@ -338,76 +342,92 @@ struct DWave
       acc2[cb][0] = 0.0;
       acc2[cb][1] = 0.0;
     }
-    for (int g = lo_t; g < hi_t; g += 16) {
-      double p[16];
+    // eight rows: their loads (an item past the end: the descriptor's extent is zero -- nothing is fetched)
+    auto issue = [&](DPair(&v)[8][NCB], int tb) {
 #pragma unroll
-      for (int h0 = 0; h0 < 16; h0 += DEPTH) {
-        DPair v[DEPTH][NCB];
-        double c[DEPTH];
+      for (int u = 0; u < 8; ++u) {
+        const int t = tb + u;
+        const int so = wave_bcast_i(offv[u & 1], (t & 127) >> 1);
+        const int nr = wave_bcast_i(nrecv[u & 1], (t & 127) >> 1);
 #pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-          const int t = g + h0 + u;
-          const bool ok = t < hi_t; // uniform
-          // (an item past the end: the descriptor's extent is zero -- nothing is fetched, whatever the address)
-          const int sel = LIST ? wave_bcast_i(rsel[u & 1], (t & 127) >> 1) : 0;
-          const int ro = ok ? rowptr(t, sel) : 0;
-          int clo, chi;
-          colrange(t, clo, chi);
-          chi = ok ? chi : 0;
+        for (int cb = 0; cb < NCB; ++cb)
+          v[u][cb] = dw_load_row<LOW>(base, so, nr, 128 * cb + 2 * lane, t);
+      }
+    };
+    // eight rows: into the column accumulators / their partial dots
+    auto consume = [&](const DPair(&v)[8][NCB], int tb, double* p8) {
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb)
-            v[u][cb] = dw_load_row<LOW>(base, ro, 128 * cb + 2 * lane, clo, chi);
-          if (COLS) {
-            const double cv = wave_bcast(cvec[u & 1], (t & 127) >> 1);
-            c[u] = ok ? cv : 0.0;
-          }
-        }
-        dw_sched_fence(); // every load of the batch is issued before the first use of one
+      for (int u = 0; u < 8; ++u) {
+        if (COLS) {
+          const int t = tb + u;
+          const double c = wave_bcast(cvec[u & 1], (t & 127) >> 1);
 #pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-          if (COLS) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-              if (u & 1) {
-                acc2[cb][0] = fma(c[u], v[u][cb].x, acc2[cb][0]);
-                acc2[cb][1] = fma(c[u], v[u][cb].y, acc2[cb][1]);
-              } else {
-                cacc[cb][0] = fma(c[u], v[u][cb].x, cacc[cb][0]);
-                cacc[cb][1] = fma(c[u], v[u][cb].y, cacc[cb][1]);
-              }
+          for (int cb = 0; cb < NCB; ++cb) {
+            if (u & 1) {
+              acc2[cb][0] = fma(c, v[u][cb].x, acc2[cb][0]);
+              acc2[cb][1] = fma(c, v[u][cb].y, acc2[cb][1]);
+            } else {
+              cacc[cb][0] = fma(c, v[u][cb].x, cacc[cb][0]);
+              cacc[cb][1] = fma(c, v[u][cb].y, cacc[cb][1]);
             }
           }
-          if (ROWS) {
-            double pv = 0.0;
+        }
+        if (ROWS) {
+          double pv = 0.0;
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-              pv = fma(v[u][cb].x, xop[cb][0], fma(v[u][cb].y, xop[cb][1], pv));
-            p[h0 + u] = pv;
-          }
+          for (int cb = 0; cb < NCB; ++cb)
+            pv = fma(v[u][cb].x, xop[cb][0], fma(v[u][cb].y, xop[cb][1], pv));
+          p8[u] = pv;
         }
       }
-      if (ROWS) {
-        pqp_d4 T;
+    };
+    auto reduce16 = [&](const double* p, int g) {
+      pqp_d4 T;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          T[k] = 0.0;
+      for (int k = 0; k < 4; ++k)
+        T[k] = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-          T = mfma_f64_16x16x4(p[j], (lr == j) ? 1.0 : 0.0, T);
-        const double qv = (T[0] + T[1]) + (T[2] + T[3]);
-        pqp_d4 T2;
+      for (int j = 0; j < 16; ++j)
+        T = mfma_f64_16x16x4(p[j], (lr == j) ? 1.0 : 0.0, T);
+      const double qv = (T[0] + T[1]) + (T[2] + T[3]);
+      pqp_d4 T2;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          T2[k] = 0.0;
-        T2 = mfma_f64_16x16x4(qv, 1.0, T2);
-        if (lr == 0) {
+      for (int k = 0; k < 4; ++k)
+        T2[k] = 0.0;
+      T2 = mfma_f64_16x16x4(qv, 1.0, T2);
+      if (lr == 0) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int t = g + lk + 4 * k;
-            if (t < hi_t)
-              rout[t] = T2[k];
-          }
+        for (int k = 0; k < 4; ++k) {
+          const int t = g + lk + 4 * k;
+          if (t < hi_t)
+            rout[t] = T2[k];
         }
+      }
+    };
+    // Sixteen rows (NCB = 1; eight with two column blocks) are loaded together and then consumed: what bounds a pass is
+    // the number of rows in flight per wavefront (4 VGPRs each), one memory latency per batch.  (A software pipeline over
+    // half batches -- the next eight rows issued while eight are consumed -- keeps FEWER rows in flight on average and was
+    // 20 - 29 % slower: 9.5 - 10.2 ms against 7.9 ms per 2048 C2 QPs, profiles/r06_ab_dwave.txt.)
+    constexpr int HB = (NCB == 1) ? PQP_DW_HB : 1; // half batches of eight rows issued together
+    constexpr int GR = (HB >= 2) ? 8 * HB : 16;    // rows per trip of the loop (a multiple of the 16-row reduction groups)
+    for (int g = lo_t; g < hi_t; g += GR) {
+      double p[GR];
+#pragma unroll
+      for (int h0 = 0; h0 < GR; h0 += 8 * HB) {
+        DPair v[HB][8][NCB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+          issue(v[hb], g + h0 + 8 * hb);
+        dw_sched_fence(); // every load of the batch is issued before the first use of one
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+          consume(v[hb], g + h0 + 8 * hb, p + h0 + 8 * hb);
+      }
+      if (ROWS) {
+#pragma unroll
+        for (int k = 0; k < GR; k += 16)
+          if (g + k < hi_t)
+            reduce16(p + k, g + k);
       }
     }
     if (COLS) {
@@ -418,41 +438,82 @@ struct DWave
       }
     }
   }
+  struct Rows1
+  {
+    int off[2], nrec[2];
+  };
+  struct Rows2
+  {
+    int off[2][2], nrec[2][2];
+  };
+  // R contiguous rows of `stride` doubles, columns [0, len)
+  __device__ __forceinline__ Rows1 rows_full(int stride, int len, int R) const
+  {
+    Rows1 w;
+    DW_S(s)
+    {
+      w.off[s] = idx(s) * stride * 8;
+      w.nrec[s] = (idx(s) < R) ? w.off[s] + len * 8 : 0;
+    }
+    return w;
+  }
+  // ... columns [0, t + 1) of row t (a lower triangular factor)
+  __device__ __forceinline__ Rows1 rows_tril(int stride, int R) const
+  {
+    Rows1 w;
+    DW_S(s)
+    {
+      w.off[s] = idx(s) * stride * 8;
+      w.nrec[s] = (idx(s) < R) ? w.off[s] + (idx(s) + 1) * 8 : 0;
+    }
+    return w;
+  }
+  __device__ __forceinline__ Rows2 rows2_tril(int stride, int R) const
+  {
+    Rows2 w;
+    DW_B(b) DW_S(s)
+    {
+      w.off[b][s] = didx(b, s) * stride * 8;
+      w.nrec[b][s] = (didx(b, s) < R) ? w.off[b][s] + (didx(b, s) + 1) * 8 : 0;
+    }
+    return w;
+  }
+  // listed rows: item t is row sel_t
+  __device__ __forceinline__ Rows1 rows_list(const int (&sel)[2], int stride, int len, int R) const
+  {
+    Rows1 w;
+    DW_S(s)
+    {
+      w.off[s] = sel[s] * stride * 8;
+      w.nrec[s] = (idx(s) < R) ? w.off[s] + len * 8 : 0;
+    }
+    return w;
+  }
+  __device__ __forceinline__ Rows2 rows2_list(const int (&sel)[2][2], int stride, int len, int R) const
+  {
+    Rows2 w;
+    DW_B(b) DW_S(s)
+    {
+      w.off[b][s] = sel[b][s] * stride * 8;
+      w.nrec[b][s] = (didx(b, s) < R) ? w.off[b][s] + len * 8 : 0;
+    }
+    return w;
+  }
   // coefficient vector of up to 256 items (two register blocks)
-  template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass2(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
+  template<bool COLS, bool ROWS, int NCB>
+  __device__ __forceinline__ void mat_pass2(cgptr base, int t1, const Rows2& w, const double (&cvec)[2][2],
                                             const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
-    const int nosel[2] = { 0, 0 };
-    auto rp = [&](int t, int) -> int { return rowptr(t); };
-    mat_pass_block<COLS, ROWS, NCB, false, false>(base, 0, t1, rp, colrange, cvec[0], nosel, xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, false>(base, 0, t1, w.off[0], w.nrec[0], cvec[0], xop, cacc, rout);
     if (t1 > 128)
-      mat_pass_block<COLS, ROWS, NCB, false, false>(base, 1, t1, rp, colrange, cvec[1], nosel, xop, cacc, rout);
-  }
-  // the same over listed rows: rowptr(t, sel) with sel = rsel of item t
-  template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass2_list(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2][2],
-                                                 const int (&rsel)[2][2], const double (&xop)[NCB][2], double (&cacc)[NCB][2],
-                                                 lptr rout)
-  {
-    mat_pass_block<COLS, ROWS, NCB, true, false>(base, 0, t1, rowptr, colrange, cvec[0], rsel[0], xop, cacc, rout);
-    if (t1 > 128)
-      mat_pass_block<COLS, ROWS, NCB, true, false>(base, 1, t1, rowptr, colrange, cvec[1], rsel[1], xop, cacc, rout);
+      mat_pass_block<COLS, ROWS, NCB, false>(base, 1, t1, w.off[1], w.nrec[1], cvec[1], xop, cacc, rout);
   }
   // coefficient vector of up to 128 items
-  template<bool COLS, bool ROWS, int NCB, bool LOW = false, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass1(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
+  template<bool COLS, bool ROWS, int NCB, bool LOW = false>
+  __device__ __forceinline__ void mat_pass1(cgptr base, int t1, const Rows1& w, const double (&cvec)[2],
                                             const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
   {
-    const int nosel[2] = { 0, 0 };
-    auto rp = [&](int t, int) -> int { return rowptr(t); };
-    mat_pass_block<COLS, ROWS, NCB, false, LOW>(base, 0, t1, rp, colrange, cvec, nosel, xop, cacc, rout);
-  }
-  template<bool COLS, bool ROWS, int NCB, typename RowPtr, typename ColRange>
-  __device__ __forceinline__ void mat_pass1_list(cgptr base, int t1, RowPtr rowptr, ColRange colrange, const double (&cvec)[2],
-                                                 const int (&rsel)[2], const double (&xop)[NCB][2], double (&cacc)[NCB][2], lptr rout)
-  {
-    mat_pass_block<COLS, ROWS, NCB, true, false>(base, 0, t1, rowptr, colrange, cvec, rsel, xop, cacc, rout);
+    mat_pass_block<COLS, ROWS, NCB, LOW>(base, 0, t1, w.off, w.nrec, cvec, xop, cacc, rout);
   }
 
   // out = H_s v (symmetric: rows as columns)
@@ -462,9 +523,7 @@ struct DWave
     const int nn = n;
     double acc[1][2] = { { 0.0, 0.0 } };
     const double none[1][2] = { { 0.0, 0.0 } };
-    mat_pass1<true, false, 1>(
-      Hs, nn, [&](int t) -> int { return t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, v, none, acc,
-      scr);
+    mat_pass1<true, false, 1>(Hs, nn, rows_full(nn, nn, nn), v, none, acc, scr);
     DW_S(s) out[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
   }
   // rowout (LDS -> registers, len R) = M x ; colout += M^T c   for a contiguous row-major R x n matrix, one read
@@ -475,8 +534,7 @@ struct DWave
     const int nn = n;
     double acc[1][2] = { { 0.0, 0.0 } };
     const double xop[1][2] = { { xv[0], xv[1] } };
-    mat_pass1<COLS, ROWS, 1>(
-      M, R, [&](int t) -> int { return t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xop, acc, scr);
+    mat_pass1<COLS, ROWS, 1>(M, R, rows_full(nn, nn, R), c, xop, acc, scr);
     if (COLS) {
       DW_S(s) colout[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
     }
@@ -812,18 +870,13 @@ struct DWave
     const int rr = r, ld = nd;
     cgptr W = P.WS();
     double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-    auto rowp = [&](int t) -> int { return t * ld; };
-    auto tril = [&](int t, int& lo, int& hi) {
-      lo = 0;
-      hi = t + 1;
-    };
     // t = W v (row sums)
     if (rr > 128)
-      mat_pass2<false, true, 2>(W, rr, rowp, tril, none, v, none, scr);
+      mat_pass2<false, true, 2>(W, rr, rows2_tril(ld, rr), none, v, none, scr);
     else {
       const double xop[1][2] = { { v[0][0], v[0][1] } };
       double na[1][2] = { { 0.0, 0.0 } };
-      mat_pass1<false, true, 1>(W, rr, rowp, tril, none[0], xop, na, scr);
+      mat_pass1<false, true, 1>(W, rr, rows_tril(ld, rr), none[0], xop, na, scr);
     }
     __syncthreads();
     double t[2][2];
@@ -836,12 +889,12 @@ struct DWave
     // v = W^T (t / D) (column sums)
     if (rr > 128) {
       double acc[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-      mat_pass2<true, false, 2>(W, rr, rowp, tril, t, none, acc, scr);
+      mat_pass2<true, false, 2>(W, rr, rows2_tril(ld, rr), t, none, acc, scr);
       DW_B(b) DW_S(s) v[b][s] = (didx(b, s) < rr) ? acc[b][s] : 0.0;
     } else {
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
-      mat_pass1<true, false, 1>(W, rr, rowp, tril, t[0], xn, acc, scr);
+      mat_pass1<true, false, 1>(W, rr, rows_tril(ld, rr), t[0], xn, acc, scr);
       DW_S(s) v[0][s] = (didx(0, s) < rr) ? acc[0][s] : 0.0;
       DW_S(s) v[1][s] = 0.0;
     }
@@ -978,17 +1031,12 @@ struct DWave
     double delta = scc;
     if (rr > 0) {
       double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-      auto rowp = [&](int t) -> int { return t * ld; };
-      auto tril = [&](int t, int& lo, int& hi) {
-        lo = 0;
-        hi = t + 1;
-      };
       if (rr > 128)
-        mat_pass2<false, true, 2>(W, rr, rowp, tril, none, gv, none, scr);
+        mat_pass2<false, true, 2>(W, rr, rows2_tril(ld, rr), none, gv, none, scr);
       else {
         const double xop[1][2] = { { gv[0][0], gv[0][1] } };
         double na[1][2] = { { 0.0, 0.0 } };
-        mat_pass1<false, true, 1>(W, rr, rowp, tril, none[0], xop, na, scr);
+        mat_pass1<false, true, 1>(W, rr, rows_tril(ld, rr), none[0], xop, na, scr);
       }
       __syncthreads();
       double tv[2][2], acc = 0.0;
@@ -1004,11 +1052,11 @@ struct DWave
       delta = scc - lane_sum(acc);
       double uacc[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
       if (rr > 128)
-        mat_pass2<true, false, 2>(W, rr, rowp, tril, tv, none, uacc, scr);
+        mat_pass2<true, false, 2>(W, rr, rows2_tril(ld, rr), tv, none, uacc, scr);
       else {
         double a1[1][2] = { { 0.0, 0.0 } };
         const double xn[1][2] = { { 0.0, 0.0 } };
-        mat_pass1<true, false, 1>(W, rr, rowp, tril, tv[0], xn, a1, scr);
+        mat_pass1<true, false, 1>(W, rr, rows_tril(ld, rr), tv[0], xn, a1, scr);
         uacc[0][0] = a1[0][0];
         uacc[0][1] = a1[0][1];
       }
@@ -1143,13 +1191,7 @@ struct DWave
       // t = L^{-1} bx = sum_k bx_k W[:, k] (row k of WU, columns k .. n-1)
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
-      mat_pass1<true, false, 1, true>(
-        WU, nn, [&](int k) -> int { return k * nn; },
-        [&](int k, int& lo, int& hi) {
-          lo = k;
-          hi = nn;
-        },
-        bx, xn, acc, scr);
+      mat_pass1<true, false, 1, true>(WU, nn, rows_full(nn, nn, nn), bx, xn, acc, scr);
       DW_S(s)
       {
         t[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
@@ -1161,16 +1203,12 @@ struct DWave
       // s_a = z_a . (t / D) - bd_a over the slots (rows rowid[a] of Zr)
       int rid[2][2];
       DW_B(b) DW_S(s) rid[b][s] = rowid[didx(b, s)];
-      auto zrow = [&](int, int sel) -> int { return sel * nn; };
-      auto full = [&](int, int& lo, int& hi) {
-        lo = 0;
-        hi = nn;
-      };
+      const Rows2 zrows = rows2_list(rid, nn, nn, rr);
       {
         const double xop[1][2] = { { t2[0], t2[1] } };
         double na[1][2] = { { 0.0, 0.0 } };
         double none[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
-        mat_pass2_list<false, true, 1>(Zr, rr, zrow, full, none, rid, xop, na, scr);
+        mat_pass2<false, true, 1>(Zr, rr, zrows, none, xop, na, scr);
       }
       __syncthreads();
       DW_B(b) DW_S(s)
@@ -1186,7 +1224,7 @@ struct DWave
       // t1 = (t - Z_J^T dvec) / D
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
-      mat_pass2_list<true, false, 1>(Zr, rr, zrow, full, bd, rid, xn, acc, scr);
+      mat_pass2<true, false, 1>(Zr, rr, zrows, bd, xn, acc, scr);
       DW_S(s) t1[s] = (idx(s) < nn) ? (t[s] - acc[0][s]) / dF[s] : 0.0;
     } else {
       DW_S(s) t1[s] = t2[s];
@@ -1195,13 +1233,7 @@ struct DWave
       // x = L^{-T} t1 = sum_j t1_j W[j][:] (row j of WL, columns 0 .. j)
       double acc[1][2] = { { 0.0, 0.0 } };
       const double xn[1][2] = { { 0.0, 0.0 } };
-      mat_pass1<true, false, 1>(
-        WL, nn, [&](int j) -> int { return j * nn; },
-        [&](int j, int& lo, int& hi) {
-          lo = 0;
-          hi = j + 1;
-        },
-        t1, xn, acc, scr);
+      mat_pass1<true, false, 1>(WL, nn, rows_tril(nn, nn), t1, xn, acc, scr);
       DW_S(s) bx[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
     }
     bytes((long)nn * (nn + 1) * 8 + (long)rr * nn * 16);
@@ -1351,9 +1383,7 @@ struct DWave
         const double xn[1][2] = { { 0.0, 0.0 } };
         int rs[2];
         DW_S(s) rs[s] = (idx(s) < listed) ? sid[idx(s)] : 0;
-        mat_pass1_list<true, false, 1>(
-          Cs, listed, [&](int, int sel) -> int { return sel * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, cl,
-          rs, xn, acc, scr + 512);
+        mat_pass1<true, false, 1>(Cs, listed, rows_list(rs, nn, nn, listed), cl, xn, acc, scr + 512);
         DW_S(s) CTzin[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
         __syncthreads();
         bytes((long)listed * nn * 8);
@@ -1961,8 +1991,7 @@ struct DWave
     const int nn = n;
     double acc[1][2] = { { 0.0, 0.0 } };
     const double xn[1][2] = { { 0.0, 0.0 } };
-    mat_pass1<true, false, 1>(
-      M, R, [&](int t) -> int { return t * nn; }, [&](int, int& lo, int& hi) { lo = 0; hi = nn; }, c, xn, acc, scr);
+    mat_pass1<true, false, 1>(M, R, rows_full(nn, nn, R), c, xn, acc, scr);
     DW_S(s) out[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
   }
 
