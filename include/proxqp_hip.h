@@ -225,8 +225,12 @@ int pqp_batch_get_stats(pqp_batch* h, int64_t* stats);
  * be NULL).  4095 lines are kept per QP and launch. */
 int pqp_batch_get_trace(pqp_batch* h, int64_t idx, double* records, int64_t capacity, int64_t* n_records);
 
-/* device time of the last solve kernel in milliseconds (HIP events on the launch stream) */
+/* device time of the last solve in milliseconds (HIP events on the launch stream around everything the solve launched) */
 double pqp_batch_last_solve_ms(const pqp_batch* h);
+/* A launch of dense QPs that fills the device is TWO kernels (the 256-thread factorisation prologue and the one-wavefront
+ * iteration kernel behind it, csrc/pqp_dwave.hpp): the part of pqp_batch_last_solve_ms the prologue kernel took, 0 for a
+ * launch of one kernel.  (No counterpart in the reference: measurement only.) */
+double pqp_batch_last_prologue_ms(const pqp_batch* h);
 /* bytes of dynamic LDS and threads per workgroup chosen for this batch */
 int pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes);
 

@@ -114,6 +114,12 @@ def kernel_label(mangled: str) -> str:
     return "%s<%s>" % (m.group(1), ",".join(re.findall(r"Li(\d+)E", m.group(2))))
 
 
+def flags_tag(extra_flags) -> str:
+    """stable name of a flag set (object directory / object suffix of a variant build)"""
+    import hashlib
+    return "v" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]
+
+
 def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_TUS) -> Path:
     """Cross-compiles for gfx950 (works without a GPU).  `out` / `extra_flags` build a variant
     of the library somewhere else (A/B runs: scripts/gpu_ab.sh); `tus` restricts the kernel
@@ -123,9 +129,9 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     lib = Path(out) if out else HIP_LIB
     deps = list(hip_sources()) + hip_headers() + [Path(__file__)]
-    if not force and not extra_flags and _newer(lib, deps):
+    if not force and _newer(lib, deps):
         return lib
-    tag = "default" if not extra_flags else "v%08x" % (hash(tuple(extra_flags)) & 0xffffffff)
+    tag = "default" if not extra_flags else flags_tag(extra_flags)
     odir = OBJ_DIR / tag
     odir.mkdir(parents=True, exist_ok=True)
     flags = hip_flags(extra_flags)
@@ -136,7 +142,11 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
         o = odir / ("kernels_%d.o" % k)
         jobs.append(([hipcc, *flags, *TU_FLAGS.get(k, []), "-DPQP_TU=%d" % k, "-c", str(CSRC / "pqp_kernels.hip"),
                       "-o", str(o)], o))
-    todo = [j for j in jobs if force or extra_flags or not _newer(j[1], deps)]
+    # an object is stale when ITS source, a header or this recipe is newer (an edit of pqp_multi.hip does not recompile
+    # sixteen kernel families)
+    common = hip_headers() + [Path(__file__)]
+    own = {"capi.o": "pqp_capi.hip", "multi.o": "pqp_multi.hip", "calib.o": "pqp_calib.hip"}
+    todo = [j for j in jobs if force or not _newer(j[1], common + [CSRC / own.get(j[1].name, "pqp_kernels.hip")])]
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
         results = list(ex.map(lambda j: _run(j[0]), todo))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *[str(j[1]) for j in jobs]])
@@ -167,7 +177,7 @@ def build_hip_stats(force: bool = False) -> Path:
     deps = list(hip_sources()) + hip_headers() + [Path(__file__)]
     if not force and _newer(lib, deps):
         return lib
-    return build_hip(force=True, extra_flags=("-DPQP_STATS",), out=lib)
+    return build_hip(extra_flags=("-DPQP_STATS",), out=lib)  # (stale objects only)
 
 
 VARIANT_DIR = CSRC / "variants"
@@ -197,9 +207,10 @@ def build_hip_variants(force: bool = False):
     return out
 
 
-def build_tu_variant(tu, extra_flags, out: Path) -> Path:
+def build_tu_variant(tu, extra_flags, out: Path):
     """A/B partner that differs from the product in ONE kernel family: translation unit `tu` recompiled with
-    `extra_flags`, every other object taken from the product build (seconds instead of minutes)."""
+    `extra_flags`, every other object taken from the product build (seconds instead of minutes).  Returns (library path,
+    {kernel: resources})."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     build_hip()
     base = OBJ_DIR / "default"
@@ -208,7 +219,7 @@ def build_tu_variant(tu, extra_flags, out: Path) -> Path:
     tus = [tu] if isinstance(tu, int) else list(tu)
     repl, res = {}, {}
     for t in tus:
-        o = base / ("kernels_%d_%08x.o" % (t, hash(tuple(extra_flags)) & 0xffffffff))
+        o = base / ("kernels_%d_%s.o" % (t, flags_tag(extra_flags)))
         r = _run([hipcc, *hip_flags(tuple(extra_flags)), *TU_FLAGS.get(t, []), "-DPQP_TU=%d" % t, "-c",
                   str(CSRC / "pqp_kernels.hip"), "-o", str(o)])
         repl[t] = o
@@ -231,11 +242,11 @@ def build_oracle(force: bool = False) -> Path:
     return lib
 
 
-def kernel_sources_sha(diag: bool = False) -> str:
+def kernel_sources_sha(diag: bool = False, dwave: bool = False) -> str:
     """sha256 (first 16 hex digits) of the device sources a solve kernel is compiled from: what a PMC traffic figure in
     profiles/pmc_traffic.json was measured on (scripts/merge_pmc_traffic.py stamps it, bench.py compares)"""
     import hashlib
-    files = ["pqp_solver.hpp", "pqp_block.hpp"] + (["pqp_diag.hpp"] if diag else [])
+    files = ["pqp_solver.hpp", "pqp_block.hpp"] + (["pqp_diag.hpp"] if diag or dwave else []) + (["pqp_dwave.hpp"] if dwave else [])
     import re
     h = hashlib.sha256()
     for f in files:

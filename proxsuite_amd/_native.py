@@ -53,7 +53,7 @@ class NativeLib:
                "pqp_batch_update", "pqp_batch_warm_start", "pqp_batch_cleanup", "pqp_batch_reset_qp", "pqp_batch_flush",
                "pqp_batch_solve", "pqp_batch_solve_range", "pqp_batch_solve_subset", "pqp_batch_copy_qp", "pqp_batch_set_stream", "pqp_batch_set_schedule", "pqp_batch_backward", "pqp_batch_backward_range",
                "pqp_batch_get_backward", "pqp_batch_get_results", "pqp_batch_result_device_ptrs", "pqp_batch_pack_results",
-               "pqp_batch_get_scaled", "pqp_batch_get_schur_factor", "pqp_batch_get_stats", "pqp_batch_get_trace", "pqp_batch_last_solve_ms",
+               "pqp_batch_get_scaled", "pqp_batch_get_schur_factor", "pqp_batch_get_stats", "pqp_batch_get_trace", "pqp_batch_last_solve_ms", "pqp_batch_last_prologue_ms",
                "pqp_batch_launch_config", "pqp_batch_solve_async", "pqp_batch_solve_range_async",
                "pqp_batch_solve_subset_async", "pqp_batch_wait", "pqp_batch_enable_host_results",
                "pqp_batch_host_results", "pqp_batch_host_results_fresh", "pqp_batch_own_stream", "pqp_batch_backward_subset",
@@ -105,6 +105,8 @@ class NativeLib:
         L.pqp_batch_get_schur_factor.argtypes = [vp, C.c_int64] + [_DP] * 3 + [C.POINTER(C.c_int32), C.POINTER(C.c_int64), _DP]
         L.pqp_batch_last_solve_ms.argtypes = [vp]
         L.pqp_batch_last_solve_ms.restype = C.c_double
+        L.pqp_batch_last_prologue_ms.argtypes = [vp]
+        L.pqp_batch_last_prologue_ms.restype = C.c_double
         L.pqp_batch_launch_config.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         L.pqp_batch_solve_async.argtypes = [vp]
         L.pqp_batch_solve_range_async.argtypes = [vp, C.c_int64, C.c_int64]
@@ -432,6 +434,12 @@ class Batch:
     @property
     def last_solve_ms(self):
         return self.lib.L.pqp_batch_last_solve_ms(self._h)
+
+    @property
+    def last_prologue_ms(self):
+        """the part of last_solve_ms the 256-thread factorisation prologue took when the launch went to the one-wavefront
+        dense kernel (two kernels per launch); 0 otherwise"""
+        return self.lib.L.pqp_batch_last_prologue_ms(self._h)
 
     def results(self, idx=-1):
         pre = (self.B,) if idx < 0 else ()

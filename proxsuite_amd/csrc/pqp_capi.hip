@@ -442,6 +442,7 @@ pqp_batch_create(int64_t batch_size, int64_t dim, int64_t n_eq, int64_t n_in, in
   }
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
+  HIP_TRY(hipEventCreate(&h->ev_mid));
   *out = h;
   return PQP_OK;
 }
@@ -467,6 +468,8 @@ pqp_batch_destroy(pqp_batch* h)
     (void)hipEventDestroy(h->ev0);
   if (h->ev1)
     (void)hipEventDestroy(h->ev1);
+  if (h->ev_mid)
+    (void)hipEventDestroy(h->ev_mid);
   delete h;
 }
 
@@ -944,6 +947,9 @@ pqp_batch_wait(pqp_batch* h)
   h->solve_in_flight = false;
   HIP_TRY(hipEventSynchronize(h->ev1));
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  h->last_prologue_ms = 0.f;
+  if (h->prologue_timed)
+    HIP_TRY(hipEventElapsedTime(&h->last_prologue_ms, h->ev0, h->ev_mid));
   return finish_solve(h);
 }
 
@@ -1460,6 +1466,14 @@ pqp_batch_last_solve_ms(const pqp_batch* h)
   if (h && h->solve_in_flight) // the time of a solve in flight is known once it has finished
     (void)pqp_batch_wait(const_cast<pqp_batch*>(h));
   return h ? double(h->last_ms) : 0.0;
+}
+
+double
+pqp_batch_last_prologue_ms(const pqp_batch* h)
+{
+  if (h && h->solve_in_flight)
+    (void)pqp_batch_wait(const_cast<pqp_batch*>(h));
+  return h ? double(h->last_prologue_ms) : 0.0;
 }
 
 int

@@ -27,12 +27,17 @@
 #define PQP_DWAVE_HPP
 
 #include "pqp_diag.hpp"
+#include <utility>
 
 namespace pqp {
 
 #ifndef PQP_DW_HB
 #define PQP_DW_HB 2
 #endif
+#ifndef PQP_DW_SCHUR_REG_BLOCKS
+#define PQP_DW_SCHUR_REG_BLOCKS 6
+#endif
+constexpr int DW_SCHUR_REG_BLOCKS = PQP_DW_SCHUR_REG_BLOCKS; // dual blocks of up to 16 x this many slots are factorised in registers
 constexpr int DW_MAXDIM = 128; // n, n_eq, n_in <= 128 (one register block each); slots n_eq + n_in <= 256 (two blocks)
 
 // vectors kept in LDS (read at most a few times per Newton step), 128 doubles each, linear by element
@@ -516,15 +521,21 @@ struct DWave
     mat_pass_block<COLS, ROWS, NCB, LOW>(base, 0, t1, w.off, w.nrec, cvec, xop, cacc, rout);
   }
 
-  // out = H_s v (symmetric: rows as columns)
+  // out = H_s v from the LOWER TRIANGLE of the symmetric H_s alone, one pass: the column sums of the rows' used parts
+  // (j <= i) are the contributions of the lower triangle to out_j, their row sums those of its transpose to out_i, and
+  // the diagonal is in both.  Half the bytes of a pass over H_s (the kernel is bound by them).
   __device__ __forceinline__ void hess_mv(const double (&v)[2], double (&out)[2])
   {
     cgptr Hs = P.Hs();
     const int nn = n;
+    double dg[2];
+    DW_S(s) dg[s] = (idx(s) < nn) ? Hs[(unsigned)(idx(s) * (nn + 1))] : 0.0;
     double acc[1][2] = { { 0.0, 0.0 } };
-    const double none[1][2] = { { 0.0, 0.0 } };
-    mat_pass1<true, false, 1>(Hs, nn, rows_full(nn, nn, nn), v, none, acc, scr);
-    DW_S(s) out[s] = (idx(s) < nn) ? acc[0][s] : 0.0;
+    const double xop[1][2] = { { v[0], v[1] } };
+    mat_pass1<true, true, 1>(Hs, nn, rows_tril(nn, nn), v, xop, acc, scr);
+    __syncthreads();
+    DW_S(s) out[s] = (idx(s) < nn) ? (acc[0][s] + scr[idx(s)]) - dg[s] * v[s] : 0.0;
+    __syncthreads();
   }
   // rowout (LDS -> registers, len R) = M x ; colout += M^T c   for a contiguous row-major R x n matrix, one read
   template<bool COLS, bool ROWS>
@@ -573,6 +584,77 @@ struct DWave
         rowid[a] = (a < ne) ? a : ne + actl[a - ne];
     }
     __syncthreads();
+  }
+
+  // LDL^T of the 16 x 16 diagonal tile in `tile` (LDS, row-major; rows / columns beyond the matrix are identity padding):
+  // one row per lane (lanes 0..15), pivot rows through scalar registers; D into dSl[k0 ..], 1 / D into dinv, the strict lower
+  // part N of L_kk back into `tile`; returns inv(L_kk) = (I - N)(I + N^2)(I + N^4)(I + N^8) in both operand layouts
+  __device__ __forceinline__ TilePair diag_tile_factor(int k0, int rr, lptr dSl, lptr tile, lptr dinv)
+  {
+    const int lr = lane & 15, lk = lane >> 4;
+    TilePair Pm;
+    const int nb = (rr - k0 < 16) ? (rr - k0) : 16;
+    const int rw = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const double v = tile[rw * 16 + c];
+      a[c] = (rw < nb && c < nb) ? v : ((rw == c) ? 1.0 : 0.0); // identity padding
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const double dc = lane_bcast(a[c], c);
+      const double l = a[c] / dc;
+#pragma unroll
+      for (int cp = c + 1; cp < 16; ++cp) {
+        const double mcp = lane_bcast(a[c], cp); // A[cp][c] before scaling
+        if (rw >= cp)
+          a[cp] = fma(-l, mcp, a[cp]);
+      }
+      if (rw > c)
+        a[c] = l;
+    }
+    __syncthreads();
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        tile[rw * 16 + c] = (c < rw) ? a[c] : 0.0; // strict lower N of L_kk
+      double dr = 1.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c == rw)
+          dr = a[c];
+      dinv[rw] = 1.0 / dr;
+      if (rw < nb)
+        dSl[k0 + rw] = dr;
+    }
+    __syncthreads();
+    TilePair N;
+    bool dg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = lk + 4 * q, col = lr;
+      N.x[q] = (row > col) ? tile[row * 16 + col] : 0.0;
+      N.xt[q] = (row < col) ? tile[col * 16 + row] : 0.0;
+      dg[q] = (row == col);
+      Pm.x[q] = (dg[q] ? 1.0 : 0.0) - N.x[q];
+      Pm.xt[q] = (dg[q] ? 1.0 : 0.0) - N.xt[q];
+    }
+    TilePair Sq = tile_mul(N, N);
+#pragma unroll
+    for (int rep = 0; rep < 3; ++rep) {
+      TilePair T = Sq;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (dg[q]) {
+          T.x[q] += 1.0;
+          T.xt[q] += 1.0;
+        }
+      Pm = tile_mul(Pm, T);
+      if (rep < 2)
+        Sq = tile_mul(Sq, Sq);
+    }
+    return Pm;
   }
 
   // Full factorisation of the current slots for r <= 128, ONE pass: the blocked left-looking LDL^T of S = M_J + G_JJ on the
@@ -668,70 +750,7 @@ struct DWave
       for (int q = 0; q < 4; ++q)
         tile[(lk + 4 * q) * 16 + lr] = acc[0][q];
       __syncthreads();
-      TilePair Pm;
-      {
-        const int nb = (rr - k0 < 16) ? (rr - k0) : 16;
-        const int rw = lane & 15;
-        double a[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double v = tile[rw * 16 + c];
-          a[c] = (rw < nb && c < nb) ? v : ((rw == c) ? 1.0 : 0.0); // identity padding
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double dc = lane_bcast(a[c], c);
-          const double l = a[c] / dc;
-#pragma unroll
-          for (int cp = c + 1; cp < 16; ++cp) {
-            const double mcp = lane_bcast(a[c], cp); // A[cp][c] before scaling
-            if (rw >= cp)
-              a[cp] = fma(-l, mcp, a[cp]);
-          }
-          if (rw > c)
-            a[c] = l;
-        }
-        __syncthreads();
-        if (lane < 16) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c)
-            tile[rw * 16 + c] = (c < rw) ? a[c] : 0.0; // strict lower N of L_kk
-          double dr = 1.0;
-#pragma unroll
-          for (int c = 0; c < 16; ++c)
-            if (c == rw)
-              dr = a[c];
-          dinv[rw] = 1.0 / dr;
-          if (rw < nb)
-            dSl[k0 + rw] = dr;
-        }
-        __syncthreads();
-        TilePair N;
-        bool dg[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = lk + 4 * q, col = lr;
-          N.x[q] = (row > col) ? tile[row * 16 + col] : 0.0;
-          N.xt[q] = (row < col) ? tile[col * 16 + row] : 0.0;
-          dg[q] = (row == col);
-          Pm.x[q] = (dg[q] ? 1.0 : 0.0) - N.x[q];
-          Pm.xt[q] = (dg[q] ? 1.0 : 0.0) - N.xt[q];
-        }
-        TilePair Sq = tile_mul(N, N);
-#pragma unroll
-        for (int rep = 0; rep < 3; ++rep) {
-          TilePair T = Sq;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (dg[q]) {
-              T.x[q] += 1.0;
-              T.xt[q] += 1.0;
-            }
-          Pm = tile_mul(Pm, T);
-          if (rep < 2)
-            Sq = tile_mul(Sq, Sq);
-        }
-      }
+      TilePair Pm = diag_tile_factor(k0, rr, dSl, tile, dinv);
       const double dcol = dinv[lr];
       // W(kb, kb) = inv(L_kk)
 #pragma unroll
@@ -821,6 +840,177 @@ struct DWave
     bytes((long)rr * rr * 8 * 2);
   }
 
+  // one step of factor_schur_reg (the block index is a template parameter: every tile index is static)
+  template<int NBR, int kb>
+  __device__ __forceinline__ void schur_reg_step(pqp_d4 (&Ut)[NBR][NBR], pqp_d4 (&Wt)[NBR][NBR], int nbk, int rr, int ld, gptr Wg,
+                                                 lptr dSl, lptr tile, lptr dinv)
+  {
+    if (kb >= nbk) // uniform
+      return;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int k0 = kb * 16;
+    // ---- diagonal tile: one row per lane (lanes 0..15), pivot rows through scalar registers
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      tile[(lk + 4 * q) * 16 + lr] = Ut[kb][kb][q];
+    __syncthreads();
+    toc(ST_CYC_F_WRITEBACK); // (sub-phases of the factorisation, instrumented build: the diagonal tile has arrived)
+    TilePair Pm = diag_tile_factor(k0, rr, dSl, tile, dinv);
+    toc(ST_CYC_S_GATHER); // (... and is factorised)
+    const double dcol = dinv[lr];
+    // W(kb, kb) = inv(L_kk)
+    Wt[kb][kb] = Pm.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = lk + 4 * q, col = lr;
+      const int gr = k0 + row, gc = k0 + col;
+      if (gr < rr && gc < rr && row >= col)
+        Wg[(unsigned)(gr * ld + gc)] = (row > col) ? Pm.x[q] : 1.0;
+    }
+    // ---- the panel to the right of the diagonal tile
+#pragma unroll
+    for (int c = kb + 1; c < NBR; ++c) {
+      if (c < nbk) {
+        const int col = 16 * c + lr;
+        pqp_d4 res;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          res[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          res = mfma_f64_16x16x4(Pm.xt[q] * dcol, (col < rr) ? Ut[kb][c][q] : 0.0, res);
+        Ut[kb][c] = res;
+      }
+    }
+    // ---- block row kb of W = L^{-1}, left of the diagonal
+#pragma unroll
+    for (int c = 0; c < kb; ++c) {
+      pqp_d4 T;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        T[q] = 0.0;
+#pragma unroll
+      for (int p = c; p < kb; ++p) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          T = mfma_f64_16x16x4(Ut[p][kb][q], Wt[p][c][q], T);
+      }
+      pqp_d4 Wij;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        Wij[q] = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        Wij = mfma_f64_16x16x4(Pm.xt[q], T[q], Wij); // inv(L_kk) * T
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Wij[q] = -Wij[q];
+        const int row = k0 + lk + 4 * q;
+        if (row < rr)
+          Wg[(unsigned)(row * ld + 16 * c + lr)] = Wij[q];
+      }
+      Wt[kb][c] = Wij;
+    }
+    // ---- trailing tiles
+#pragma unroll
+    for (int i = kb + 1; i < NBR; ++i) {
+      if (i < nbk) {
+        double an[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          an[q] = -Ut[kb][i][q] * dSl[k0 + 4 * q + lk];
+#pragma unroll
+        for (int j = i; j < NBR; ++j) {
+          if (j < nbk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              Ut[i][j] = mfma_f64_16x16x4(an[q], Ut[kb][j][q], Ut[i][j]);
+          }
+        }
+      }
+    }
+  }
+  template<int NBR, int... KB>
+  __device__ __forceinline__ void schur_reg_steps(pqp_d4 (&Ut)[NBR][NBR], pqp_d4 (&Wt)[NBR][NBR], int nbk, int rr, int ld, gptr Wg,
+                                                  lptr dSl, lptr tile, lptr dinv, std::integer_sequence<int, KB...>)
+  {
+    (schur_reg_step<NBR, KB>(Ut, Wt, nbk, rr, ld, Wg, dSl, tile, dinv), ...);
+  }
+
+  // The same factorisation with every tile in REGISTERS (r <= 16 NBR): S is gathered once (all loads of the upper block
+  // triangle in flight together: one memory round trip), the factor never travels through HBM, W_S is written as it is
+  // formed.  A lone wavefront on a saturated device pays ~5 us per DEPENDENT memory round trip, and the form above has
+  // 1 + 2 kb of them per panel (gather, history of U, history of W: 25 at r = 80 plus the stores they wait for): 34 % of
+  // this kernel's cycles for 5 % of its bytes (profiles/r06_dwave_phases.txt).  Right-looking over statically indexed
+  // tiles in the MFMA result layout; tile (i, j) takes its updates in ascending p with the operands of
+  // factor_schur_fused, so both forms give the same bits:
+  //   step kb:  diagonal tile -> LDS -> L_kk, D_k, inv(L_kk) = Pm                      (as above)
+  //             U(kb, c) <- D_k^{-1} inv(L_kk) U(kb, c)                                c > kb
+  //             U(i, j) -= U(kb, i)^T D_k U(kb, j)                                     kb < i <= j
+  //             W(kb, c) = -inv(L_kk) sum_{p = c}^{kb - 1} U(p, kb)^T W(p, c)           c < kb;  W(kb, kb) = inv(L_kk)
+  // Live tiles: rows <= kb of U right of column kb, the trailing triangle, rows <= kb of W: nbk (nbk + 1) / 2 at every step
+  // (21 tiles = 84 VGPRs at NBR = 6).
+  template<int NBR>
+  __device__ __forceinline__ void factor_schur_reg()
+  {
+    const int rr = r, ld = nd;
+    const int nbk = (rr + 15) >> 4; // <= NBR
+    const int lr = lane & 15, lk = lane >> 4;
+    cgptr G = P.G();
+    gptr Wg = P.WS();
+    lptr dSl = scr, tile = scr + 256, dinv = scr + 512;
+    const double mu_eq = info.mu_eq, mu_in = info.mu_in;
+    pqp_d4 Ut[NBR][NBR]; // i <= j
+    pqp_d4 Wt[NBR][NBR]; // j <= i
+    {
+      int cs[NBR];
+#pragma unroll
+      for (int j = 0; j < NBR; ++j) {
+        const int col = 16 * j + lr;
+        cs[j] = sid[(col < rr) ? col : rr - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < NBR; ++i) {
+        if (i < nbk) { // uniform
+          int rs[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 16 * i + lk + 4 * q;
+            rs[q] = sid[(row < rr) ? row : rr - 1];
+          }
+#pragma unroll
+          for (int j = i; j < NBR; ++j) {
+            if (j < nbk) {
+              const int col = 16 * j + lr;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int row = 16 * i + lk + 4 * q;
+                const bool live = (rs[q] | cs[j]) >= 0;
+                double v = G[(unsigned)((live ? rs[q] : 0) * ld + (live ? cs[j] : 0))];
+                if (row == col)
+                  v = live ? v + ((row < ne) ? mu_eq : mu_in) : 1.0;
+                else
+                  v = live ? v : 0.0;
+                Ut[i][j][q] = (row < rr && col < rr) ? v : 0.0;
+              }
+            }
+          }
+        }
+      }
+    }
+    toc(ST_CYC_F_LOAD);
+    schur_reg_steps<NBR>(Ut, Wt, nbk, rr, ld, Wg, dSl, tile, dinv, std::make_integer_sequence<int, NBR>{});
+    __syncthreads();
+    DW_B(b) DW_S(s)
+    {
+      const int a = didx(b, s);
+      dS[b][s] = (a < rr) ? dSl[a] : 1.0;
+    }
+    __syncthreads();
+    bytes((long)rr * rr * 8);
+  }
+
   // full factorisation of the current slots (holes stay identity rows): blocked LDL^T + row-wise inverse on the matrix
   // cores (pqp_block.hpp, one wavefront); leaves W_S in HBM, D_S in registers
   __device__ __forceinline__ void factor_schur()
@@ -834,7 +1024,10 @@ struct DWave
     }
     __syncthreads();
     if (rr <= 128) {
-      factor_schur_fused();
+      if (rr <= 16 * DW_SCHUR_REG_BLOCKS)
+        factor_schur_reg<DW_SCHUR_REG_BLOCKS>();
+      else
+        factor_schur_fused();
       toc(ST_CYC_F_UPDATE);
       schur_dirty = false;
       schur_incremental = false;
@@ -1298,7 +1491,7 @@ struct DWave
       m = vmax_abs(m, e);
     }
     __syncthreads();
-    bytes(((long)nn * nn + (long)ne * nn + (long)ni * nn) * 8);
+    bytes(((long)nn * (nn + 1) / 2 + (long)ne * nn + (long)ni * nn) * 8);
     return lane_max0(m);
   }
 
@@ -2082,7 +2275,7 @@ struct DWave
     else
       hess_mv(x, hx);
     const bool have_products = aty_fresh;
-    bytes(((iterate_zero ? 0L : (long)n * n) + (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
+    bytes(((iterate_zero ? 0L : (long)n * (n + 1) / 2) + (have_products ? 0L : (long)ne * n + (long)ni * n)) * 8);
     double aty[2], ctz[2];
     if (have_products) {
       vcopy(aty, ATdy);

@@ -64,6 +64,10 @@ struct pqp_batch
   pqp::Cmd* d_cmd = nullptr;
   std::vector<void*> allocs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // dense launches of the one-wavefront kernel are TWO kernels (factorisation prologue + iteration): ev_mid sits between them
+  hipEvent_t ev_mid = nullptr;
+  bool prologue_timed = false; // the last launch recorded ev_mid
+  float last_prologue_ms = 0.f;
   float last_ms = 0.f;
   // Asynchronous solves (pqp_batch_solve*_async): the launch is enqueued, ev1 recorded, nothing waited for.
   // pqp_batch_wait -- or any other entry of the handle, which waits first -- reads the elapsed time, runs the

@@ -110,7 +110,7 @@ int pqp_launch_solve_256_s2(pqp_batch* h);
 int pqp_launch_solve_diag_wave(pqp_batch* h);
 int pqp_diag_wave_slots(int dim);
 int pqp_launch_dense_wave(pqp_batch* h);
-int pqp_launch_prologue(pqp_batch* h);
+int pqp_launch_prologue(pqp_batch* h, long first, long count, hipStream_t stream);
 int pqp_launch_solve_512(pqp_batch* h, bool common);
 int pqp_launch_solve_512_dense(pqp_batch* h, bool common);
 int pqp_launch_solve_1024(pqp_batch* h, bool common);
@@ -236,8 +236,9 @@ pqp_prologue_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
   S.prologue();
 }
 
+// (first, count): the QPs of the launch this call covers (slots of the launch's order); stream: where it is enqueued
 int
-pqp_launch_prologue(pqp_batch* h)
+pqp_launch_prologue(pqp_batch* h, long first, long count, hipStream_t stream)
 {
   const size_t lds = (256 == h->nt) ? h->lds_solve : pqp::lds_bytes(h->dev.d, 256);
   if (lds > 64 * 1024)
@@ -245,8 +246,12 @@ pqp_launch_prologue(pqp_batch* h)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
   const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
-  hipLaunchKernelGGL((pqp_prologue_kernel<256>), dim3((unsigned)h->range_count), dim3(256), lds, h->stream, h->dev,
-                     h->range_first, order);
+  if (order)
+    hipLaunchKernelGGL((pqp_prologue_kernel<256>), dim3((unsigned)count), dim3(256), lds, stream, h->dev, h->range_first,
+                       order + first);
+  else
+    hipLaunchKernelGGL((pqp_prologue_kernel<256>), dim3((unsigned)count), dim3(256), lds, stream, h->dev,
+                       h->range_first + first, order);
   HIP_TRY(hipGetLastError());
   return PQP_OK;
 }
@@ -264,12 +269,18 @@ pqp_dwave_kernel(pqp::Batch batch, long first, const int* __restrict__ order)
   pqp::dwave_solve_body(batch, first + slot, (pqp::lptr)smem);
 }
 
+// Two kernels per launch: the 256-thread factorisation prologue, then the one-wavefront iteration kernel.
+// (Cutting the launch into 2 - 8 chunks on streams of their own, so that a chunk's prologue runs beside the iteration
+// kernel of the chunk before it, changes nothing: 7.67 - 7.93 ms against 7.69 ms per 2048 C2 QPs,
+// profiles/r06_ab_dwave.txt -- the pair is bound by the bytes it moves, not by the order it moves them in.)
 int
 pqp_launch_dense_wave(pqp_batch* h)
 {
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
-  if (int rc = pqp_launch_prologue(h))
+  if (int rc = pqp_launch_prologue(h, 0, h->range_count, h->stream))
     return rc;
+  HIP_TRY(hipEventRecord(h->ev_mid, h->stream));
+  h->prologue_timed = true;
   const bool whole = h->range_first == 0 && h->range_count == h->dev.B;
   const int* order = h->subset_order ? h->subset_order : ((h->lpt && h->order_valid && whole) ? h->d_order : nullptr);
   hipLaunchKernelGGL((pqp_dwave_kernel<PQP_WPS_DENSE_WAVE>), dim3((unsigned)h->range_count), dim3(64), pqp::dwave_lds_bytes(),
@@ -504,7 +515,7 @@ pqp_diag_dispatch(const pqp_batch* h)
 
 // 0: the workgroup kernels; 1: the one-wavefront dense kernel (pqp_dwave.hpp) behind the factorisation prologue.
 // PQP_DENSE_KERNEL=workgroup / wave forces either (the A/B partners of the tests; read per launch).  By default the
-// one-wavefront form takes the launches that fill the device (more workgroups than three per CU).
+// one-wavefront form takes the launches made of full resident rounds (see below).
 size_t
 pqp_dense_wave_lds_bytes()
 {
@@ -521,7 +532,12 @@ pqp_dense_wave_dispatch(const pqp_batch* h, long count)
     return 0;
   if (e && e[0] == 'w' && e[1] == 'a') // "wave"
     return 1;
-  return (count > 3L * h->n_cu) ? 1 : 0;
+  // Measured on C2-shaped batches (profiles/r06_ab_dwave.txt): the one-wavefront kernel keeps 8 QPs per CU resident and
+  // is 4 - 6 % faster than the workgroup kernel when the launch is made of FULL rounds of that many (2048, 4096, 8192 QPs
+  // on 256 CUs); a ragged last round is run at a lone wavefront's latency and loses as much (2304, 2560, 3072 QPs), and
+  // below one round the workgroup kernel's four wavefronts per QP win outright (1024 QPs: 4.6 against 5.6 ms).
+  const long round = 8L * h->n_cu, rem = count % round;
+  return (count >= round - round / 10 && (rem == 0 || rem >= round - round / 10)) ? 1 : 0;
 }
 
 int
@@ -530,6 +546,7 @@ pqp_launch_solve(pqp_batch* h)
   // SPEC = 1: no box constraints, dense Hessian, PrimalDualLDLT engine -- all known at compile time
   const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE &&
                       h->dev.d.backend != PQP_BACKEND_PRIMAL_LDLT;
+  h->prologue_timed = false;
   if (h->vec_scratch) // per-QP vectors beyond the LDS of a CU: the solver runs on an HBM slice per workgroup
     return pqp_launch_solve_hbm(h, common);
   switch (h->nt) {

@@ -457,6 +457,18 @@ pqp_multi_gather_device(pqp_multi* m, int root_shard, double* out)
       bad(r, pqp_last_error());
       break;
     }
+    // direct xGMI copy where the two devices can map each other (enabled once per pair, from the source device: the
+    // current one); otherwise hipMemcpyPeerAsync stages through the host by itself -- slower, still correct
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, h->device, root_dev) == hipSuccess && can) {
+      e = hipDeviceEnablePeerAccess(root_dev, 0);
+      if (e == hipErrorPeerAccessAlreadyEnabled)
+        (void)hipGetLastError(); // (clear the sticky code: not an error)
+      else if (e != hipSuccess) {
+        bad(PQP_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        break;
+      }
+    }
     if ((e = hipMemcpyPeerAsync(dst, root_dev, m->pack[s], h->device, bytes, m->stream[s])) != hipSuccess)
       bad(PQP_ERR_HIP, std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e));
   }

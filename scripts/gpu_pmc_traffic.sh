@@ -26,6 +26,7 @@ import csv, glob, json, sys, collections
 for w in sys.argv[1:]:
     acc = collections.defaultdict(list)          # counter -> one value per launch (summed over its dimension rows)
     dur = []
+    dur_k = collections.defaultdict(list)
     names = set()
     import os
     newest = {}
@@ -33,33 +34,52 @@ for w in sys.argv[1:]:
         d = f.split('/')[1]
         if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
             newest[d] = f  # (gpurun_out accumulates the runs of earlier sessions: the latest one of each pass)
+    SOLVE = ('pqp_solve_kernel', 'pqp_diag_kernel', 'pqp_dwave_kernel', 'pqp_prologue_kernel')
+    # a solve of the one-wavefront dense path is TWO kernels (factorisation prologue + iteration): counters per kernel,
+    # a launch = the sum of the per-kernel medians
+    by_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in newest.values():
         per = collections.defaultdict(float)
         for row in csv.DictReader(open(f)):
-            if 'pqp_solve_kernel' not in row.get('Kernel_Name', '') and 'pqp_diag_kernel' not in row.get('Kernel_Name', ''):
+            kn = row.get('Kernel_Name', '')
+            if not any(k in kn for k in SOLVE):
                 continue
-            names.add(row['Kernel_Name'])
-            per[(row['Counter_Name'], row['Dispatch_Id'])] += float(row['Counter_Value'])
-        for (c, _), v in per.items():
-            acc[c].append(v)
+            names.add(kn)
+            per[(kn, row['Counter_Name'], row['Dispatch_Id'])] += float(row['Counter_Value'])
+        for (kn, c, _), v in per.items():
+            by_kernel[kn][c].append(v)
     traces = glob.glob('gpurun_out/pmct_%s_FETCH_SIZE/**/*kernel_trace.csv' % w, recursive=True)
     for f in sorted(traces, key=os.path.getmtime)[-1:]:
         for row in csv.DictReader(open(f)):
-            if 'pqp_solve_kernel' in row.get('Kernel_Name', '') or 'pqp_diag_kernel' in row.get('Kernel_Name', ''):
-                dur.append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) * 1e-6)
+            kn = row.get('Kernel_Name', '')
+            if any(k in kn for k in SOLVE):
+                dur_k[kn].append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) * 1e-6)
     # per launch: the MEDIAN over the launches of the run -- the steady-state dirty re-solve of an init-ed batch that the
     # timed region of bench.py consists of (the launches that follow a fresh init rewrite the equilibrated matrices and
     # move a third more: they are the first solve, reported separately by the bench line, not the step that is priced)
     def med(v):
         v = sorted(v)
         return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
-    mean = {c: med(v) for c, v in acc.items() if v}
-    out = {"workload": w, "kernel": sorted(names), "launches_per_counter": {c: len(v) for c, v in acc.items()},
+    mean = collections.defaultdict(float)
+    per_kernel = {}
+    for kn, cs in by_kernel.items():
+        per_kernel[kn] = {c: med(v) for c, v in cs.items() if v}
+        for c, v in per_kernel[kn].items():
+            mean[c] += v
+        acc.update({c: v for c, v in cs.items()})
+    mean = dict(mean)
+    dur = [sum(sum(v) / len(v) for v in dur_k.values())] if dur_k else []
+    out = {"workload": w, "kernel": sorted(names), "launches_per_counter": {kn: {c: len(v) for c, v in cs.items()} for kn, cs in by_kernel.items()},
            "per_launch": mean}
+    if len(per_kernel) > 1:
+        out["per_kernel"] = {kn: dict(v, **({"hbm_bytes": 1024.0 * (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE'])} if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v else {}),
+                                       **({"ms_under_profiler": sum(dur_k[kn]) / len(dur_k[kn])} if dur_k.get(kn) else {}))
+                             for kn, v in per_kernel.items()}
     if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
         out["hbm_bytes_per_launch"] = 1024.0 * (2.0 * mean['FETCH_SIZE'] + mean['WRITE_SIZE'])
         out["formula"] = "1024 * (2 * FETCH_SIZE + WRITE_SIZE), separate --pmc passes (profiles/r01_hbm_counter_calibration.txt); per_launch = median over the launches of the run"
-        out["hbm_bytes_every_launch"] = [1024.0 * (2.0 * a + b) for a, b in zip(acc['FETCH_SIZE'], acc['WRITE_SIZE'])]
+        if len(per_kernel) == 1:
+            out["hbm_bytes_every_launch"] = [1024.0 * (2.0 * a + b) for a, b in zip(acc['FETCH_SIZE'], acc['WRITE_SIZE'])]
     if dur:
         out["kernel_ms_under_profiler"] = sum(dur) / len(dur)
     if 'SQ_WAVE_CYCLES' in mean and mean['SQ_WAVE_CYCLES']:

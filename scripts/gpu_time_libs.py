@@ -14,6 +14,7 @@ B = int(os.environ.get("B", B))
 w = bench.Workload(kind, B, n, ne, ni)
 args, kw = w.init_args()
 res = {l: [] for l in libs}
+pro = {l: [] for l in libs}  # the factorisation prologue's part (two-kernel launches of the one-wavefront dense kernel)
 for r in range(rounds):
     for l in libs:
         lib = N.NativeLib(l, legacy=True)
@@ -23,11 +24,16 @@ for r in range(rounds):
             s.eps_abs, s.eps_rel, s.initial_guess = 1e-9, 0.0, 0
         b.init(-1, *args, **kw)
         b.flush()
-        ms = []
+        ms, pm = [], []
         for k in range(8):
             b.solve()
             ms.append(b.last_solve_ms)
+            try:
+                pm.append(b.last_prologue_ms)
+            except AttributeError:
+                pm.append(0.0)
         res[l].append(float(np.mean(ms[2:])))
+        pro[l].append(float(np.mean(pm[2:])))
         b.close()
 for l in libs:
-    print("%-6s %-28s %s  mean %.3f ms  %.0f QPs/s" % (wl, os.path.basename(l), " ".join("%.3f" % v for v in res[l]), np.mean(res[l]), B / np.mean(res[l]) * 1e3))
+    print("%-6s %-28s %s  mean %.3f ms  %.0f QPs/s  (prologue %.3f ms)" % (wl, os.path.basename(l), " ".join("%.3f" % v for v in res[l]), np.mean(res[l]), B / np.mean(res[l]) * 1e3, np.mean(pro[l])))

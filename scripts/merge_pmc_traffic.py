@@ -24,13 +24,16 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_traffic_*.json")
         sys.path.insert(0, root)
         from proxsuite_amd import _build
         diag = any("diag" in k for k in j["kernel"])
+        dwave = any("dwave" in k for k in j["kernel"])
         try:
             commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
         except Exception:
             commit = None
         table["workloads"][w] = {"hbm_bytes_per_launch": j["hbm_bytes_per_launch"], "kernel": j["kernel"],
                                  # what it was measured on: bench.py prints traffic_stale when the kernel sources have changed since
-                                 "kernel_sources_sha": _build.kernel_sources_sha(diag), "measured_at_commit": commit,
+                                 "kernel_sources_sha": _build.kernel_sources_sha(diag, dwave), "measured_at_commit": commit,
+                                 **({"per_kernel": {k: {"hbm_bytes": v.get("hbm_bytes"), "ms_under_profiler": v.get("ms_under_profiler")}
+                                                    for k, v in j["per_kernel"].items()}} if j.get("per_kernel") else {}),
                                  # what the kernel waits for, from the same passes (SQ_* / TCC_* counters)
                                  "counters": {k: j.get(k) for k in ("wait_any_over_wave_cycles", "valu_active_over_wave_cycles",
                                                                      "valu_issue_frac_of_peak", "l2_hit_rate",

@@ -197,7 +197,8 @@ enum
 {
   hipSuccess = 0,
   hipErrorInvalidValue = 1,
-  hipErrorNoDevice = 100
+  hipErrorNoDevice = 100,
+  hipErrorPeerAccessAlreadyEnabled = 704
 };
 enum hipMemcpyKind
 {
@@ -323,6 +324,18 @@ inline hipError_t
 hipHostFree(void* p)
 {
   std::free(p);
+  return hipSuccess;
+}
+// (one emulated device: no peer to map)
+inline hipError_t
+hipDeviceCanAccessPeer(int* can, int, int)
+{
+  *can = 0;
+  return hipSuccess;
+}
+inline hipError_t
+hipDeviceEnablePeerAccess(int, unsigned)
+{
   return hipSuccess;
 }
 inline hipError_t

@@ -579,7 +579,7 @@ def case_determinism(lib, randqp, n=20, ne=5, ni=8, B=6):
     assert np.array_equal(out[0], out[1])
 
 
-def case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk, box=False, dense_backend=0):
+def case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk, box=False, dense_backend=0, exact=True):
     """A QP's result must not depend on how many QPs share its launch: device-filling launches take
     the 128-VGPR builds of the solve kernels (four / two workgroups per CU), small ones the builds with
     the larger register budget (csrc/pqp_kernels.hip) -- same arithmetic in the same order, so the
@@ -596,10 +596,17 @@ def case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk, box=False, den
         b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u, **kw)
         for first in range(0, B, step):
             b.solve(first, min(step, B - first))
-        out.append([a.copy() for a in b.results()[:3]] + [np.array([i.status for i in b.infos()])])
+        out.append([a.copy() for a in b.results()[:3]] +
+                   [np.array([(i.status, i.iter, i.iter_ext, i.mu_updates, i.rho_updates) for i in b.infos()])])
         b.close()
-    for a, c in zip(out[0], out[1]):
-        assert np.array_equal(a, c)
+    if exact:
+        for a, c in zip(out[0], out[1]):
+            assert np.array_equal(a, c)
+    else:
+        # two kernels that sum in different orders (the launch size picks one): same decisions, values to rounding
+        assert np.array_equal(out[0][3], out[1][3])
+        for a, c in zip(out[0][:3], out[1][:3]):
+            assert np.all(np.abs(a - c) <= 1e-10 * (1.0 + np.abs(c)))
     return out[0]
 
 

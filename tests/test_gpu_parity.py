@@ -120,14 +120,26 @@ def test_determinism(lib, randqp):
 @pytest.mark.parametrize("shape", [(100, 50, 100, 1024, 256, False), (100, 50, 100, 1024, 512, False),
                                    (100, 50, 100, 1024, 768, False),
                                    (40, 5, 300, 320, 64, False), (100, 200, 200, 320, 64, True)])
-def test_launch_size_invariance(lib, randqp, shape):
-    """1024 QPs in one launch (four workgroups per CU, pqp_solve_kernel<256,4,1>) against the same QPs in
+def test_launch_size_invariance(lib, randqp, shape, monkeypatch):
+    """(The dense shapes on the 256-thread WORKGROUP kernels, PQP_DENSE_KERNEL=workgroup: by default a device-filling launch
+    of this signature goes to the one-wavefront kernel, which sums in another order -- test_launch_size_wave_vs_workgroup.)
+    1024 QPs in one launch (four workgroups per CU, pqp_solve_kernel<256,4,1>) against the same QPs in
     launches of 256 (a CU per QP: <256,1,1>, the whole register file), of 512 (two per CU: <256,2,1>) and of 768
     (<256,3,1>); 320 QPs of two
     512-thread shapes in one launch (<512,4,.>) against launches of 64 (<512,2,.>), the boxed one on the PrimalLDLT
     engine: bit-identical."""
     n, ne, ni, B, chunk, box = shape
+    monkeypatch.setenv("PQP_DENSE_KERNEL", "workgroup")
     pc.case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk, box=box)
+
+
+@pytest.mark.parametrize("chunk", [256, 768])
+def test_launch_size_wave_vs_workgroup(lib, randqp, chunk, monkeypatch):
+    """The default dispatch: 2048 C2-shaped QPs in one launch take the one-wavefront kernel (csrc/pqp_dwave.hpp behind the
+    factorisation prologue), the same QPs in launches of 256 / 768 a 256-thread workgroup kernel.  Same algorithm and
+    decisions, sums in another order: every Info counter equal, (x, y, z) equal to 1e-10 (1 + |.|)."""
+    monkeypatch.delenv("PQP_DENSE_KERNEL", raising=False)
+    pc.case_launch_size_invariance(lib, randqp, 100, 50, 100, 2048, chunk, exact=False)
 
 
 @pytest.mark.parametrize("shape", [(1500, 300, 600), (60, 10, 1500), (40, 0, 2100)])
