@@ -55,6 +55,22 @@ def test_launch_size_wave_vs_workgroup(lib, randqp, monkeypatch):
     pc.case_launch_size_invariance(lib, randqp, 30, 7, 9, 8, 2, exact=False)
 
 
+@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+def test_dense_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
+    """The dense solver as ONE wavefront per QP (csrc/pqp_dwave.hpp behind the factorisation prologue) -- and, as its A/B
+    partner, the 256-thread workgroup kernel on the same cases (PQP_DENSE_KERNEL forces either): random batches over the
+    shapes its layout distinguishes (odd n, no equalities, no inequalities, a Schur block beyond the 96 slots that are
+    factorised in registers), every initial guess of the state machine (restored / edited factors, warm starts, updates),
+    the infeasibility statuses, the verbose trace: each against the oracle, 1e-10 and equal Info."""
+    monkeypatch.setenv("PQP_DENSE_KERNEL", kernel)
+    for (n, ne, ni, B) in [(10, 2, 3, 3), (33, 8, 11, 3), (12, 0, 9, 2), (9, 5, 0, 2), (50, 25, 50, 2), (64, 60, 70, 2)]:
+        pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B)
+    for guess in InitialGuess:
+        pc.case_state_machine(lib, oracle, randqp, guess)
+    pc.case_infeasibility_statuses(lib, oracle)
+    pc.case_verbose_round_trip(lib, oracle, randqp)
+
+
 @pytest.mark.parametrize("shape", [(120, 100, 100), (40, 5, 300), (130, 10, 20)])
 def test_matrix_core_fallback_paths(lib, oracle, randqp, shape):
     """shapes that leave the register-resident factorisations: a dual Schur block above 112 rows

@@ -204,6 +204,22 @@ def test_full_shape_c5_against_oracle(lib, oracle, randqp, box):
 
 
 @pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+def test_dense_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
+    """the one-wavefront dense kernel (csrc/pqp_dwave.hpp) and its 256-thread A/B partner on the same cases, each against
+    the oracle: random batches over the shapes the register layout distinguishes (odd n, no equalities, no inequalities,
+    n = n_eq = n_in = 128, a Schur block beyond the 96 slots factorised in registers), the state machine under every
+    initial guess, the infeasibility statuses, the verbose trace"""
+    monkeypatch.setenv("PQP_DENSE_KERNEL", kernel)
+    for (n, ne, ni, B) in [(10, 2, 3, 6), (33, 8, 11, 6), (12, 0, 9, 4), (9, 5, 0, 4), (100, 50, 100, 24), (64, 60, 70, 6),
+                           (128, 128, 128, 4), (2, 1, 1, 4)]:
+        pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B)
+    for guess in pc.InitialGuess:
+        pc.case_state_machine(lib, oracle, randqp, guess)
+    pc.case_infeasibility_statuses(lib, oracle)
+    pc.case_verbose_round_trip(lib, oracle, randqp)
+
+
+@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
 def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     """the one-wavefront, register-resident diagonal-structure kernel (csrc/pqp_diag.hpp) and its 256-thread A/B partner
     through the whole solve state machine against the oracle, at the sizes of BASELINE.json configs[4] and at the edges of
