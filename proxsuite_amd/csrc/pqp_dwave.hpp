@@ -413,6 +413,9 @@ struct DWave
     // the number of rows in flight per wavefront (4 VGPRs each), one memory latency per batch.  (A software pipeline over
     // half batches -- the next eight rows issued while eight are consumed -- keeps FEWER rows in flight on average and was
     // 20 - 29 % slower: 9.5 - 10.2 ms against 7.9 ms per 2048 C2 QPs, profiles/r06_ab_dwave.txt.)
+    // (Reducing a batch's row sums BEHIND the loads of the next batch -- the 17 matrix-core instructions of a group are 0.5 us
+    // of the 1.7 us a lone wavefront spends per batch on an idle device -- keeps 32 more VGPRs live across the loads: 428
+    // more spilled registers, 8.73 against 7.69 ms per 2048 C2 QPs and 4.09 against 3.69 ms per 256, profiles/r06_ab_dwave.txt.)
     constexpr int HB = (NCB == 1) ? PQP_DW_HB : 1; // half batches of eight rows issued together
     constexpr int GR = (HB >= 2) ? 8 * HB : 16;    // rows per trip of the loop (a multiple of the 16-row reduction groups)
     for (int g = lo_t; g < hi_t; g += GR) {
