@@ -146,7 +146,11 @@ def build_hip(force: bool = False, extra_flags=(), out: Path = None, tus=KERNEL_
     # sixteen kernel families)
     common = hip_headers() + [Path(__file__)]
     own = {"capi.o": "pqp_capi.hip", "multi.o": "pqp_multi.hip", "calib.o": "pqp_calib.hip"}
-    todo = [j for j in jobs if force or not _newer(j[1], common + [CSRC / own.get(j[1].name, "pqp_kernels.hip")])]
+    # (pqp_dwave.hpp is parsed by every kernel family and instantiated by family 17 alone: inline templates, no code elsewhere)
+    only = {"pqp_dwave.hpp": ("kernels_17.o",)}
+    def deps_of(o):
+        return [h for h in common if h.name not in only or o.name in only[h.name]] + [CSRC / own.get(o.name, "pqp_kernels.hip")]
+    todo = [j for j in jobs if force or not _newer(j[1], deps_of(j[1]))]
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
         results = list(ex.map(lambda j: _run(j[0]), todo))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *[str(j[1]) for j in jobs]])
