@@ -15,6 +15,8 @@ for w in c1 c4 c5 c5box; do
 done
 python bench.py --workload backend --steps 5 --warmup 1 --mpc-steps 0 --cpu-sample 256 > gpurun_out/final/${TAG}_bench_backend_primal_ldlt.log 2>&1
 PQP_BENCH_ONE_DEVICE=1 PQP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --mpc-steps 0 > gpurun_out/final/${TAG}_bench_2ranks_one_gpu.log 2>&1
+# RCCL with one rank (the "nccl" process group on one GPU): pack kernel + all_gather_into_tensor on ROCm tensors
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29547 python bench.py --gpus 1 --rccl-single-rank --steps 3 --warmup 1 --no-cpu-baseline --mpc-steps 0 > gpurun_out/final/${TAG}_bench_rccl_single_rank.log 2>&1
 # BASELINE.json configs[2] at N = 1 (the 16 384 QPs of the 8-GPU configuration in one launch of one handle), every QP against the CPU path
 python bench.py --gpus 1 --total-batch 16384 --steps 5 --warmup 1 --mpc-steps 0 --cpu-sample 16384 > gpurun_out/final/${TAG}_bench_c3_1gpu.log 2>&1
 tail -1 gpurun_out/final/${TAG}_bench_c3_1gpu.log > gpurun_out/final/${TAG}_bench_c3_1gpu.json

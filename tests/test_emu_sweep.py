@@ -38,3 +38,14 @@ def test_random_sweep_small(oracle, randqp, monkeypatch, seed):
     assert r["failures"] == 0 and r["info_mismatch"] == 0, r
     assert r["solved"] + r["unsolved_alike"] + r["forks"] == 7 * 3 * 2, r
     assert r["pdal_forked"] <= 2, r  # (PDAL shapes: the full gate on every QP whose two sides walk the same path)
+
+
+def test_random_sweep_dense_wave_kernel(oracle, randqp, monkeypatch):
+    """a short leg of the sweep with the one-wavefront dense kernel forced on every launch of its signature (csrc/pqp_dwave.hpp)"""
+    import build as emu_build
+    lib = N.NativeLib(emu_build.build())
+    monkeypatch.setenv("PQP_DENSE_KERNEL", "wave")
+    r = pc.case_random_sweep(lib, oracle, randqp, 5, 7, verbose=True, n_range=(2, 22))
+    assert r["failures"] == 0 and r["info_mismatch"] == 0, r
+    assert r["solved"] + r["unsolved_alike"] + r["forks"] == 7 * 3 * 2, r
+    assert r["pdal_forked"] <= 2, r

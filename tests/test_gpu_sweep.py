@@ -40,3 +40,17 @@ def test_random_sweep_large_shapes(oracle, randqp):
     assert r["solved"] >= 40, r
     assert r["forks"] <= 3, r
     assert r["pdal_same_path"] >= 20 and r["pdal_forked"] <= 4, r  # (measured 28 and 2)
+
+
+def test_random_sweep_dense_wave_kernel(oracle, randqp, monkeypatch):
+    """the sweep with the one-wavefront dense kernel forced (PQP_DENSE_KERNEL=wave: every launch of its signature -- dense
+    Hessian, no box, PrimalDualLDLT / Automatic, n, n_eq, n_in <= 128 -- whatever its size), n in 2 .. 60: cold solves, warm
+    re-solves on the restored, edited Schur factor, infeasible instances, PDAL shapes -- same gates as above"""
+    monkeypatch.setenv("PQP_DENSE_KERNEL", "wave")
+    r = pc.case_random_sweep(N.load(), oracle, randqp, 31, 60, n_range=(2, 60))
+    print("sweep wave", r)
+    assert r["failures"] == 0, r
+    assert r["info_mismatch"] == 0, r
+    assert r["solved"] >= 120, r
+    assert r["forks"] <= max(3, 0.08 * (r["unsolved_alike"] + r["forks"])), r
+    assert r["pdal_forked"] <= max(2, 0.05 * (r["pdal_same_path"] + r["pdal_forked"])), r
