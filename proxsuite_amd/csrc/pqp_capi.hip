@@ -913,8 +913,10 @@ solve_impl(pqp_batch* h, int64_t first, int64_t count, const int64_t* idx, bool 
     h->range_first = 0;
     h->range_count = long(count);
     h->subset_order = h->d_order;
+    h->subset_host = &order;
     rc = pqp_launch_solve(h);
     h->subset_order = nullptr;
+    h->subset_host = nullptr;
     h->flight_idx.assign(idx, idx + count);
   } else {
     h->range_first = first;
@@ -1481,7 +1483,7 @@ pqp_batch_launch_config(const pqp_batch* h, int* threads, int64_t* lds_bytes)
 {
   if (!h)
     return fail(PQP_ERR_INVALID_ARGUMENT, "null batch handle");
-  const bool wave = pqp_diag_dispatch(h) == 1; // (known once the set-up kernel has run: pqp_batch_flush)
+  const bool wave = pqp_diag_dispatch(h, true) == 1; // (known once the set-up kernel has run: pqp_batch_flush)
   // (dense QPs: the configuration of a whole-batch launch; a 256-thread factorisation prologue runs in front of the
   // one-wavefront iteration kernel)
   const bool common = h->dev.d.box == 0 && h->dev.d.hessian == PQP_HESSIAN_DENSE && h->dev.d.backend != PQP_BACKEND_PRIMAL_LDLT;

@@ -98,6 +98,7 @@ struct pqp_batch
   long range_first = 0, range_count = 0;
   long setup_first = 0, setup_count = 0; // QPs with a queued init / update / cleanup command
   const int* subset_order = nullptr;     // pqp_batch_solve_subset: slot of workgroup i (device memory)
+  const std::vector<int>* subset_host = nullptr; // ... and the same list on the host, for the duration of the launch call
   // every per-QP device array with its element size and per-QP element count (pqp_batch_copy_qp)
   struct Arr
   {
@@ -152,7 +153,7 @@ struct DeviceGuard
 int pqp_launch_setup(pqp_batch* h);
 int pqp_launch_solve(pqp_batch* h);
 int pqp_diag_wave_slots(int dim); // register slots per vector of that kernel for a dimension (1, 2 or 4)
-int pqp_diag_dispatch(const pqp_batch* h); // 1: the launch goes to the one-wavefront diagonal kernel (pqp_diag.hpp)
+int pqp_diag_dispatch(const pqp_batch* h, bool whole_batch = false); // 1: the launch (or, whole_batch, a launch of every QP) goes to the one-wavefront diagonal kernel (pqp_diag.hpp)
 int pqp_dense_wave_dispatch(const pqp_batch* h, long count); // 1: a launch of `count` QPs goes to the one-wavefront dense kernel (pqp_dwave.hpp)
 size_t pqp_dense_wave_lds_bytes();
 int pqp_launch_backward(pqp_batch* h, const pqp::BackwardArgs& bw, long count);

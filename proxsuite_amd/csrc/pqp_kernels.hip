@@ -497,18 +497,28 @@ pqp_launch_pack(pqp_batch* h, long first, long count, double* out, hipStream_t s
   return PQP_OK;
 }
 
-// 0: the workgroup kernels; 1: every QP of the batch has diagonal structure (signature + the flags the set-up kernel left)
-// and the launch goes to the one-wavefront kernel of pqp_diag.hpp; 2: the same, forced to the 256-thread form of that
-// solver by PQP_DIAG_KERNEL=workgroup (its A/B partner in the tests; read per launch: they switch it between two solves)
+// 0: the workgroup kernels; 1: every QP OF THE LAUNCH (its range or its subset; whole_batch: of the handle) has diagonal
+// structure (signature + the flags the set-up kernel left) and the launch goes to the one-wavefront kernel of pqp_diag.hpp;
+// 2: the same, forced to the 256-thread form of that solver by PQP_DIAG_KERNEL=workgroup (its A/B partner in the tests;
+// read per launch: they switch it between two solves).  (a general QP or a never-initialised slot elsewhere in
+// the handle no longer sends a launch of structured QPs to the 6.5 x slower kernel.)
 int
-pqp_diag_dispatch(const pqp_batch* h)
+pqp_diag_dispatch(const pqp_batch* h, bool whole_batch)
 {
   const pqp::Dims& dd = h->dev.d;
   if (h->nt != 256 || h->vec_scratch || !pqp::diag_structure_signature(dd.hessian, dd.n_eq, dd.n_in, dd.box) || h->c_diag.empty())
     return 0;
-  for (size_t q = 0; q < h->c_diag.size(); ++q)
-    if (!h->c_diag[q])
-      return 0;
+  if (!whole_batch && h->subset_host) {
+    for (int q : *h->subset_host)
+      if (!h->c_diag[size_t(q)])
+        return 0;
+  } else {
+    const size_t lo = whole_batch ? 0 : size_t(h->range_first);
+    const size_t hi = whole_batch ? h->c_diag.size() : std::min(h->c_diag.size(), size_t(h->range_first + h->range_count));
+    for (size_t q = lo; q < hi; ++q)
+      if (!h->c_diag[q])
+        return 0;
+  }
   const char* e = std::getenv("PQP_DIAG_KERNEL");
   return (e && e[0] == 'w') || dd.n > 256 ? 2 : 1;
 }

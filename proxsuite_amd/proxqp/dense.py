@@ -472,14 +472,23 @@ def solve_in_parallel(qps, num_threads=None):
     pools = {}
     for qp in qps:
         pools.setdefault(id(qp._pool), (qp._pool, []))[1].append(qp._slot)
-    launched = []
+    launched, first_error = [], None
     try:
         for pool, slots in pools.values():
             launched.append(pool)
             pool.solve_async(sorted(set(slots)))  # the listed slots of a pool in ONE launch (a QP listed twice is solved once)
-    finally:
-        for pool in launched:  # (also when a later pool refused its launch: nothing stays in flight behind an exception)
+    except Exception as e:  # a pool refused its launch: the ones already in flight are still drained below
+        first_error = e
+    for pool in launched:
+        # every pool is waited for, whatever the others did: nothing stays in flight behind an exception, and the FIRST
+        # error is the one the caller sees (a wait that raises must not hide it, nor leave later pools unwaited)
+        try:
             pool.wait()
+        except Exception as e:
+            if first_error is None:
+                first_error = e
+    if first_error is not None:
+        raise first_error
 
 
 def estimate_minimal_eigen_value_of_symmetric_matrix(H, estimate_method_option=EigenValueEstimateMethodOption.ExactMethod,

@@ -750,6 +750,38 @@ def case_c5(lib, oracle, randqp, B, sample, box, dim=200):
     return x, z
 
 
+def case_diag_mixed_handle(lib, oracle, randqp, dim=24, B=6):
+    """A handle whose QP 0 has a GENERAL constraint matrix beside QPs in diagonal structure: a range / subset launch of the
+    structured ones takes the one-wavefront diagonal kernel (pqp_diag_dispatch looks at the QPs of the launch), the
+    general one and a whole-batch launch the 256-thread kernel -- same HBM state either way; every QP against the oracle
+    after each launch."""
+    H, g, Cm, l, u = c5_models(randqp, B, dim)
+    Cm[0][0, 1] = 0.3  # QP 0: not one variable per row any more
+    hess = HessianType.Diagonal
+    b = N.Batch(B, dim, 0, dim, hessian_type=int(hess), lib=lib)
+    settings_all(b, eps_abs=EPS, eps_rel=0, initial_guess=int(InitialGuess.NO_INITIAL_GUESS))
+    b.init(-1, H, g, None, None, Cm, l, u)
+    qs = oracle_solve_many(oracle, [(H[i], g[i], None, None, Cm[i], l[i], u[i]) for i in range(B)], dim, 0, dim, hessian_type=hess)
+
+    def check(which):
+        x, y, z, se, si, info = b.results()
+        for i in which:
+            assert info[i].status == QPSolverOutput.PROXQP_SOLVED, (i, info[i].status)
+            assert close(x[i], qs[i].results.x) and close(z[i], qs[i].results.z), i
+            bad = info_close(info[i], qs[i].results.info)
+            assert bad is None, (i, bad)
+
+    b.solve(1, B - 1)          # a range of structured QPs
+    check(range(1, B))
+    b.solve(0, 1)              # the general one alone
+    check([0])
+    b.solve_subset([2, 4])     # a subset of structured QPs
+    check([2, 4])
+    b.solve()                  # everything in one launch: the general kernel
+    check(range(B))
+    b.close()
+
+
 def case_diag_wave_flows(lib, oracle, randqp, dim, box, hessian=HessianType.Diagonal, merit=0, B=3, constrained=True):
     """The one-wavefront diagonal-structure kernel (proxsuite_amd/csrc/pqp_diag.hpp) through every entry of the solve
     state machine, mirrored call by call on the oracle: cold solve, dirty re-solve (stored equilibration re-applied),

@@ -167,6 +167,11 @@ def test_c5_forms_small(lib, oracle, randqp):
     assert np.max(np.abs(xa - xb)) <= 1e-7 * (1 + np.max(np.abs(xa)))
 
 
+def test_diag_mixed_handle(lib, oracle, randqp):
+    """range / subset launches of structured QPs out of a handle that also holds a general one (parity_cases.case_diag_mixed_handle)"""
+    pc.case_diag_mixed_handle(lib, oracle, randqp)
+
+
 @pytest.mark.parametrize("kernel", ["wave", "workgroup"])
 def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     """the diagonal-structure solver as one wavefront per QP with its vectors in registers (csrc/pqp_diag.hpp) -- and, as

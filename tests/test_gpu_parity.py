@@ -219,6 +219,11 @@ def test_dense_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     pc.case_verbose_round_trip(lib, oracle, randqp)
 
 
+def test_diag_mixed_handle(lib, oracle, randqp):
+    """range / subset launches of structured QPs out of a handle that also holds a general one (parity_cases.case_diag_mixed_handle)"""
+    pc.case_diag_mixed_handle(lib, oracle, randqp)
+
+
 @pytest.mark.parametrize("kernel", ["wave", "workgroup"])
 def test_diag_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     """the one-wavefront, register-resident diagonal-structure kernel (csrc/pqp_diag.hpp) and its 256-thread A/B partner
