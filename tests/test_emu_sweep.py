@@ -45,7 +45,7 @@ def test_random_sweep_dense_wave_kernel(oracle, randqp, monkeypatch):
     import build as emu_build
     lib = N.NativeLib(emu_build.build())
     monkeypatch.setenv("PQP_DENSE_KERNEL", "wave")
-    r = pc.case_random_sweep(lib, oracle, randqp, 5, 7, verbose=True, n_range=(2, 22))
+    r = pc.case_random_sweep(lib, oracle, randqp, 5, 4, verbose=True, n_range=(2, 16))
     assert r["failures"] == 0 and r["info_mismatch"] == 0, r
-    assert r["solved"] + r["unsolved_alike"] + r["forks"] == 7 * 3 * 2, r
+    assert r["solved"] + r["unsolved_alike"] + r["forks"] == 4 * 3 * 2, r
     assert r["pdal_forked"] <= 2, r
