@@ -58,3 +58,28 @@ def test_device_reproduces_the_reference_binary(path, randqp):
     _check(g, x, y, z, np.array([info[i].status for i in range(B)]), np.array([info[i].iter for i in range(B)]),
            np.array([info[i].iter_ext for i in range(B)]))
     b.close()
+
+
+def test_committed_diag_kernel_sweep_residue():
+    """profiles/r06_diag_kernel_sweep_300.txt: the 300-shape sweep of the diagonal-structure kernels on the MI355X
+    (scripts/diag_kernel_sweep.py, seeds 20 .. 24 x 60 shapes x settings x cold and dirty solve) -- the
+    residue by name, so that it cannot grow unseen: three shapes, all with a ZERO Hessian under a two-iteration inner cap,
+    on all of which the one-wavefront kernel and its 256-thread partner agree bit for bit and differ from the oracle by one
+    Newton iteration or in x beyond 1e-8 (the last-bit sensitivity of the rho-only primal block)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "profiles", "r06_diag_kernel_sweep_300.txt")).read()
+    totals = re.findall(r"diag kernel sweep seed (\d+): (\d+) shapes, (\d+) mismatches", txt)
+    assert [(int(s), int(c)) for s, c, _ in totals] == [(20, 60), (21, 60), (22, 60), (23, 60), (24, 60)]
+    assert sum(int(m) for _, _, m in totals) == 3
+    blocks = txt.split("MISMATCH it ")[1:]
+    seen = []
+    for blk, seed in zip(blocks, (20, 21, 22)):
+        it = int(blk.split()[0])
+        seen.append((seed, it))
+        assert "'hess': 'Zero'" in blk and "'max_iter_in': 2" in blk, blk[:300]
+        wave = re.search(r"wave (\[.*?\]) \n", blk).group(1)
+        wg = re.search(r"wg   (\[.*?\]) \n", blk).group(1)
+        assert wave == wg and "dx 0.0" in blk  # the two device kernels: same counters, identical x
+    assert seen == [(20, 41), (21, 17), (22, 11)]
