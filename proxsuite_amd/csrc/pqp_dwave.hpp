@@ -34,8 +34,13 @@ namespace pqp {
 #ifndef PQP_DW_HB
 #define PQP_DW_HB 2
 #endif
+#ifndef PQP_DW_SCHUR_LAZY
+#define PQP_DW_SCHUR_LAZY 1 // register factorisation of the Schur block: left-looking, S gathered one block row ahead (0: all at once)
+#endif
+// (5 / 6 / 7 / 8 blocks: 8.07 / 7.85 / 8.15 / 7.66 ms per 2048 C2 QPs on one box, profiles/r06_ab_dwave.txt section 11: with eight
+// every block of the signature (r <= 128) is factorised in registers and the memory-resident form drops out of the kernel)
 #ifndef PQP_DW_SCHUR_REG_BLOCKS
-#define PQP_DW_SCHUR_REG_BLOCKS 6
+#define PQP_DW_SCHUR_REG_BLOCKS 8
 #endif
 constexpr int DW_SCHUR_REG_BLOCKS = PQP_DW_SCHUR_REG_BLOCKS; // dual blocks of up to 16 x this many slots are factorised in registers
 constexpr int DW_MAXDIM = 128; // n, n_eq, n_in <= 128 (one register block each); slots n_eq + n_in <= 256 (two blocks)
@@ -843,15 +848,71 @@ struct DWave
     bytes((long)rr * rr * 8 * 2);
   }
 
+  // tiles (i, j >= i) of S = M_J + G_JJ gathered from the Gram cache (sid: slot -> row of G, -1 at a hole)
+  template<int NBR, int i>
+  __device__ __forceinline__ void schur_reg_gather_row(pqp_d4 (&Ut)[NBR][NBR], int nbk, int rr, int ld, cgptr G, double mu_eq, double mu_in)
+  {
+    if (i >= NBR || i >= nbk) // uniform
+      return;
+    constexpr int ii = (i < NBR) ? i : 0;
+    const int lr = lane & 15, lk = lane >> 4;
+    int rs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * ii + lk + 4 * q;
+      rs[q] = sid[(row < rr) ? row : rr - 1];
+    }
+#pragma unroll
+    for (int j = ii; j < NBR; ++j) {
+      if (j < nbk) {
+        const int col = 16 * j + lr;
+        const int cs = sid[(col < rr) ? col : rr - 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * ii + lk + 4 * q;
+          const bool live = (rs[q] | cs) >= 0;
+          double v = G[(unsigned)((live ? rs[q] : 0) * ld + (live ? cs : 0))];
+          if (row == col)
+            v = live ? v + ((row < ne) ? mu_eq : mu_in) : 1.0;
+          else
+            v = live ? v : 0.0;
+          Ut[ii][j][q] = (row < rr && col < rr) ? v : 0.0;
+        }
+      }
+    }
+  }
+
   // one step of factor_schur_reg (the block index is a template parameter: every tile index is static)
   template<int NBR, int kb>
   __device__ __forceinline__ void schur_reg_step(pqp_d4 (&Ut)[NBR][NBR], pqp_d4 (&Wt)[NBR][NBR], int nbk, int rr, int ld, gptr Wg,
-                                                 lptr dSl, lptr tile, lptr dinv)
+                                                 lptr dSl, lptr tile, lptr dinv, cgptr G, double mu_eq, double mu_in)
   {
     if (kb >= nbk) // uniform
       return;
     const int lr = lane & 15, lk = lane >> 4;
     const int k0 = kb * 16;
+    if (PQP_DW_SCHUR_LAZY) {
+      // LEFT-LOOKING with the gather one block row ahead: the loads of row kb + 1 go out before this step computes, and row
+      // kb takes the updates of every earlier step here, in the order the right-looking form applies them (same bits).
+      // S tiles of later rows are not live yet: 11 tiles instead of 21 at the first step, and no burst of 84 gathers that
+      // serialise behind the spills they cause.
+      schur_reg_gather_row<NBR, kb + 1>(Ut, nbk, rr, ld, G, mu_eq, mu_in);
+#pragma unroll
+      for (int p = 0; p < kb; ++p) {
+        double an[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          an[q] = -Ut[p][kb][q] * dSl[16 * p + 4 * q + lk];
+#pragma unroll
+        for (int j = kb; j < NBR; ++j) {
+          if (j < nbk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              Ut[kb][j] = mfma_f64_16x16x4(an[q], Ut[p][j][q], Ut[kb][j]);
+          }
+        }
+      }
+    }
     // ---- diagonal tile: one row per lane (lanes 0..15), pivot rows through scalar registers
     __syncthreads();
 #pragma unroll
@@ -915,10 +976,10 @@ struct DWave
       }
       Wt[kb][c] = Wij;
     }
-    // ---- trailing tiles
+    // ---- trailing tiles (right-looking form)
 #pragma unroll
     for (int i = kb + 1; i < NBR; ++i) {
-      if (i < nbk) {
+      if (!PQP_DW_SCHUR_LAZY && i < nbk) {
         double an[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -936,9 +997,16 @@ struct DWave
   }
   template<int NBR, int... KB>
   __device__ __forceinline__ void schur_reg_steps(pqp_d4 (&Ut)[NBR][NBR], pqp_d4 (&Wt)[NBR][NBR], int nbk, int rr, int ld, gptr Wg,
-                                                  lptr dSl, lptr tile, lptr dinv, std::integer_sequence<int, KB...>)
+                                                  lptr dSl, lptr tile, lptr dinv, cgptr G, double mu_eq, double mu_in,
+                                                  std::integer_sequence<int, KB...>)
   {
-    (schur_reg_step<NBR, KB>(Ut, Wt, nbk, rr, ld, Wg, dSl, tile, dinv), ...);
+    (schur_reg_step<NBR, KB>(Ut, Wt, nbk, rr, ld, Wg, dSl, tile, dinv, G, mu_eq, mu_in), ...);
+  }
+  template<int NBR, int... I>
+  __device__ __forceinline__ void schur_reg_gather_all(pqp_d4 (&Ut)[NBR][NBR], int nbk, int rr, int ld, cgptr G, double mu_eq,
+                                                       double mu_in, std::integer_sequence<int, I...>)
+  {
+    (schur_reg_gather_row<NBR, I>(Ut, nbk, rr, ld, G, mu_eq, mu_in), ...);
   }
 
   // The same factorisation with every tile in REGISTERS (r <= 16 NBR): S is gathered once (all loads of the upper block
@@ -966,44 +1034,12 @@ struct DWave
     const double mu_eq = info.mu_eq, mu_in = info.mu_in;
     pqp_d4 Ut[NBR][NBR]; // i <= j
     pqp_d4 Wt[NBR][NBR]; // j <= i
-    {
-      int cs[NBR];
-#pragma unroll
-      for (int j = 0; j < NBR; ++j) {
-        const int col = 16 * j + lr;
-        cs[j] = sid[(col < rr) ? col : rr - 1];
-      }
-#pragma unroll
-      for (int i = 0; i < NBR; ++i) {
-        if (i < nbk) { // uniform
-          int rs[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 16 * i + lk + 4 * q;
-            rs[q] = sid[(row < rr) ? row : rr - 1];
-          }
-#pragma unroll
-          for (int j = i; j < NBR; ++j) {
-            if (j < nbk) {
-              const int col = 16 * j + lr;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int row = 16 * i + lk + 4 * q;
-                const bool live = (rs[q] | cs[j]) >= 0;
-                double v = G[(unsigned)((live ? rs[q] : 0) * ld + (live ? cs[j] : 0))];
-                if (row == col)
-                  v = live ? v + ((row < ne) ? mu_eq : mu_in) : 1.0;
-                else
-                  v = live ? v : 0.0;
-                Ut[i][j][q] = (row < rr && col < rr) ? v : 0.0;
-              }
-            }
-          }
-        }
-      }
-    }
+    if (PQP_DW_SCHUR_LAZY)
+      schur_reg_gather_row<NBR, 0>(Ut, nbk, rr, ld, G, mu_eq, mu_in); // (row kb + 1 goes out at the top of step kb)
+    else
+      schur_reg_gather_all<NBR>(Ut, nbk, rr, ld, G, mu_eq, mu_in, std::make_integer_sequence<int, NBR>{});
     toc(ST_CYC_F_LOAD);
-    schur_reg_steps<NBR>(Ut, Wt, nbk, rr, ld, Wg, dSl, tile, dinv, std::make_integer_sequence<int, NBR>{});
+    schur_reg_steps<NBR>(Ut, Wt, nbk, rr, ld, Wg, dSl, tile, dinv, G, mu_eq, mu_in, std::make_integer_sequence<int, NBR>{});
     __syncthreads();
     DW_B(b) DW_S(s)
     {

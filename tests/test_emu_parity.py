@@ -69,6 +69,9 @@ def test_dense_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
         pc.case_state_machine(lib, oracle, randqp, guess)
     pc.case_infeasibility_statuses(lib, oracle)
     pc.case_verbose_round_trip(lib, oracle, randqp)
+    # QPLayer backward on the state the forward kernel left in HBM (slot list, W_S, D_S, active-set flags)
+    pc.case_backward(lib, oracle, randqp)
+    pc.case_backward(lib, oracle, randqp, with_dual_terms=False)
 
 
 @pytest.mark.parametrize("shape", [(120, 100, 100), (40, 5, 300), (130, 10, 20)])

@@ -217,6 +217,9 @@ def test_dense_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
         pc.case_state_machine(lib, oracle, randqp, guess)
     pc.case_infeasibility_statuses(lib, oracle)
     pc.case_verbose_round_trip(lib, oracle, randqp)
+    # QPLayer backward on the state the forward kernel left in HBM (slot list, W_S, D_S, active-set flags)
+    pc.case_backward(lib, oracle, randqp)
+    pc.case_backward(lib, oracle, randqp, with_dual_terms=False)
 
 
 def test_diag_mixed_handle(lib, oracle, randqp):
