@@ -73,7 +73,8 @@ CODEGEN_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-ma
 # per translation unit (kernel family, csrc/pqp_kernels.hip): measured on the workload each one serves --
 # C2 +4.3 %, C1 +3.4 %, C4 +2 % with -disable-lsr; the structured / boxed 256-thread kernel (C5: -17 %) and the
 # 512-thread kernels (dense-backend shape: -7 %) keep loop strength reduction
-TU_FLAGS = {18: ["-mllvm", "-disable-lsr"], 1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-mllvm", "-disable-lsr"], 13: ["-mllvm", "-disable-lsr"], 15: ["-mllvm", "-disable-lsr"]}
+TU_FLAGS = {17: ["-mllvm", "-disable-lsr"],  # the one-wavefront dense kernel: 7.65 -> 7.37 ms per 2048 C2 QPs (profiles/r06_ab_dwave.txt section 13)
+            18: ["-mllvm", "-disable-lsr"], 1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-mllvm", "-disable-lsr"], 13: ["-mllvm", "-disable-lsr"], 15: ["-mllvm", "-disable-lsr"]}
 
 
 def hip_flags(extra_flags=()):

@@ -13,6 +13,9 @@ base = B.OBJ_DIR / os.environ.get("OBJ_TAG", "default")  # OBJ_TAG=v29fce601: th
 os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
 flags = [f for f in B.hip_flags(tuple(extra))]
 flags[flags.index(str(B.CSRC))] = src  # -I <csrc> -> the variant's directory
+for drop in filter(None, os.environ.get("DROP_FLAGS", "").split(",")):  # e.g. DROP_FLAGS=-sink-insts-to-avoid-spills
+    i = flags.index(drop)
+    del flags[i - 1:i + 1]  # ("-mllvm", flag)
 repl = {}
 for tu in tus:
     o = os.path.abspath(out) + ".k%d.o" % tu
