@@ -3,8 +3,7 @@
 item 1(i)) from what the instrumented build and the PMC passes measured --
   * device cycles per phase, mean per QP, on a full device (2048 QPs: profiles/r06_dwave_phases.txt, section v2) and on an idle
     one (256 QPs, one wavefront per CU: profiles/r06_dwave_phases_B256.txt),
-  * executed instructions of the two kernels of a launch (rocprofv3 --pmc, profiles/r06_pmc_prologue_variants.txt, build z0g0
-    = the product),
+  * executed instructions of the two kernels of a launch (rocprofv3 --pmc, profiles/r06_pmc_dwave_final.txt),
   * the algorithmic minimum of each phase: its multiply-adds / 64 lanes, from the event counts of the same run.
 The one-wavefront kernel has no PQP_REPEAT_PHASE differencing (a wavefront's phases are not idempotent in registers): the
 instruction counters are per KERNEL, the split over phases is by device cycles.
@@ -33,11 +32,11 @@ def counters(path, tag, kernel):
     return {k: float(v) for k, v in re.findall(r"(\w+)=([\d.e+]+)", line)}
 
 
-full = phases(os.path.join(ROOT, "profiles", "r06_dwave_phases.txt"), "==== v2")
-idle = phases(os.path.join(ROOT, "profiles", "r06_dwave_phases_B256.txt"))
-pm = os.path.join(ROOT, "profiles", "r06_pmc_prologue_variants.txt")
-cw = counters(pm, "libpqp_z0g0", "pqp_dwave_kernel<2>")
-cp = counters(pm, "libpqp_z0g0", "pqp_prologue_kernel<256>")
+full = phases(os.path.join(ROOT, "profiles", "r06_dwave_phases_final.txt"))
+idle = phases(os.path.join(ROOT, "profiles", "r06_dwave_phases_final_B256.txt"))
+pm = os.path.join(ROOT, "profiles", "r06_pmc_dwave_final.txt")
+cw = counters(pm, "libproxqp_hip", "pqp_dwave_kernel<2>")
+cp = counters(pm, "libproxqp_hip", "pqp_prologue_kernel<256>")
 n, ne, ni = 100, 50, 100
 newton, facts = full["n_newton"], full["n_schur_fact"]
 r = ne + full["n_active_final"]  # slots of the dual block at the end of a solve (a little fewer on the way)
@@ -88,17 +87,17 @@ out = {
     "minimum_wave_instructions_per_qp_all_matrix_phases": sum(v for v in fma.values()) / 64.0,
     "phases": rows,
     "reading": "The mat-vec phases (KKT solve, residuals, Schur edits) need ~%.0f k wavefront multiply-add instructions per QP and the "
-               "factorisations (matrix cores) the equivalent of ~%.0f k; the iteration kernel executes 378 k vector "
+               "factorisations (matrix cores) the equivalent of ~%.0f k; the iteration kernel executes 383 k vector "
                "instructions (911 k in the round-5 workgroup kernel): a row of a pass costs 3 instructions to fetch (two "
                "broadcasts of its descriptor fields, the load) and 4 to consume (two broadcasts of its coefficient, two "
                "multiply-adds) plus 17 / 16 matrix-core instructions where its row sum is wanted, so a pass runs at 2 "
-               "useful of ~8 executed vector instructions; the rest is the line search, the active-set bookkeeping and 673 "
-               "spilled registers.  On a FULL device the phases' shares follow their HBM bytes (the kernel moves 31.7 GB per "
-               "launch at 4.7 TB/s); on an IDLE one (the tail of every launch) a batch of 16 rows costs one memory round "
+               "useful of ~8 executed vector instructions; the rest is the line search, the active-set bookkeeping and 757 "
+               "spilled registers.  On a FULL device the phases' shares follow their HBM bytes (the kernel moves 31.2 GB per "
+               "launch at 4.9 TB/s); on an IDLE one (the tail of every launch) a batch of 16 rows costs one memory round "
                "trip (1.2 us) plus its row-sum reduction (0.5 us), ~64 batches per Newton step." % (
                    sum(v for k, v in fma.items() if "factorisation" not in k and "prologue" not in k) / 64e3,
                    sum(v for k, v in fma.items() if "factorisation" in k or "prologue" in k) / 64e3),
-    "sources": ["profiles/r06_dwave_phases.txt", "profiles/r06_dwave_phases_B256.txt", "profiles/r06_pmc_prologue_variants.txt"],
+    "sources": ["profiles/r06_dwave_phases_final.txt", "profiles/r06_dwave_phases_final_B256.txt", "profiles/r06_pmc_dwave_final.txt"],
 }
 json.dump(out, open(os.path.join(ROOT, "profiles", "r06_pmc_c2_insts_by_phase.json"), "w"), indent=1)
 print(json.dumps(out["executed_instructions_per_qp"]["pqp_dwave_kernel<2>"], indent=1))
