@@ -74,7 +74,8 @@ CODEGEN_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-ma
 # C2 +4.3 %, C1 +3.4 %, C4 +2 % with -disable-lsr; the structured / boxed 256-thread kernel (C5: -17 %) and the
 # 512-thread kernels (dense-backend shape: -7 %) keep loop strength reduction
 TU_FLAGS = {17: ["-mllvm", "-disable-lsr"],  # the one-wavefront dense kernel: 7.65 -> 7.37 ms per 2048 C2 QPs (profiles/r06_ab_dwave.txt section 13)
-            18: ["-mllvm", "-disable-lsr"], 1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-mllvm", "-disable-lsr"], 13: ["-mllvm", "-disable-lsr"], 15: ["-mllvm", "-disable-lsr"]}
+            18: ["-mllvm", "-disable-lsr", "-DPQP_ZG_DEPTH=4"],  # the prologue kernel: 4 k-steps of operand loads in flight per lane in its Z / G build (8 elsewhere): 1.026 -> 0.985 ms per 2048 C2 QPs; 2 / 3 / 5 / 6 / 12: 1.000 / 1.003 / 0.986 / 1.020 / 1.467 ms
+            1: ["-mllvm", "-disable-lsr"], 4: ["-mllvm", "-disable-lsr"], 7: ["-mllvm", "-disable-lsr"], 13: ["-mllvm", "-disable-lsr"], 15: ["-mllvm", "-disable-lsr"]}
 
 
 def hip_flags(extra_flags=()):
