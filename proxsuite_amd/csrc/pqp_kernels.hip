@@ -542,12 +542,18 @@ pqp_dense_wave_dispatch(const pqp_batch* h, long count)
     return 0;
   if (e && e[0] == 'w' && e[1] == 'a') // "wave"
     return 1;
-  // Measured on C2-shaped batches (profiles/r06_ab_dwave.txt): the one-wavefront kernel keeps 8 QPs per CU resident and
-  // is 4 - 6 % faster than the workgroup kernel when the launch is made of FULL rounds of that many (2048, 4096, 8192 QPs
-  // on 256 CUs); a ragged last round is run at a lone wavefront's latency and loses as much (2304, 2560, 3072 QPs), and
-  // below one round the workgroup kernel's four wavefronts per QP win outright (1024 QPs: 4.6 against 5.6 ms).
+  // Measured on C2-shaped batches, both kernels at 22 batch sizes (profiles/r06_ab_dwave.txt sections 5 and 17): the
+  // one-wavefront kernel keeps 8 QPs per CU resident; it wins from 0.6 of a resident round upwards (1280 QPs on 256 CUs: +7 %;
+  // 2048: +10 %) and in later rounds whenever the last one is empty or at least 0.4 full (3072: +6 %, 4096: +5 %); a thinner
+  // last round is run at a lone wavefront's latency and ties or loses 1 - 2 % (2304, 2560), and below 0.6 of a round the
+  // workgroup kernel's four wavefronts per QP win outright (1024 QPs: 4.4 against 5.2 ms).  Five other shapes of the
+  // signature behave the same way (section 10).
   const long round = 8L * h->n_cu, rem = count % round;
-  return (count >= round - round / 10 && (rem == 0 || rem >= round - round / 10)) ? 1 : 0;
+  if (count < 64) // (whatever the device: a handful of QPs is a latency problem -- and the one-CU emulated device of the CPU tests
+    return 0;     //  dispatches small launches as a real one does)
+  if (count < round)
+    return (5 * count >= 3 * round) ? 1 : 0;
+  return (rem == 0 || 5 * rem >= 2 * round) ? 1 : 0;
 }
 
 int

@@ -44,15 +44,8 @@ def test_launch_size_invariance(lib, randqp, shape, monkeypatch):
     """the launcher's choice between the two register-budget builds of a solve kernel (by launch
     size; the emulated device has one CU) must not change a result"""
     n, ne, ni, B, chunk = shape
-    monkeypatch.setenv("PQP_DENSE_KERNEL", "workgroup")  # (the one-wavefront kernel sums in another order: next test)
+    monkeypatch.setenv("PQP_DENSE_KERNEL", "workgroup")  # (the one-wavefront kernel, which launches of 64 QPs and more may take, sums in another order: tests/test_gpu_parity.py::test_launch_size_wave_vs_workgroup)
     pc.case_launch_size_invariance(lib, randqp, n, ne, ni, B, chunk)
-
-
-def test_launch_size_wave_vs_workgroup(lib, randqp, monkeypatch):
-    """default dispatch on the emulated one-CU device: 8 QPs = one full resident round of the one-wavefront dense kernel
-    (pqp_dense_wave_dispatch), launches of 2 go to the workgroup kernel: same Info counters, values to rounding"""
-    monkeypatch.delenv("PQP_DENSE_KERNEL", raising=False)
-    pc.case_launch_size_invariance(lib, randqp, 30, 7, 9, 8, 2, exact=False)
 
 
 @pytest.mark.parametrize("kernel", ["wave", "workgroup"])
