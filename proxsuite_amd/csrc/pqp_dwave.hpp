@@ -112,14 +112,19 @@ dw_load_row(cgptr base, int off8, int nrec8, int col, int clo)
   const pqp_d2v t = __builtin_bit_cast(pqp_d2v, raw);
   return DPair{ t.x, t.y };
 #else
+  // (the buffer's range check as the hardware applies it: the byte offset from the base -- row offset + column -- against
+  // the extent; an item past the end of a pass has extent 0 and whatever row offset its stale descriptor holds: nothing is
+  // read.  AddressSanitizer on the CPU build found the first form of this emulation reading in front of the matrix there.)
   DPair r{ 0.0, 0.0 };
-  cgptr row = base + off8 / 8;
-  const int chi = (nrec8 - off8) / 8;
+  auto in_range = [&](int c) {
+    const long o = (long)off8 + 8L * c;
+    return o >= 0 && o + 8 <= (long)nrec8;
+  };
   if (!LOW || col + 1 >= clo) {
-    if (col < chi)
-      r.x = row[col];
-    if (col + 1 < chi)
-      r.y = row[col + 1];
+    if (in_range(col))
+      r.x = base[((long)off8 + 8L * col) / 8];
+    if (in_range(col + 1))
+      r.y = base[((long)off8 + 8L * (col + 1)) / 8];
   }
   return r;
 #endif

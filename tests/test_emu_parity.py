@@ -56,7 +56,7 @@ def test_dense_wave_kernel_flows(lib, oracle, randqp, monkeypatch, kernel):
     factorised in registers), every initial guess of the state machine (restored / edited factors, warm starts, updates),
     the infeasibility statuses, the verbose trace: each against the oracle, 1e-10 and equal Info."""
     monkeypatch.setenv("PQP_DENSE_KERNEL", kernel)
-    for (n, ne, ni, B) in [(10, 2, 3, 3), (33, 8, 11, 3), (12, 0, 9, 2), (9, 5, 0, 2), (50, 25, 50, 2), (64, 60, 70, 2)]:
+    for (n, ne, ni, B) in [(10, 2, 3, 3), (33, 8, 11, 3), (12, 0, 9, 2), (9, 5, 0, 2), (50, 25, 50, 2), (64, 60, 70, 2), (100, 50, 100, 3)]:
         pc.case_random_batch(lib, oracle, randqp, n, ne, ni, B)
     for guess in InitialGuess:
         pc.case_state_machine(lib, oracle, randqp, guess)
