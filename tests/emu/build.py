@@ -37,6 +37,10 @@ def build_variant(tag, defines):
 
 
 def build(force=False, debug=False):
+    # PQP_EMU_LIBRARY=<path>: the emulator tests load that build of the emulator library instead (scripts/dev/emu_asan.sh: the
+    # AddressSanitizer build, with LD_PRELOAD=libasan.so in front of python)
+    if os.environ.get("PQP_EMU_LIBRARY"):
+        return Path(os.environ["PQP_EMU_LIBRARY"])
     csrc = ROOT / "proxsuite_amd" / "csrc"
     srcs = [csrc / "pqp_capi.hip", csrc / "pqp_multi.hip", csrc / "pqp_kernels.hip", csrc / "pqp_calib.hip", HERE / "hip_emu.cpp"]
     deps = srcs + [csrc / "pqp_block.hpp", csrc / "pqp_solver.hpp", csrc / "pqp_host.hpp", csrc / "pqp_diag.hpp", csrc / "pqp_dwave.hpp", HERE / "hip_emu.hpp",
