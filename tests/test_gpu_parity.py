@@ -331,3 +331,59 @@ def test_diag_kernel_settings_sweep():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_kernel_sweep.py"), "2", "60"], capture_output=True, text=True,
                        env=env, timeout=1200)
     assert "60 shapes, 0 mismatches" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_dense_wave_launch_forms(lib, randqp, monkeypatch):
+    """Every launch form of the one-wavefront dense pair at a size its default dispatch takes (2048 C2-shaped QPs: the
+    factorisation prologue and the iteration kernel both walk the same order array): a whole-batch solve, two ranges,
+    a shuffled subset, and the opt-in learned order of a repeated whole-batch solve -- each QP's result must be the
+    whole-batch solve's bit for bit (same kernel, same arithmetic, whatever the order or the slice)."""
+    monkeypatch.delenv("PQP_DENSE_KERNEL", raising=False)
+    B, n, ne, ni = 2048, 100, 50, 100
+    m = randqp.dense_strongly_convex_qp_batch(B, n, ne, ni, 0.15, 1e-2)
+
+    def fresh():
+        b = N.Batch(B, n, ne, ni, lib=lib)
+        pc.settings_all(b, eps_abs=pc.EPS, eps_rel=0)
+        b.init(-1, m.H, m.g, m.A, m.b, m.C, m.l, m.u)
+        return b
+
+    def snap(b):
+        x, y, z, se, si, info = b.results()
+        return x.copy(), y.copy(), z.copy(), np.array([(i.status, i.iter, i.iter_ext, i.mu_updates) for i in info])
+
+    b = fresh()
+    b.solve()
+    assert b.launch_config()[0] == 64 and b.last_prologue_ms > 0  # the pair ran
+    ref = snap(b)
+    assert all(s == 0 for s in ref[3][:, 0])
+    b.close()
+    # two ranges of 1280 + 768 (the second one is below the dispatch's 0.6 of a round: force the pair for both)
+    monkeypatch.setenv("PQP_DENSE_KERNEL", "wave")
+    b = fresh()
+    b.solve(0, 1280)
+    b.solve(1280, 768)
+    got = snap(b)
+    for a, c in zip(ref, got):
+        assert np.array_equal(a, c)
+    b.close()
+    # a shuffled subset of 1500 QPs, then the rest
+    b = fresh()
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(B)
+    b.solve_subset(perm[:1500])
+    b.solve_subset(perm[1500:])
+    got = snap(b)
+    for a, c in zip(ref, got):
+        assert np.array_equal(a, c)
+    b.close()
+    monkeypatch.delenv("PQP_DENSE_KERNEL", raising=False)
+    # the learned longest-first order: the second whole-batch solve is dispatched through the order array
+    b = fresh()
+    b.set_schedule(True)
+    b.solve()
+    b.solve()
+    got = snap(b)
+    for a, c in zip(ref, got):
+        assert np.array_equal(a, c)
+    b.close()
